@@ -1,0 +1,213 @@
+"""oxDNA configuration / trajectory text files <-> dense arrays.
+
+File layout (reference: mythos/input/trajectory.py:192-331): per frame three
+header lines ``t = ..``, ``b = ..``, ``E = ..`` then one row per nucleotide
+``com(3) a1(3) a3(3) v(3) L(3)``.  Memory order is oxDNA-classic 3'->5'; files
+written against a new-format topology are 5'->3' and are reversed per strand on
+load when ``is_5p_3p=True`` (:309-313).
+
+The whole file is parsed in one ``numpy`` pass into an (S, N, 15) fp64 block; the
+axes -> quaternion conversion goes directly from the rotation matrix
+``[a1 a2 a3]`` (Shepperd's method) instead of through Tait-Bryan angles
+(reference: mythos/utils/math.py:9-65) - same rotation, no gimbal branch.
+"""
+
+from __future__ import annotations
+
+import dataclasses as dc
+import itertools
+from pathlib import Path
+
+import numpy as np
+
+ERR_TRAJECTORY_FILE_NOT_FOUND = "Trajectory file not found: {}"
+ERR_N_NUCLEOTIDE_STRAND_LENGTHS = "n_nucleotides and sum(strand_lengths) do not match"
+ERR_FIXED_BOX_SIZE = "Only trajecories in a fixed box size are supported"
+ERR_STATE_SHAPE = "Invalid shape for nucleotide states:"
+
+
+def axes_to_quaternion(a1: np.ndarray, a3: np.ndarray) -> np.ndarray:
+    """Unit quaternions [q0=w, q1, q2, q3] whose rotation matrix has columns a1, a3 x a1, a3.
+
+    Inverse of the reference's ``q_to_back_base`` / ``q_to_base_normal``
+    (mythos/energy/utils.py:18-29). Works on (..., 3) arrays; sign fixed to q0 >= 0.
+    """
+    a1 = np.asarray(a1, dtype=np.float64)
+    a3 = np.asarray(a3, dtype=np.float64)
+    a2 = np.cross(a3, a1)
+    m00, m10, m20 = a1[..., 0], a1[..., 1], a1[..., 2]
+    m01, m11, m21 = a2[..., 0], a2[..., 1], a2[..., 2]
+    m02, m12, m22 = a3[..., 0], a3[..., 1], a3[..., 2]
+    tr = m00 + m11 + m22
+    # four candidate pivots; pick the largest for stability
+    cand = np.stack([tr, m00, m11, m22], axis=-1)
+    piv = np.argmax(cand, axis=-1)
+    q = np.empty(a1.shape[:-1] + (4,), dtype=np.float64)
+
+    def fill(mask, w, x, y, z):
+        q[mask, 0], q[mask, 1], q[mask, 2], q[mask, 3] = w[mask], x[mask], y[mask], z[mask]
+
+    with np.errstate(invalid="ignore"):
+        s0 = np.sqrt(np.maximum(1.0 + tr, 0.0)) * 2.0
+        s1 = np.sqrt(np.maximum(1.0 + m00 - m11 - m22, 0.0)) * 2.0
+        s2 = np.sqrt(np.maximum(1.0 - m00 + m11 - m22, 0.0)) * 2.0
+        s3 = np.sqrt(np.maximum(1.0 - m00 - m11 + m22, 0.0)) * 2.0
+        fill(piv == 0, 0.25 * s0, (m21 - m12) / s0, (m02 - m20) / s0, (m10 - m01) / s0)
+        fill(piv == 1, (m21 - m12) / s1, 0.25 * s1, (m01 + m10) / s1, (m02 + m20) / s1)
+        fill(piv == 2, (m02 - m20) / s2, (m01 + m10) / s2, 0.25 * s2, (m12 + m21) / s2)
+        fill(piv == 3, (m10 - m01) / s3, (m02 + m20) / s3, (m12 + m21) / s3, 0.25 * s3)
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    q *= np.where(q[..., :1] < 0, -1.0, 1.0)
+    return q
+
+
+def quaternion_to_axes(q: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """a1, a2, a3 from quaternions, un-normalised formulas of mythos/energy/utils.py:18-36."""
+    q0, q1, q2, q3 = (q[..., k] for k in range(4))
+    a1 = np.stack([q0**2 + q1**2 - q2**2 - q3**2, 2 * (q1 * q2 + q0 * q3), 2 * (q1 * q3 - q0 * q2)], axis=-1)
+    a2 = np.stack([2 * (q1 * q2 - q0 * q3), q0**2 - q1**2 + q2**2 - q3**2, 2 * (q2 * q3 + q0 * q1)], axis=-1)
+    a3 = np.stack([2 * (q1 * q3 + q0 * q2), 2 * (q2 * q3 - q0 * q1), q0**2 - q1**2 - q2**2 + q3**2], axis=-1)
+    return a1, a2, a3
+
+
+@dc.dataclass(frozen=True)
+class NucleotideState:
+    """One frame, (N, 15) rows of com a1 a3 v L (reference: trajectory.py:125-182)."""
+
+    array: np.ndarray
+
+    def __post_init__(self) -> None:
+        if not isinstance(self.array, np.ndarray):
+            raise TypeError("Invalid type for nucleotide states:" + str(type(self.array)))
+        if self.array.ndim != 2 or self.array.shape[1] != 15:
+            raise ValueError(ERR_STATE_SHAPE + str(self.array.shape))
+
+    @property
+    def com(self):
+        return self.array[:, :3]
+
+    @property
+    def back_base_vector(self):
+        return self.array[:, 3:6]
+
+    @property
+    def base_normal(self):
+        return self.array[:, 6:9]
+
+    @property
+    def velocity(self):
+        return self.array[:, 9:12]
+
+    @property
+    def angular_velocity(self):
+        return self.array[:, 12:15]
+
+    @property
+    def quaternions(self):
+        return axes_to_quaternion(self.back_base_vector, self.base_normal)
+
+
+@dc.dataclass(frozen=True)
+class Trajectory:
+    """A parsed oxDNA trajectory (reference: trajectory.py:37-122)."""
+
+    n_nucleotides: int
+    strand_lengths: list
+    times: np.ndarray
+    energies: np.ndarray
+    frames: np.ndarray  # (S, N, 15) float64
+    box_size: np.ndarray | None = None
+
+    def __post_init__(self) -> None:
+        if self.n_nucleotides != int(sum(self.strand_lengths)):
+            raise ValueError(ERR_N_NUCLEOTIDE_STRAND_LENGTHS)
+        if len(self.times) != len(self.energies) or len(self.times) != len(self.frames):
+            raise ValueError("times, energies, and states do not have the same length")
+
+    @property
+    def states(self) -> list[NucleotideState]:
+        return [NucleotideState(array=f) for f in self.frames]
+
+    @property
+    def center(self) -> np.ndarray:
+        return np.ascontiguousarray(self.frames[:, :, :3])
+
+    @property
+    def a1(self) -> np.ndarray:
+        return np.ascontiguousarray(self.frames[:, :, 3:6])
+
+    @property
+    def a3(self) -> np.ndarray:
+        return np.ascontiguousarray(self.frames[:, :, 6:9])
+
+    @property
+    def quaternions(self) -> np.ndarray:
+        """(S, N, 4) unit quaternions; the ``state_rigid_body`` orientation of the reference."""
+        return axes_to_quaternion(self.a1, self.a3)
+
+    def slice(self, key) -> "Trajectory":
+        if isinstance(key, int):
+            key = slice(key, key + 1)
+        return Trajectory(
+            n_nucleotides=self.n_nucleotides,
+            strand_lengths=self.strand_lengths,
+            times=self.times[key],
+            energies=self.energies[key],
+            frames=self.frames[key],
+            box_size=self.box_size,
+        )
+
+    def to_file(self, filepath) -> None:
+        box = self.box_size if self.box_size is not None else (0, 0, 0)
+        with Path(filepath).open("w") as f:
+            for t, e, fr in zip(self.times, self.energies, self.frames):
+                write_state(f, float(t), e, fr, box)
+
+
+def write_state(file, time, energies, state, box_size=(0, 0, 0)) -> None:
+    """Append one frame in oxDNA text format (reference: trajectory.py:322-331)."""
+    file.write(f"t = {time}\n")
+    file.write(f"b = {box_size[0]} {box_size[1]} {box_size[2]}\n")
+    file.write(f"E = {energies[0]} {energies[1]} {energies[2]}\n")
+    np.savetxt(file, np.asarray(state), fmt="%.15g")
+
+
+def from_file(path, strand_lengths, *, is_5p_3p: bool = True, n_processes: int = 1) -> Trajectory:  # noqa: ARG001
+    """Parse an oxDNA trajectory / configuration file."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(ERR_TRAJECTORY_FILE_NOT_FOUND.format(path))
+    strand_lengths = [int(s) for s in strand_lengths]
+    n = int(sum(strand_lengths))
+    ts, bs, es, rows = [], [], [], []
+    with path.open() as f:
+        for line in f:
+            c = line[0]
+            if c == "t":
+                ts.append(float(line.split("=")[1]))
+            elif c == "b":
+                bs.append(np.array(line.split("=")[1].split(), dtype=np.float64))
+            elif c == "E":
+                es.append(np.array(line.split("=")[1].split(), dtype=np.float64))
+            elif line.strip():
+                rows.append(line)
+    data = np.loadtxt(rows, dtype=np.float64, ndmin=2) if rows else np.zeros((0, 15))
+    n_frames = len(ts)
+    if data.shape[0] != n_frames * n:
+        raise ValueError(ERR_N_NUCLEOTIDE_STRAND_LENGTHS)
+    frames = data.reshape(n_frames, n, 15)
+    if is_5p_3p:
+        bounds = list(itertools.accumulate([0, *strand_lengths]))
+        order = np.concatenate([np.arange(s, e)[::-1] for s, e in itertools.pairwise(bounds)])
+        frames = frames[:, order, :]
+    bs_arr = np.array(bs)
+    if len(bs_arr) and not np.all(bs_arr == bs_arr[0]):
+        raise ValueError(ERR_FIXED_BOX_SIZE)
+    return Trajectory(
+        n_nucleotides=n,
+        strand_lengths=strand_lengths,
+        times=np.array(ts, dtype=np.float64),
+        energies=np.array(es, dtype=np.float64).reshape(n_frames, 3),
+        frames=np.ascontiguousarray(frames),
+        box_size=bs_arr[0] if len(bs_arr) else None,
+    )

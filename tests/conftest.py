@@ -1,0 +1,23 @@
+"""pytest configuration: markers, repo root on sys.path, golden-fixture helpers."""
+
+import sys
+import warnings
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    warnings.filterwarnings("ignore", message="Type of strand")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN

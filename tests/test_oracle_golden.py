@@ -1,0 +1,102 @@
+"""Pin the CPU oracle to the oxDNA-standalone golden files.
+
+Mirrors mythos/energy/dna{1,2}/tests/test_integration.py: per-term energies per
+nucleotide, rounded to 6 decimals, against ``split_energy.dat`` with the reference's
+tolerances; totals against ``energy.dat``.  Additionally uses ``pair.dat`` (per pair,
+per term) which the reference ships but does not test.
+"""
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+CASES = [
+    (1, "simple-helix", False),
+    (1, "simple-coax", False),
+    (2, "simple-helix", False),
+    (2, "simple-coax", False),
+    (2, "simple-helix-half-charged-ends", True),
+]
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), CASES)
+def test_split_energy_terms(model, name, hce):
+    top, traj, split, _ = H.load_golden(model, name)
+    P = H.oracle_params(model, half_charged_ends=hce)
+    e = H.oracle_terms_traj(model, P, top, traj)
+    names = H.SPLIT_COLUMNS[1 : 1 + e.shape[1]]
+    for k, term in enumerate(names):
+        if model == 1 and name == "simple-coax" and term == "stacking":
+            continue  # the reference only pins dna1 stacking on simple-helix (test_integration.py:243-249)
+        np.testing.assert_allclose(np.around(e[:, k], 6), split[:, 1 + k], atol=H.TERM_ATOL[term], err_msg=term)
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), CASES)
+def test_total_energy(model, name, hce):
+    top, traj, _, energy = H.load_golden(model, name)
+    P = H.oracle_params(model, half_charged_ends=hce)
+    e = H.oracle_terms_traj(model, P, top, traj).sum(1)
+    # dna2 total: atol 1e-3 (dna2/tests/test_integration.py:374); dna1: rtol 1e-5/atol 1e-6 is only
+    # met by the reference for terms without mesh interpolation; 1e-4 holds for every frame here.
+    np.testing.assert_allclose(e, energy, atol=1e-3 if model == 2 else 1e-4)
+
+
+def test_quaternion_route_equals_axes_route():
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    P = H.oracle_params(2)
+    fr = range(0, 100, 10)
+    a = H.oracle_terms_traj(2, P, top, traj, frames=fr, use_axes=True)
+    b = H.oracle_terms_traj(2, P, top, traj, frames=fr, use_axes=False)
+    np.testing.assert_allclose(a, b, atol=1e-12)
+
+
+@pytest.mark.parametrize("top_file", ["generated.top", "generated-new.top"])
+def test_sequence_dependent_weights(top_file):
+    """dna1 seq-dep stacking / H-bond (dna1/tests/test_integration.py:192-293)."""
+    top, traj, split, _ = H.load_golden(1, "simple-helix-seq-dep", top_file)
+    ss = H.read_ss_weights(H.GOLDEN / "dna1" / "simple-helix-seq-dep" / "seq_dep.dat")
+    P = H.oracle_params(
+        1,
+        overrides={
+            "stacking": {"ss_stack_weights": ss["ss_stack_weights"], "eps_stack_kt_coeff": ss["eps_stack_kt_coeff"]},
+            "hydrogen_bonding": {"ss_hb_weights": ss["ss_hb_weights"]},
+        },
+    )
+    e = H.oracle_terms_traj(1, P, top, traj)
+    np.testing.assert_allclose(np.around(e[:, 2], 6), split[:, 3], atol=1e-6)
+    np.testing.assert_allclose(np.around(e[:, 4], 6), split[:, 5], atol=1e-3)
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), [(2, "simple-helix", False), (2, "simple-coax", False), (1, "simple-helix", False)])
+def test_pair_dat(model, name, hce):
+    """Per-pair per-term energies, 10 frames (pair.dat block k <-> frame k-1)."""
+    import torch
+
+    from oracle import oxdna_oracle as orc
+
+    top, traj, _, _ = H.load_golden(model, name)
+    P = H.oracle_params(model, half_charged_ends=hce)
+    blocks = H.read_pair_dat(H.GOLDEN / f"dna{model}" / name / "pair.dat", n_blocks=11)
+    seq, is_end, b, u = H.topo_tensors(top)
+    cols_b = {"fene": 0, "bonded_excluded_volume": 1, "stacking": 2}
+    cols_u = {"unbonded_excluded_volume": 3, "hydrogen_bonding": 4, "cross_stacking": 5, "coaxial_stacking": 6, "debye": 7}
+    for f in range(10):
+        blk = blocks[f + 1]
+        bt, ut = orc.pair_terms(
+            model, P, torch.as_tensor(traj.center[f]), None, seq, is_end, b, u, box=traj.box_size,
+            axes=(torch.as_tensor(traj.a1[f]), torch.as_tensor(traj.a3[f])),
+        )
+        for pairs, terms, cols in ((top.bonded_neighbors, bt, cols_b), (top.unbonded_neighbors, ut, cols_u)):
+            for term, col in cols.items():
+                if term not in terms:
+                    continue
+                ours = terms[term].numpy()
+                for k, (i, j) in enumerate(pairs):
+                    ref = blk.get((int(i), int(j)))
+                    val = 0.0 if ref is None else ref[col]
+                    # oxDNA evaluates HB / cross-stacking angular factors through interpolation meshes and
+                    # Debye with fp32 constants; everything else agrees to the 6 printed digits
+                    tol = 2e-4 if term in ("hydrogen_bonding", "cross_stacking") else 2e-6
+                    rtol = 3e-4 if term == "debye" else 1e-5
+                    assert abs(ours[k] - val) <= tol + rtol * abs(val), (term, f, i, j, ours[k], val)
