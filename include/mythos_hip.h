@@ -1,0 +1,166 @@
+/*
+ * mythos_hip.h  --  C ABI of libmythos_hip.so: the MI355X (gfx950) force-evaluation and
+ * Langevin-integrator core for oxDNA1/2 (and MARTINI 2/3) energy functions.
+ *
+ * The reference (mythos-bio/mythos) has no FFI: its plugin surface is the Python protocol
+ *   EnergyFunction.__call__/map/with_params        mythos/energy/base.py:24-93, 215-434
+ *   JaxMDSimulator.run -> scan(step_fn)            mythos/simulators/jax_md/jaxmd.py:45-103
+ *   jax.value_and_grad over the energy             mythos/optimization/objective.py:198-235
+ * Each entry point below names the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types: streams are passed as void* (a hipStream_t, NULL = default).
+ *   - "dev" pointers are device memory owned by the caller (PyTorch tensors) and only borrowed;
+ *     "host" pointers are read during the call and may be freed afterwards.
+ *   - dtype: 0 = float32 state/arithmetic, 1 = float64.  Energies and dU/dparams are always
+ *     float64.
+ *   - every function returning int returns 0 on success or a negative mythos_status; the text
+ *     is available from mythos_last_error() (thread-local).
+ *   - handles are independent: one handle per thread / stream, no global state.
+ *   - nucleotides are in oxDNA-classic 3'->5' memory order; quaternions are [w, x, y, z].
+ */
+#ifndef MYTHOS_HIP_H
+#define MYTHOS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mythos_system mythos_system_t;   /* one oxDNA system: topology + parameters + neighbours */
+typedef struct mythos_sim mythos_sim_t;         /* Langevin integrator state bound to a system */
+typedef struct mythos_martini mythos_martini_t; /* one MARTINI system */
+typedef void* mythos_stream_t;                  /* hipStream_t */
+
+enum mythos_status {
+  MYTHOS_OK = 0,
+  MYTHOS_ERR_INVALID_ARGUMENT = -1,
+  MYTHOS_ERR_HIP = -2,
+  MYTHOS_ERR_NO_DEVICE = -3,
+  MYTHOS_ERR_NOT_READY = -4,   /* parameters or neighbours not set */
+  MYTHOS_ERR_OVERFLOW = -5,    /* neighbour row capacity exceeded / skin violated */
+  MYTHOS_ERR_NUMERIC = -6      /* NaN / Inf detected */
+};
+
+enum mythos_dtype { MYTHOS_F32 = 0, MYTHOS_F64 = 1 };
+
+/* number of energy terms reported per frame (dna1 leaves the Debye slot 0):
+ * fene, bonded_excluded_volume, stacking, unbonded_excluded_volume, hydrogen_bonding,
+ * cross_stacking, coaxial_stacking, debye  -- the order of dna2.default_energy_fns()
+ * (mythos/energy/dna2/__init__.py:74-85). */
+#define MYTHOS_OXDNA_N_TERMS 8
+
+const char* mythos_version(void);
+/* last error text of the calling thread ("" if none) */
+const char* mythos_last_error(void);
+/* number of visible HIP devices (0 if none); never initialises a context beyond the count */
+int mythos_device_count(void);
+
+/* ---- flat parameter vector ------------------------------------------------------------------
+ * Replaces the per-term frozen dataclasses (*Configuration, mythos/energy/configuration.py:16-123)
+ * at the kernel boundary: independent AND dependent constants, one double each, in the order
+ * reported here.  The host-side shim derives the dependent ones (init_params) and applies the
+ * chain rule to dU_dparams. */
+int mythos_oxdna_param_count(void);
+const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
+
+/* ---- system ---------------------------------------------------------------------------------
+ * Replaces BaseEnergyFunction.__post_init__ topology capture (mythos/energy/base.py:133-140).
+ *   model     1 = oxDNA1, 2 = oxDNA2
+ *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
+ *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
+ *   bonded    host int32[n_bonded][2] rows (nn_i, nn_j) as mythos/input/topology.py:166-183
+ *   box       host double[3] periodic box (jax_md.space.periodic), or NULL for free space
+ */
+mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded,
+                                     const int32_t* bonded, const double* box, int dtype, int device);
+void mythos_oxdna_destroy(mythos_system_t* sys);
+
+/* host double[n_params] in mythos_oxdna_param_name() order; replaces with_params() at the boundary */
+int mythos_oxdna_set_params(mythos_system_t* sys, const double* flat_params, int n_params);
+
+/* Unbonded pair list, reference semantics (NoNeighborList.idx, simulators/jax_md/utils.py:48-67):
+ * host int32[n_pairs][2], rows (op_i, op_j) in that role order.  Converted to per-nucleotide rows. */
+int mythos_oxdna_set_neighbors(mythos_system_t* sys, const int32_t* pairs, int n_pairs);
+
+/* GPU Verlet list with bonded exclusions from positions (replaces mythos/utils/neighbors.py:12-59):
+ * center dev real[n][3]; pairs with |c_i - c_j| < r_cut + skin are kept. */
+int mythos_oxdna_build_neighbors(mythos_system_t* sys, const void* center, double r_cut, double skin,
+                                 mythos_stream_t stream);
+/* max and mean row length of the current list (directed neighbours per nucleotide) */
+int mythos_oxdna_neighbor_stats(mythos_system_t* sys, int* max_row, double* mean_row);
+
+/* Energy of n_frames configurations; replaces ComposedEnergyFunction.compute_terms / map
+ * (mythos/energy/base.py:312-319, 90-93) and the jax.grad of them.
+ *   center      dev real[n_frames][n][3]
+ *   quat        dev real[n_frames][n][4]
+ *   e_terms     dev double[n_frames][8]                      (required)
+ *   dU_dcenter  dev real[n_frames][n][3] or NULL
+ *   dU_dquat    dev real[n_frames][n][4] or NULL             (gradient w.r.t. the un-normalised quaternion,
+ *                                                            as jax.grad of mythos/energy/utils.py:18-36 gives)
+ *   dU_dparams  dev double[n_frames][n_params] or NULL       (flat vector; dependent entries treated as free)
+ */
+int mythos_oxdna_energy(mythos_system_t* sys, const void* center, const void* quat, int n_frames, double* e_terms,
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_stream_t stream);
+
+/* ---- Langevin integrator ----------------------------------------------------------------------
+ * Replaces jax_md.simulate.nvt_langevin on RigidBody states as driven by
+ * mythos/simulators/jax_md/jaxmd.py:73-94: BAOAB, rigid-body rotation with body-frame angular
+ * momentum (equivalent to the quaternion-momentum NO_SQUISH form), counter-based RNG.
+ *   gamma_t/gamma_r   friction of the translational / rotational thermostat
+ *   inertia           host double[3] principal moments
+ */
+mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT, double gamma_t, double gamma_r,
+                                     double mass, const double* inertia, uint64_t seed);
+void mythos_langevin_destroy(mythos_sim_t* sim);
+
+/* neighbour-list policy of the MD loop: rebuild every `every` steps with cut-off r_cut + skin
+ * (every <= 0: keep the list given by set_neighbors for the whole run) */
+int mythos_langevin_set_neighbor_policy(mythos_sim_t* sim, double r_cut, double skin, int every);
+
+/* draw Maxwell-Boltzmann momenta at kT (init_fn of nvt_langevin) */
+int mythos_langevin_init_momenta(mythos_sim_t* sim, void* p_lin, void* p_ang, mythos_stream_t stream);
+
+/* Run n_steps; state arrays are updated in place.
+ *   center dev real[n][3], quat dev real[n][4], p_lin dev real[n][3], p_ang dev real[n][3] (body frame)
+ *   save_every > 0: traj_center dev real[n_steps/save_every][n][3], traj_quat [..][n][4] receive the
+ *   state after steps save_every, 2*save_every, ...; e_trace dev double[n_steps/save_every][10] receives
+ *   the 8 term energies + translational + rotational kinetic energy (any of the three may be NULL).
+ * Returns MYTHOS_ERR_OVERFLOW if a nucleotide outran the Verlet skin between rebuilds. */
+int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin, void* p_ang, int n_steps,
+                        int save_every, void* traj_center, void* traj_quat, double* e_trace,
+                        mythos_stream_t stream);
+/* absolute step counter (RNG stream position); settable for checkpoint/resume */
+int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
+int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
+
+/* timing hook for bench.py: average device time (ms) of the last run's force+integrate kernel
+ * launches measured with HIP events on the launch stream, and the launch count */
+int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* avg_ms, int* launches);
+
+/* ---- MARTINI 2/3 ------------------------------------------------------------------------------
+ * Replaces mythos/energy/martini/m2/{lj,bond,angle}.py and m3/angle.py.
+ *   types        host int32[n]            bead type index
+ *   sigma, eps   host double[n_types][n_types]
+ *   bonds        host int32[n_bonds][2], bond_k / bond_r0 host double[n_bonds]
+ *   angles       host int32[n_angles][3], angle_k / angle_t0 host double[n_angles] (t0 in radians)
+ *   angle_kind   0 = G96 cosine (MARTINI 2), 1 = harmonic (MARTINI 3)
+ *   r_cut        LJ cut-off (1.1 nm in the reference), potential shifted to 0 at r_cut
+ * Energy terms per frame: [lj, bond, angle].  box dev real[n_frames][3] (per-frame periodic box).
+ */
+#define MYTHOS_MARTINI_N_TERMS 3
+mythos_martini_t* mythos_martini_create(int n, const int32_t* types, int n_types, const double* sigma,
+                                        const double* eps, int n_bonds, const int32_t* bonds, const double* bond_k,
+                                        const double* bond_r0, int n_angles, const int32_t* angles,
+                                        const double* angle_k, const double* angle_t0, int angle_kind, double r_cut,
+                                        int dtype, int device);
+void mythos_martini_destroy(mythos_martini_t* m);
+int mythos_martini_energy(mythos_martini_t* m, const void* pos, const void* box, int n_frames, double* e_terms,
+                          void* dU_dpos, mythos_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYTHOS_HIP_H */

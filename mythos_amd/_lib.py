@@ -1,0 +1,140 @@
+"""ctypes binding of libmythos_hip.so (the C ABI declared in include/mythos_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a compute entry point is
+called without a visible GPU, the call raises.  Building: ``python -c "import
+__graft_entry__ as g; g.build()"`` or ``make -C mythos_amd/csrc``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libmythos_hip.so"
+
+c_int_p = C.POINTER(C.c_int32)
+c_double_p = C.POINTER(C.c_double)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class MythosHipError(RuntimeError):
+    """An error reported by libmythos_hip.so."""
+
+
+_lib = None
+
+
+def lib_path() -> Path:
+    return Path(os.environ.get("MYTHOS_HIP_LIB", _LIB_PATH))
+
+
+def load() -> C.CDLL:
+    """Load the library once and declare every prototype of include/mythos_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not path.exists():
+        raise MythosHipError(
+            f"{path} not found: the HIP extension is not built (run __graft_entry__.build()). "
+            "mythos_amd has no CPU fallback."
+        )
+    lib = C.CDLL(str(path))
+    V = C.c_void_p
+    sigs = {
+        "mythos_version": (C.c_char_p, []),
+        "mythos_last_error": (C.c_char_p, []),
+        "mythos_device_count": (C.c_int, []),
+        "mythos_oxdna_param_count": (C.c_int, []),
+        "mythos_oxdna_param_name": (C.c_char_p, [C.c_int]),
+        "mythos_oxdna_create": (V, [C.c_int, C.c_int, c_int_p, c_uint8_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
+        "mythos_oxdna_destroy": (None, [V]),
+        "mythos_oxdna_set_params": (C.c_int, [V, c_double_p, C.c_int]),
+        "mythos_oxdna_set_neighbors": (C.c_int, [V, c_int_p, C.c_int]),
+        "mythos_oxdna_build_neighbors": (C.c_int, [V, V, C.c_double, C.c_double, V]),
+        "mythos_oxdna_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
+        "mythos_oxdna_energy": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V]),
+        "mythos_langevin_create": (V, [V, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, C.c_uint64]),
+        "mythos_langevin_destroy": (None, [V]),
+        "mythos_langevin_set_neighbor_policy": (C.c_int, [V, C.c_double, C.c_double, C.c_int]),
+        "mythos_langevin_init_momenta": (C.c_int, [V, V, V, V]),
+        "mythos_langevin_run": (C.c_int, [V, V, V, V, V, C.c_int, C.c_int, V, V, V, V]),
+        "mythos_langevin_get_step": (C.c_int64, [V]),
+        "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
+        "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, C.POINTER(C.c_int)]),
+        "mythos_martini_create": (
+            V,
+            [C.c_int, c_int_p, C.c_int, c_double_p, c_double_p, C.c_int, c_int_p, c_double_p, c_double_p, C.c_int,
+             c_int_p, c_double_p, c_double_p, C.c_int, C.c_double, C.c_int, C.c_int],
+        ),
+        "mythos_martini_destroy": (None, [V]),
+        "mythos_martini_energy": (C.c_int, [V, V, V, C.c_int, V, V, V]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = header / library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+DECLARED_SYMBOLS = (
+    "mythos_version",
+    "mythos_last_error",
+    "mythos_device_count",
+    "mythos_oxdna_param_count",
+    "mythos_oxdna_param_name",
+    "mythos_oxdna_create",
+    "mythos_oxdna_destroy",
+    "mythos_oxdna_set_params",
+    "mythos_oxdna_set_neighbors",
+    "mythos_oxdna_build_neighbors",
+    "mythos_oxdna_neighbor_stats",
+    "mythos_oxdna_energy",
+    "mythos_langevin_create",
+    "mythos_langevin_destroy",
+    "mythos_langevin_set_neighbor_policy",
+    "mythos_langevin_init_momenta",
+    "mythos_langevin_run",
+    "mythos_langevin_get_step",
+    "mythos_langevin_set_step",
+    "mythos_langevin_last_kernel_ms",
+    "mythos_martini_create",
+    "mythos_martini_destroy",
+    "mythos_martini_energy",
+)
+
+
+def last_error() -> str:
+    return load().mythos_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Raise on a negative mythos_status (error conventions of SURVEY.md section 8b)."""
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()} (status {rc})"
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -6:
+        raise FloatingPointError(msg)
+    raise MythosHipError(msg)
+
+
+def param_names() -> list[str]:
+    lib = load()
+    return [lib.mythos_oxdna_param_name(i).decode() for i in range(lib.mythos_oxdna_param_count())]
+
+
+def device_count() -> int:
+    return int(load().mythos_device_count())
+
+
+def ptr(t):
+    """Device (or host) data pointer of a torch tensor / numpy array as c_void_p (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)

@@ -1,0 +1,217 @@
+// C-ABI entry points of libmythos_hip.so (declared in include/mythos_hip.h).
+#include <cmath>
+#include <cstring>
+
+#include "mythos_internal.h"
+
+namespace mythos {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what) {
+  g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+  return MYTHOS_ERR_HIP;
+}
+
+static const char* const kParamNames[] = {
+#define OXP(name) #name,
+#include "oxdna_param_list.inc"
+#undef OXP
+};
+
+}  // namespace mythos
+
+using namespace mythos;
+
+extern "C" {
+
+const char* mythos_version(void) { return "mythos_amd 0.1 (gfx950)"; }
+
+const char* mythos_last_error(void) { return g_last_error.c_str(); }
+
+int mythos_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int mythos_oxdna_param_count(void) { return (int)OXP_COUNT; }
+
+const char* mythos_oxdna_param_name(int index) {
+  if (index < 0 || index >= (int)OXP_COUNT) return nullptr;
+  return kParamNames[index];
+}
+
+mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded,
+                                     const int32_t* bonded, const double* box, int dtype, int device) {
+  g_last_error.clear();
+  if ((model != 1 && model != 2) || n < 1 || !seq || n_bonded < 0 || (n_bonded > 0 && !bonded) ||
+      (dtype != MYTHOS_F32 && dtype != MYTHOS_F64) || n >= ROW_ROLE_Q) {
+    set_error("mythos_oxdna_create: invalid argument");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    set_error("mythos_oxdna_create: no HIP device visible (the HIP path has no CPU fallback)");
+    return nullptr;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("mythos_oxdna_create: device index out of range");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    set_error("mythos_oxdna_create: hipSetDevice failed");
+    return nullptr;
+  }
+  auto* s = new mythos_system();
+  s->model = model;
+  s->n = n;
+  s->dtype = dtype;
+  s->device = device;
+  s->n_bonded = n_bonded;
+  if (box) {
+    s->has_box = true;
+    for (int k = 0; k < 3; ++k) s->box[k] = box[k];
+    if (!(box[0] > 0 && box[1] > 0 && box[2] > 0)) {
+      set_error("mythos_oxdna_create: box lengths must be positive");
+      delete s;
+      return nullptr;
+    }
+  }
+  std::vector<int> meta(n);
+  for (int i = 0; i < n; ++i) {
+    if (seq[i] < 0 || seq[i] > 3) {
+      set_error("mythos_oxdna_create: sequence entries must be 0..3");
+      delete s;
+      return nullptr;
+    }
+    meta[i] = seq[i] | ((is_end && is_end[i]) ? 4 : 0);
+  }
+  s->h_partners.assign((size_t)2 * n, -1);
+  for (int b = 0; b < n_bonded; ++b) {
+    const int i = bonded[2 * b], j = bonded[2 * b + 1];
+    if (i < 0 || j < 0 || i >= n || j >= n || i == j) {
+      set_error("mythos_oxdna_create: bonded index out of range");
+      delete s;
+      return nullptr;
+    }
+    if (s->h_partners[2 * i + 1] != -1 || s->h_partners[2 * j + 0] != -1) {
+      set_error("mythos_oxdna_create: a nucleotide has more than one bonded partner per side");
+      delete s;
+      return nullptr;
+    }
+    s->h_partners[2 * i + 1] = j;  // i plays nn_i
+    s->h_partners[2 * j + 0] = i;  // j plays nn_j
+  }
+  bool ok = hipMalloc((void**)&s->d_meta, n * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_row_len, (size_t)3 * n * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
+            hipMemcpy(s->d_meta, meta.data(), n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(s->d_row_len + n, s->h_partners.data(), (size_t)2 * n * sizeof(int), hipMemcpyHostToDevice) ==
+                hipSuccess &&
+            hipMemset(s->d_overflow, 0, sizeof(int)) == hipSuccess;
+  if (!ok) {
+    set_error("mythos_oxdna_create: device allocation failed");
+    mythos_oxdna_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+void mythos_oxdna_destroy(mythos_system_t* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->d_meta) (void)hipFree(s->d_meta);
+  if (s->d_rows) (void)hipFree(s->d_rows);
+  if (s->d_row_len) (void)hipFree(s->d_row_len);
+  if (s->d_overflow) (void)hipFree(s->d_overflow);
+  if (s->d_ref_pos) (void)hipFree(s->d_ref_pos);
+  if (s->d_epart) (void)hipFree(s->d_epart);
+  if (s->d_pgpart) (void)hipFree(s->d_pgpart);
+  delete s;
+}
+
+int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params) {
+  if (!s || !flat || n_params != (int)OXP_COUNT) {
+    set_error("mythos_oxdna_set_params: expected " + std::to_string((int)OXP_COUNT) + " parameters");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  for (int k = 0; k < n_params; ++k) {
+    if (!std::isfinite(flat[k])) {
+      set_error(std::string("mythos_oxdna_set_params: non-finite value for ") + kParamNames[k]);
+      return MYTHOS_ERR_NUMERIC;
+    }
+    s->pd.v[k] = flat[k];
+    s->pf.v[k] = (float)flat[k];
+  }
+  s->params_set = true;
+  return MYTHOS_OK;
+}
+
+int mythos_oxdna_set_neighbors(mythos_system_t* s, const int32_t* pairs, int n_pairs) {
+  if (!s || n_pairs < 0 || (n_pairs > 0 && !pairs)) {
+    set_error("mythos_oxdna_set_neighbors: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  return rows_from_pairs(s, pairs, n_pairs);
+}
+
+int mythos_oxdna_build_neighbors(mythos_system_t* s, const void* center, double r_cut, double skin,
+                                 mythos_stream_t stream) {
+  if (!s || !center || !(r_cut > 0) || skin < 0) {
+    set_error("mythos_oxdna_build_neighbors: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  hipStream_t st = (hipStream_t)stream;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (int rc = rows_build_device(s, center, false, r_cut, skin, st)) return rc;
+    int ov = 0;
+    MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, s->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+    if (ov == 0) return MYTHOS_OK;
+    if (int rc = rows_reserve(s, ((ov + 15) / 16) * 16 + 16)) return rc;
+  }
+  set_error("mythos_oxdna_build_neighbors: neighbour rows keep overflowing");
+  return MYTHOS_ERR_OVERFLOW;
+}
+
+int mythos_oxdna_neighbor_stats(mythos_system_t* s, int* max_row, double* mean_row) {
+  if (!s || !s->nbrs_set) {
+    set_error("mythos_oxdna_neighbor_stats: no neighbour list");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  std::vector<int> len(s->n);
+  MYTHOS_HIP_TRY(hipMemcpy(len.data(), s->d_row_len, s->n * sizeof(int), hipMemcpyDeviceToHost));
+  long long tot = 0;
+  int mx = 0;
+  for (int v : len) {
+    tot += v - ROW_BONDED_SLOTS;
+    mx = std::max(mx, v - ROW_BONDED_SLOTS);
+  }
+  if (max_row) *max_row = mx;
+  if (mean_row) *mean_row = double(tot) / s->n;
+  return MYTHOS_OK;
+}
+
+int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat, int n_frames, double* e_terms,
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_stream_t stream) {
+  if (!s || !center || !quat || !e_terms || n_frames < 0) {
+    set_error("mythos_oxdna_energy: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->params_set || !s->nbrs_set) {
+    set_error("mythos_oxdna_energy: parameters and neighbours must be set first");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  if (n_frames == 0) return MYTHOS_OK;
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams,
+                             (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// Internal definitions shared by the translation units of libmythos_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/mythos_hip.h"
+#include "oxdna_math.h"
+
+namespace mythos {
+
+void set_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what);
+
+#define MYTHOS_HIP_TRY(expr)                                   \
+  do {                                                         \
+    hipError_t _e = (expr);                                    \
+    if (_e != hipSuccess) return ::mythos::hip_fail(_e, #expr); \
+  } while (0)
+
+// Row entry encoding of the per-nucleotide neighbour rows:
+//   slot 0 : bonded partner on the 3' side  (bond (j, self): self plays nn_j)   or -1
+//   slot 1 : bonded partner on the 5' side  (bond (self, j): self plays nn_i)   or -1
+//   slot>=2: unbonded neighbour index | ROLE_Q if self plays op_j of the ordered pair
+constexpr int ROW_ROLE_Q = 1 << 30;
+constexpr int ROW_INDEX_MASK = ROW_ROLE_Q - 1;
+constexpr int ROW_BONDED_SLOTS = 2;
+
+template <typename R>
+struct BoxT {
+  R l[3];
+  R il[3];
+  int on;
+};
+
+}  // namespace mythos
+
+struct mythos_system {
+  int model = 0;
+  int n = 0;
+  int dtype = 0;
+  int device = 0;
+  int n_bonded = 0;
+  bool has_box = false;
+  double box[3] = {0, 0, 0};
+
+  // topology (device)
+  int* d_meta = nullptr;  // [n] seq | is_end << 2
+
+  // neighbour rows (device)
+  int* d_rows = nullptr;     // [n][row_stride]
+  int* d_row_len = nullptr;  // [n] number of used slots (>= 2)
+  int row_stride = 0;
+  size_t rows_cap = 0;  // allocated ints in d_rows
+  bool nbrs_set = false;
+  // host copy of the bonded partners, [n][2]
+  std::vector<int> h_partners;
+
+  // Verlet build scratch
+  int* d_overflow = nullptr;  // [1] set when a row would exceed row_stride
+  void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)
+
+  // parameters
+  bool params_set = false;
+  mythos::OxParams<float> pf;
+  mythos::OxParams<double> pd;
+
+  // energy-pass scratch
+  double* d_epart = nullptr;  // [frames_chunk][blocks][8]
+  size_t epart_cap = 0;
+  double* d_pgpart = nullptr;  // [frames_chunk][blocks][OXP_COUNT]
+  size_t pgpart_cap = 0;
+};
+
+namespace mythos {
+
+template <typename R>
+BoxT<R> make_box(const mythos_system* s) {
+  BoxT<R> b;
+  b.on = s->has_box ? 1 : 0;
+  for (int k = 0; k < 3; ++k) {
+    b.l[k] = R(s->has_box ? s->box[k] : 1.0);
+    b.il[k] = R(s->has_box ? 1.0 / s->box[k] : 1.0);
+  }
+  return b;
+}
+
+template <typename R>
+const OxParams<R>& params_of(const mythos_system* s);
+template <>
+inline const OxParams<float>& params_of<float>(const mythos_system* s) { return s->pf; }
+template <>
+inline const OxParams<double>& params_of<double>(const mythos_system* s) { return s->pd; }
+
+// oxdna_kernels.hip
+int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream);
+// neighbors.hip
+int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs);
+int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
+                      hipStream_t stream);
+int rows_reserve(mythos_system* sys, int stride);
+
+}  // namespace mythos

@@ -1,0 +1,148 @@
+// Per-nucleotide gather of all pair interactions: the work decomposition of every oxDNA kernel.
+//
+// A group of G consecutive lanes (G = 8..64, a divisor of the 64-wide wavefront) owns one
+// nucleotide.  Each lane walks the nucleotide's neighbour row with stride G, evaluates the
+// ordered pair, keeps the half that belongs to the owner, and the group folds the partial
+// force / axis gradients / energies with DPP shuffles.  No atomics, results are bitwise
+// reproducible, rows are read as G consecutive ints (coalesced per group) and neighbour state
+// comes through L2 (a 12 kbp duplex is 0.7 MB of fp32 state).  Each pair is evaluated from
+// both ends (energies and parameter partials are therefore weighted 1/2).
+#pragma once
+#include "mythos_internal.h"
+#include "oxdna_pair.h"
+
+namespace mythos {
+
+template <typename R>
+struct Vec4T;
+template <>
+struct Vec4T<float> {
+  using type = float4;
+};
+template <>
+struct Vec4T<double> {
+  using type = double4;
+};
+
+// state as the reference lays it out: center (N,3), quaternion (N,4), one frame
+template <typename R>
+struct PackedLoader {
+  const R* __restrict__ center;
+  const R* __restrict__ quat;
+  const int* __restrict__ meta;
+  __device__ __forceinline__ void load(int j, Nuc<R>& o, R* q4) const {
+    o.c = {center[3 * j + 0], center[3 * j + 1], center[3 * j + 2]};
+    q4[0] = quat[4 * j + 0];
+    q4[1] = quat[4 * j + 1];
+    q4[2] = quat[4 * j + 2];
+    q4[3] = quat[4 * j + 3];
+    quat_axes(q4[0], q4[1], q4[2], q4[3], o.a1, o.a2, o.a3);
+    const int m = meta[j];
+    o.seq = m & 3;
+    o.is_end = (m >> 2) & 1;
+  }
+};
+
+// MD state: 16/32-byte aligned vec4 position (w unused) and vec4 quaternion
+template <typename R>
+struct Vec4Loader {
+  using V4 = typename Vec4T<R>::type;
+  const V4* __restrict__ pos;
+  const V4* __restrict__ quat;
+  const int* __restrict__ meta;
+  __device__ __forceinline__ void load(int j, Nuc<R>& o, R* q4) const {
+    const V4 c = pos[j];
+    const V4 q = quat[j];
+    o.c = {c.x, c.y, c.z};
+    q4[0] = q.x;
+    q4[1] = q.y;
+    q4[2] = q.z;
+    q4[3] = q.w;
+    quat_axes(q4[0], q4[1], q4[2], q4[3], o.a1, o.a2, o.a3);
+    const int m = meta[j];
+    o.seq = m & 3;
+    o.is_end = (m >> 2) & 1;
+  }
+};
+
+template <typename R>
+__device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
+  if (box.on) {
+    d.x -= box.l[0] * m_rint(d.x * box.il[0]);
+    d.y -= box.l[1] * m_rint(d.y * box.il[1]);
+    d.z -= box.l[2] * m_rint(d.z * box.il[2]);
+  }
+  return d;
+}
+
+template <int G, typename R>
+__device__ __forceinline__ R group_sum(R v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+
+// Walk row i with the G lanes of a group.  On return every lane holds its PARTIAL sums;
+// call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
+// parameter partials, inside the sink) carry weight 1/2.
+template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader>
+__device__ __forceinline__ void gather_row(const OxParams<R>& P, const Loader& ld, const BoxT<R>& box,
+                                           const int* __restrict__ rows, int row_stride, int len, int i,
+                                           const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
+                                           PG& pg) {
+  const int* __restrict__ row = rows + (size_t)i * row_stride;
+  for (int s = lane; s < len; s += G) {
+    const int entry = row[s];
+    if (entry < 0) continue;
+    const int j = entry & ROW_INDEX_MASK;
+    const bool bonded = s < ROW_BONDED_SLOTS;
+    const bool role_p = bonded ? (s == 1) : ((entry & ROW_ROLE_Q) == 0);
+    Nuc<R> other;
+    R q4[4];
+    ld.load(j, other, q4);
+    const V3<R> dco = min_image(other.c - self.c, box);
+    if (bonded)
+      bonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+    else
+      unbonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+  }
+}
+
+template <int G, typename R>
+__device__ __forceinline__ void group_reduce_v3(V3<R>& v) {
+  v.x = group_sum<G>(v.x);
+  v.y = group_sum<G>(v.y);
+  v.z = group_sum<G>(v.z);
+}
+
+template <int G, typename R, bool GRAD>
+__device__ __forceinline__ void group_reduce(R* __restrict__ e, SelfGrad<R>& sg) {
+#pragma unroll
+  for (int k = 0; k < T_COUNT; ++k) e[k] = group_sum<G>(e[k]);
+  if constexpr (GRAD) {
+    group_reduce_v3<G>(sg.dc);
+    group_reduce_v3<G>(sg.g1);
+    group_reduce_v3<G>(sg.g2);
+    group_reduce_v3<G>(sg.g3);
+  }
+}
+
+// dU/dq (4) from the axis gradients; a_k(q) as in mythos/energy/utils.py:18-36
+template <typename R>
+__device__ __forceinline__ void axes_grad_to_quat_grad(const R* q, const SelfGrad<R>& sg, R* dq) {
+  const R q0 = R(2) * q[0], q1 = R(2) * q[1], q2 = R(2) * q[2], q3 = R(2) * q[3];
+  const V3<R>&g1 = sg.g1, &g2 = sg.g2, &g3 = sg.g3;
+  dq[0] = (q0 * g1.x + q3 * g1.y - q2 * g1.z) + (-q3 * g2.x + q0 * g2.y + q1 * g2.z) + (q2 * g3.x - q1 * g3.y + q0 * g3.z);
+  dq[1] = (q1 * g1.x + q2 * g1.y + q3 * g1.z) + (q2 * g2.x - q1 * g2.y + q0 * g2.z) + (q3 * g3.x - q0 * g3.y - q1 * g3.z);
+  dq[2] = (-q2 * g1.x + q1 * g1.y - q0 * g1.z) + (q1 * g2.x + q2 * g2.y + q3 * g2.z) + (q0 * g3.x + q3 * g3.y - q2 * g3.z);
+  dq[3] = (-q3 * g1.x + q0 * g1.y + q1 * g1.z) + (-q0 * g2.x - q3 * g2.y + q2 * g2.z) + (q1 * g3.x + q2 * g3.y + q3 * g3.z);
+}
+
+// lab-frame torque  -sum_k a_k x dU/da_k
+template <typename R>
+__device__ __forceinline__ V3<R> axes_grad_to_torque(const Nuc<R>& s, const SelfGrad<R>& sg) {
+  V3<R> t = cross(s.a1, sg.g1) + cross(s.a2, sg.g2) + cross(s.a3, sg.g3);
+  return -t;
+}
+
+}  // namespace mythos

@@ -1,0 +1,192 @@
+// Energy / gradient evaluation over frames: the kernel behind mythos_oxdna_energy().
+//
+// Replaces ComposedEnergyFunction.compute_terms + EnergyFunction.map
+// (mythos/energy/base.py:312-319, 90-93) and jax.grad / jax.value_and_grad of them
+// (mythos/optimization/objective.py:235): one launch covers (frame, nucleotide-group) and
+// returns the 8 term energies per frame, dU/dcenter, dU/dquat and dU/dparam.
+//
+// Layout: grid = (ceil(N / PPB), frames); a 256-thread block owns PPB = 256/G nucleotides of
+// one frame.  Energies: group -> LDS (fixed order) -> per-block partial in HBM -> a second
+// tiny kernel sums the partials in a fixed order, so e_terms are run-to-run reproducible.
+// Roofline: HBM; algorithmic bytes per frame = (7 s + 4) N + 4 (nbar + 2) N  read,
+// 7 s N + 8*8 + 8 K written (s = sizeof(real)).
+#include "oxdna_gather.h"
+
+namespace mythos {
+
+constexpr int kBlock = 256;
+
+struct LdsPG {
+  static constexpr bool on = true;
+  double* acc;
+  template <typename R>
+  __device__ __forceinline__ void add(int idx, R v) const {
+    atomicAdd(&acc[idx], 0.5 * double(v));
+  }
+};
+
+template <typename R, int MODEL, int MODE, int G>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
+__global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy_kernel(
+    const OxParams<R> P, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
+    const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
+    double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
+    double* __restrict__ pg_part) {
+  constexpr int PPB = kBlock / G;
+  constexpr bool GRAD = MODE >= 1;
+  __shared__ double e_lds[PPB][T_COUNT];
+  __shared__ double pg_lds[MODE == 2 ? OXP_COUNT : 1];
+
+  const int frame = blockIdx.y;
+  const int grp = threadIdx.x / G;
+  const int lane = threadIdx.x % G;
+  const int i = blockIdx.x * PPB + grp;
+  const size_t fo = (size_t)frame * n;
+
+  if constexpr (MODE == 2) {
+    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) pg_lds[k] = 0.0;
+    __syncthreads();
+  }
+
+  R e[T_COUNT];
+#pragma unroll
+  for (int k = 0; k < T_COUNT; ++k) e[k] = R(0);
+  SelfGrad<R> sg;
+  sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
+  R qs[4] = {R(1), R(0), R(0), R(0)};
+
+  if (i < n) {
+    PackedLoader<R> ld{center + fo * 3, quat + fo * 4, meta};
+    Nuc<R> self;
+    ld.load(i, self, qs);
+    if constexpr (MODE == 2) {
+      LdsPG pg{pg_lds};
+      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
+    } else {
+      NoPG pg;
+      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
+    }
+  }
+  group_reduce<G, R, GRAD>(e, sg);
+
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < T_COUNT; ++k) e_lds[grp][k] = (i < n) ? double(e[k]) : 0.0;
+    if constexpr (GRAD) {
+      if (i < n) {
+        if (dU_dcenter) {
+          R* o = dU_dcenter + (fo + i) * 3;
+          o[0] = sg.dc.x;
+          o[1] = sg.dc.y;
+          o[2] = sg.dc.z;
+        }
+        if (dU_dquat) {
+          R dq[4];
+          axes_grad_to_quat_grad(qs, sg, dq);
+          R* o = dU_dquat + (fo + i) * 4;
+          o[0] = dq[0];
+          o[1] = dq[1];
+          o[2] = dq[2];
+          o[3] = dq[3];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const size_t bo = (size_t)frame * gridDim.x + blockIdx.x;
+  if (threadIdx.x < T_COUNT) {
+    double s = 0.0;
+    for (int g = 0; g < PPB; ++g) s += e_lds[g][threadIdx.x];
+    e_part[bo * T_COUNT + threadIdx.x] = s;
+  }
+  if constexpr (MODE == 2) {
+    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) pg_part[bo * OXP_COUNT + k] = pg_lds[k];
+  }
+}
+
+// out[frame][k] = sum_b part[frame][b][k], fixed order
+__global__ void reduce_partials_kernel(const double* __restrict__ part, int n_blocks, int width,
+                                       double* __restrict__ out) {
+  const int frame = blockIdx.x;
+  for (int k = threadIdx.x; k < width; k += blockDim.x) {
+    double s = 0.0;
+    const double* p = part + (size_t)frame * n_blocks * width + k;
+    for (int b = 0; b < n_blocks; ++b) s += p[(size_t)b * width];
+    out[(size_t)frame * width + k] = s;
+  }
+}
+
+template <typename T>
+static int ensure(T*& ptr, size_t& cap, size_t need) {
+  if (need <= cap) return 0;
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  MYTHOS_HIP_TRY(hipMalloc((void**)&ptr, need * sizeof(T)));
+  cap = need;
+  return 0;
+}
+
+template <typename R, int MODEL, int G>
+static int launch_typed(mythos_system* sys, const R* center, const R* quat, int n_frames, double* e_terms,
+                        R* dU_dcenter, R* dU_dquat, double* dU_dparams, hipStream_t stream) {
+  constexpr int PPB = kBlock / G;
+  const int n = sys->n;
+  const int blocks = (n + PPB - 1) / PPB;
+  const int mode = dU_dparams ? 2 : ((dU_dcenter || dU_dquat) ? 1 : 0);
+  // frames per chunk bounded by scratch (<= 256 MB of parameter partials) and the 65535 grid.y limit
+  size_t per_frame = (size_t)blocks * (mode == 2 ? OXP_COUNT : T_COUNT) * sizeof(double);
+  int chunk = (int)std::min<size_t>(65535, std::max<size_t>(1, (size_t(256) << 20) / per_frame));
+  chunk = std::min(chunk, n_frames);
+  if (int rc = ensure(sys->d_epart, sys->epart_cap, (size_t)chunk * blocks * T_COUNT)) return rc;
+  if (mode == 2)
+    if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * OXP_COUNT)) return rc;
+  const OxParams<R>& P = params_of<R>(sys);
+  const BoxT<R> box = make_box<R>(sys);
+  for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+    const int nf = std::min(chunk, n_frames - f0);
+    dim3 grid(blocks, nf);
+    const R* c = center + (size_t)f0 * n * 3;
+    const R* q = quat + (size_t)f0 * n * 4;
+    R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
+    R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
+    if (mode == 0)
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
+                         sys->d_pgpart);
+    else if (mode == 1)
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
+                         sys->d_pgpart);
+    else
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
+                         sys->d_pgpart);
+    MYTHOS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
+                       e_terms + (size_t)f0 * T_COUNT);
+    if (mode == 2)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(256), 0, stream, sys->d_pgpart, blocks,
+                         (int)OXP_COUNT, dU_dparams + (size_t)f0 * OXP_COUNT);
+    MYTHOS_HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream) {
+  constexpr int G = 16;
+  if (sys->dtype == MYTHOS_F32) {
+    if (sys->model == 1)
+      return launch_typed<float, 1, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
+    return launch_typed<float, 2, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                     (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
+  }
+  if (sys->model == 1)
+    return launch_typed<double, 1, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                      (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+  return launch_typed<double, 2, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                    (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+}
+
+}  // namespace mythos

@@ -1,0 +1,419 @@
+// Scalar building blocks of the oxDNA force field for gfx950: value AND analytic derivative
+// of f1..f6 / FENE / Debye, plus their partials with respect to every parameter.
+//
+// What each function computes follows the reference's jnp graph
+//   mythos/energy/potentials.py:11-70, mythos/energy/dna1/base_functions.py:13-129,
+//   mythos/energy/dna2/base_functions.py:13-17, mythos/energy/dna1/interactions.py:16-41,
+//   mythos/energy/dna2/interactions.py:15-28, mythos/utils/math.py:68-81
+// with the same strict inequalities on every branch.  The reference obtains derivatives by
+// jax.grad; here they are written out so one pass yields energy, force and dU/dtheta.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mythos {
+
+// ------------------------------------------------------------------ parameter index enum
+enum OxParamIndex : int {
+#define OXP(name) name,
+#include "oxdna_param_list.inc"
+#undef OXP
+  OXP_COUNT
+};
+
+template <typename R>
+struct OxParams {
+  R v[OXP_COUNT];
+  __host__ __device__ __forceinline__ R operator[](int i) const { return v[i]; }
+};
+
+// ------------------------------------------------------------------ tiny vector algebra
+template <typename R>
+struct V3 {
+  R x, y, z;
+};
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> mk(R x, R y, R z) { return V3<R>{x, y, z}; }
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> operator+(V3<R> a, V3<R> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> operator-(V3<R> a, V3<R> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> operator-(V3<R> a) { return {-a.x, -a.y, -a.z}; }
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> operator*(R s, V3<R> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <typename R>
+__host__ __device__ __forceinline__ R dot(V3<R> a, V3<R> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename R>
+__host__ __device__ __forceinline__ V3<R> cross(V3<R> a, V3<R> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <typename R>
+__host__ __device__ __forceinline__ void axpy(V3<R>& y, R a, V3<R> x) {
+  y.x += a * x.x;
+  y.y += a * x.y;
+  y.z += a * x.z;
+}
+
+__device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float m_rsqrt(float x) { return rsqrtf(x); }
+__device__ __forceinline__ double m_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ float m_exp(float x) { return __expf(x); }
+__device__ __forceinline__ double m_exp(double x) { return exp(x); }
+__device__ __forceinline__ float m_log(float x) { return __logf(x); }
+__device__ __forceinline__ double m_log(double x) { return log(x); }
+__device__ __forceinline__ float m_acos(float x) { return acosf(x); }
+__device__ __forceinline__ double m_acos(double x) { return acos(x); }
+__device__ __forceinline__ float m_rint(float x) { return rintf(x); }
+__device__ __forceinline__ double m_rint(double x) { return rint(x); }
+
+template <typename R>
+struct FD {  // value and derivative with respect to the argument
+  R f, d;
+};
+
+constexpr double kPi = 3.14159265358979323846;
+
+// No-op / real sinks for parameter partials.  A sink receives (index, dV/dparam).
+struct NoPG {
+  static constexpr bool on = false;
+  template <typename R>
+  __device__ __forceinline__ void add(int, R) const {}
+};
+
+// acos(clamp(c)) with d(theta)/dc; the clamp has zero slope where it clips (math.py:78-81)
+template <typename R>
+__device__ __forceinline__ FD<R> acos_clamped(R c) {
+  const bool clipped = (c >= R(1)) || (c <= R(-1));
+  const R cc = c >= R(1) ? R(1) : (c <= R(-1) ? R(-1) : c);
+  FD<R> o;
+  o.f = m_acos(cc);
+  o.d = clipped ? R(0) : -m_rsqrt(R(1) - cc * cc);
+  return o;
+}
+
+// ------------------------------------------------------------------ f1 (base_functions.py:13-37), eps = 1
+// parameter block layout: RLOW,RHIGH,RCLOW,RCHIGH,A,R0,RC,BLOW,BHIGH,SHIFT
+template <typename R>
+__device__ __forceinline__ FD<R> f1_eval(R r, const OxParams<R>& P, int b) {
+  const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3];
+  FD<R> o{R(0), R(0)};
+  if (rlow < r && r < rhigh) {
+    const R a = P[b + 4];
+    const R e = m_exp(-a * (r - P[b + 5]));
+    o.f = (R(1) - e) * (R(1) - e) - P[b + 9];
+    o.d = R(2) * a * e * (R(1) - e);
+  } else if (rclow < r && r < rlow) {
+    const R t = rclow - r;
+    o.f = P[b + 7] * t * t;
+    o.d = R(-2) * P[b + 7] * t;
+  } else if (rhigh < r && r < rchigh) {
+    const R t = rchigh - r;
+    o.f = P[b + 8] * t * t;
+    o.d = R(-2) * P[b + 8] * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f1_pgrad(R r, const OxParams<R>& P, int b, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3];
+  if (rlow < r && r < rhigh) {
+    const R a = P[b + 4], x = r - P[b + 5];
+    const R e = m_exp(-a * x);
+    pg.add(b + 4, scale * R(2) * (R(1) - e) * e * x);
+    pg.add(b + 5, scale * R(-2) * a * e * (R(1) - e));
+    pg.add(b + 9, -scale);
+  } else if (rclow < r && r < rlow) {
+    const R t = rclow - r;
+    pg.add(b + 7, scale * t * t);
+    pg.add(b + 2, scale * R(2) * P[b + 7] * t);
+  } else if (rhigh < r && r < rchigh) {
+    const R t = rchigh - r;
+    pg.add(b + 8, scale * t * t);
+    pg.add(b + 3, scale * R(2) * P[b + 8] * t);
+  }
+}
+
+// ------------------------------------------------------------------ f2 (base_functions.py:40-63)
+// layout: RLOW,RHIGH,RCLOW,RCHIGH,K,R0,RC,BLOW,BHIGH,SHIFT ; SHIFT = (rc-r0)^2/2
+template <typename R>
+__device__ __forceinline__ FD<R> f2_eval(R r, const OxParams<R>& P, int b) {
+  const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3], k = P[b + 4];
+  FD<R> o{R(0), R(0)};
+  if (rlow < r && r < rhigh) {
+    const R x = r - P[b + 5];
+    o.f = k * (R(0.5) * x * x - P[b + 9]);
+    o.d = k * x;
+  } else if (rclow < r && r < rlow) {
+    const R t = rclow - r;
+    o.f = k * P[b + 7] * t * t;
+    o.d = R(-2) * k * P[b + 7] * t;
+  } else if (rhigh < r && r < rchigh) {
+    const R t = rchigh - r;
+    o.f = k * P[b + 8] * t * t;
+    o.d = R(-2) * k * P[b + 8] * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f2_pgrad(R r, const OxParams<R>& P, int b, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3], k = P[b + 4];
+  if (rlow < r && r < rhigh) {
+    const R x = r - P[b + 5];
+    pg.add(b + 4, scale * (R(0.5) * x * x - P[b + 9]));
+    pg.add(b + 5, -scale * k * x);
+    pg.add(b + 9, -scale * k);
+  } else if (rclow < r && r < rlow) {
+    const R t = rclow - r;
+    pg.add(b + 4, scale * P[b + 7] * t * t);
+    pg.add(b + 7, scale * k * t * t);
+    pg.add(b + 2, scale * R(2) * k * P[b + 7] * t);
+  } else if (rhigh < r && r < rchigh) {
+    const R t = rchigh - r;
+    pg.add(b + 4, scale * P[b + 8] * t * t);
+    pg.add(b + 8, scale * k * t * t);
+    pg.add(b + 3, scale * R(2) * k * P[b + 8] * t);
+  }
+}
+
+// ------------------------------------------------------------------ f3 (base_functions.py:66-79)
+// per-site-pair block layout: RSTAR,SIGMA,B,RC ; eps is shared by the term
+template <typename R>
+struct F3P {
+  R rstar, sigma, b, rc;
+  int base;  // index of RSTAR in the flat vector (for parameter partials)
+};
+template <typename R>
+__device__ __forceinline__ F3P<R> f3_params(const OxParams<R>& P, int b) {
+  return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], b};
+}
+// role-dependent choice between two blocks (compile-time indices -> one v_cndmask per value)
+template <typename R>
+__device__ __forceinline__ F3P<R> f3_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+  return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
+          first ? P[ba + 3] : P[bb + 3], first ? ba : bb};
+}
+template <typename R>
+__device__ __forceinline__ FD<R> f3_eval(R r, R eps, const F3P<R>& p) {
+  FD<R> o{R(0), R(0)};
+  if (r < p.rstar) {
+    const R ir = R(1) / r;
+    const R s = p.sigma * ir;
+    const R s2 = s * s;
+    const R s6 = s2 * s2 * s2;
+    const R s12 = s6 * s6;
+    o.f = R(4) * eps * (s12 - s6);
+    o.d = R(-24) * eps * (R(2) * s12 - s6) * ir;
+  } else if (p.rstar < r && r < p.rc) {
+    const R t = p.rc - r;
+    o.f = eps * p.b * t * t;
+    o.d = R(-2) * eps * p.b * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f3_pgrad(R r, R eps, int ie, const F3P<R>& p, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  if (r < p.rstar) {
+    const R s = p.sigma / r;
+    const R s2 = s * s;
+    const R s6 = s2 * s2 * s2;
+    const R s12 = s6 * s6;
+    pg.add(ie, scale * R(4) * (s12 - s6));
+    pg.add(p.base + 1, scale * R(4) * eps * (R(12) * s12 - R(6) * s6) / p.sigma);
+  } else if (p.rstar < r && r < p.rc) {
+    const R t = p.rc - r;
+    pg.add(ie, scale * p.b * t * t);
+    pg.add(p.base + 2, scale * eps * t * t);
+    pg.add(p.base + 3, scale * R(2) * eps * p.b * t);
+  }
+}
+
+// ------------------------------------------------------------------ f4 (base_functions.py:82-107)
+// block layout: T0,TS,TC,A,B
+template <typename R>
+struct F4P {
+  R t0, ts, tc, a, b;
+  int base;
+};
+template <typename R>
+__device__ __forceinline__ F4P<R> f4_params(const OxParams<R>& P, int b) {
+  return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], P[b + 4], b};
+}
+template <typename R>
+__device__ __forceinline__ F4P<R> f4_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+  return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
+          first ? P[ba + 3] : P[bb + 3], first ? P[ba + 4] : P[bb + 4], first ? ba : bb};
+}
+template <typename R>
+__device__ __forceinline__ FD<R> f4_eval(R th, const F4P<R>& p) {
+  FD<R> o{R(0), R(0)};
+  if (p.t0 - p.ts < th && th < p.t0 + p.ts) {
+    const R x = th - p.t0;
+    o.f = R(1) - p.a * x * x;
+    o.d = R(-2) * p.a * x;
+  } else if (p.t0 - p.tc < th && th < p.t0 - p.ts) {
+    const R t = p.t0 - p.tc - th;
+    o.f = p.b * t * t;
+    o.d = R(-2) * p.b * t;
+  } else if (p.t0 + p.ts < th && th < p.t0 + p.tc) {
+    const R t = p.t0 + p.tc - th;
+    o.f = p.b * t * t;
+    o.d = R(-2) * p.b * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f4_pgrad(R th, const F4P<R>& p, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  if (p.t0 - p.ts < th && th < p.t0 + p.ts) {
+    const R x = th - p.t0;
+    pg.add(p.base + 3, -scale * x * x);
+    pg.add(p.base + 0, scale * R(2) * p.a * x);
+  } else if (p.t0 - p.tc < th && th < p.t0 - p.ts) {
+    const R t = p.t0 - p.tc - th;
+    pg.add(p.base + 4, scale * t * t);
+    pg.add(p.base + 0, scale * R(2) * p.b * t);
+    pg.add(p.base + 2, -scale * R(2) * p.b * t);
+  } else if (p.t0 + p.ts < th && th < p.t0 + p.tc) {
+    const R t = p.t0 + p.tc - th;
+    pg.add(p.base + 4, scale * t * t);
+    pg.add(p.base + 0, scale * R(2) * p.b * t);
+    pg.add(p.base + 2, scale * R(2) * p.b * t);
+  }
+}
+
+// ------------------------------------------------------------------ f5 (base_functions.py:110-129)
+// block layout: XS,XC,A,B
+template <typename R>
+struct F5P {
+  R xs, xc, a, b;
+  int base;
+};
+template <typename R>
+__device__ __forceinline__ F5P<R> f5_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+  return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
+          first ? P[ba + 3] : P[bb + 3], first ? ba : bb};
+}
+template <typename R>
+__device__ __forceinline__ FD<R> f5_eval(R x, const F5P<R>& p) {
+  FD<R> o{R(0), R(0)};
+  if (x > R(0)) {
+    o.f = R(1);
+  } else if (p.xs < x && x < R(0)) {
+    o.f = R(1) - p.a * x * x;
+    o.d = R(-2) * p.a * x;
+  } else if (p.xc < x && x < p.xs) {
+    const R t = p.xc - x;
+    o.f = p.b * t * t;
+    o.d = R(-2) * p.b * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f5_pgrad(R x, const F5P<R>& p, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  if (x > R(0)) {
+  } else if (p.xs < x && x < R(0)) {
+    pg.add(p.base + 2, -scale * x * x);
+  } else if (p.xc < x && x < p.xs) {
+    const R t = p.xc - x;
+    pg.add(p.base + 3, scale * t * t);
+    pg.add(p.base + 1, scale * R(2) * p.b * t);
+  }
+}
+
+// ------------------------------------------------------------------ f6 (dna2/base_functions.py:13-17)
+// layout: A,B
+template <typename R>
+__device__ __forceinline__ FD<R> f6_eval(R th, const OxParams<R>& P, int b) {
+  FD<R> o{R(0), R(0)};
+  if (th >= P[b + 1]) {
+    const R t = th - P[b + 1];
+    o.f = R(0.5) * P[b + 0] * t * t;
+    o.d = P[b + 0] * t;
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void f6_pgrad(R th, const OxParams<R>& P, int b, R scale, PG& pg) {
+  if constexpr (!PG::on) return;
+  if (th >= P[b + 1]) {
+    const R t = th - P[b + 1];
+    pg.add(b + 0, scale * R(0.5) * t * t);
+    pg.add(b + 1, -scale * P[b + 0] * t);
+  }
+}
+
+// ------------------------------------------------------------------ smoothed FENE (interactions.py:16-41)
+template <typename R>
+__device__ __forceinline__ FD<R> fene_eval(R r, const OxParams<R>& P) {
+  const R eps = P[FENE_EPS], x = r - P[FENE_R0], delta = P[FENE_DELTA];
+  const R diff = m_sqrt(x * x + R(1e-10));
+  FD<R> o;
+  if (diff > P[FENE_XMAX]) {
+    const R c = (P[FENE_FMAX] - P[FENE_FINF]) * P[FENE_XMAX];
+    o.f = c * m_log(diff) + P[FENE_FINF] * diff + P[FENE_CONST];
+    o.d = (c / diff + P[FENE_FINF]) * x / diff;
+  } else {
+    const R d2 = delta * delta;
+    o.f = R(-0.5) * eps * m_log(R(1) - x * x / d2);
+    o.d = eps * x / (d2 - x * x);
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void fene_pgrad(R r, const OxParams<R>& P, R dVdr, PG& pg) {
+  if constexpr (!PG::on) return;
+  const R eps = P[FENE_EPS], x = r - P[FENE_R0], delta = P[FENE_DELTA];
+  const R diff = m_sqrt(x * x + R(1e-10));
+  pg.add(FENE_R0, -dVdr);
+  if (diff > P[FENE_XMAX]) {
+    const R ld = m_log(diff);
+    pg.add(FENE_FMAX, P[FENE_XMAX] * ld);
+    pg.add(FENE_FINF, -P[FENE_XMAX] * ld + diff);
+    pg.add(FENE_XMAX, (P[FENE_FMAX] - P[FENE_FINF]) * ld);
+    pg.add(FENE_CONST, R(1));
+  } else {
+    const R d2 = delta * delta;
+    pg.add(FENE_EPS, R(-0.5) * m_log(R(1) - x * x / d2));
+    pg.add(FENE_DELTA, -eps * x * x / (delta * (d2 - x * x)));
+  }
+}
+
+// ------------------------------------------------------------------ Debye-Hueckel (dna2/interactions.py:15-28)
+template <typename R>
+__device__ __forceinline__ FD<R> debye_eval(R r, const OxParams<R>& P) {
+  FD<R> o{R(0), R(0)};
+  if (r < P[DH_RCUT]) {
+    if (r < P[DH_RHIGH]) {
+      const R ir = R(1) / r;
+      o.f = m_exp(-P[DH_KAPPA] * r) * P[DH_PREFACTOR] * ir;
+      o.d = -o.f * (P[DH_KAPPA] + ir);
+    } else {
+      const R t = r - P[DH_RCUT];
+      o.f = P[DH_BSMOOTH] * t * t;
+      o.d = R(2) * P[DH_BSMOOTH] * t;
+    }
+  }
+  return o;
+}
+template <typename R, class PG>
+__device__ __forceinline__ void debye_pgrad(R r, const OxParams<R>& P, R mult, PG& pg) {
+  if constexpr (!PG::on) return;
+  if (r < P[DH_RCUT]) {
+    if (r < P[DH_RHIGH]) {
+      const R e = m_exp(-P[DH_KAPPA] * r) / r;
+      pg.add(DH_KAPPA, -mult * r * e * P[DH_PREFACTOR]);
+      pg.add(DH_PREFACTOR, mult * e);
+    } else {
+      const R t = r - P[DH_RCUT];
+      pg.add(DH_BSMOOTH, mult * t * t);
+      pg.add(DH_RCUT, -mult * R(2) * P[DH_BSMOOTH] * t);
+    }
+  }
+}
+
+}  // namespace mythos

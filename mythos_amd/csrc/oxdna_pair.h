@@ -1,0 +1,502 @@
+// Pair interactions of oxDNA1 / oxDNA2 with analytic gradients, written from the point of view
+// of ONE nucleotide ("self") interacting with a neighbour ("other").
+//
+// The reference evaluates every ordered pair (p, q) once and lets jax.grad scatter the
+// derivatives to both members.  On the GPU each nucleotide gathers its own row instead, so a
+// pair function only needs the OWNER's derivatives:
+//   dU/dc_self and dU/da1, dU/da2, dU/da3 of self (axes treated as independent vectors),
+// from which the caller forms the lab torque  -sum_k a_k x dU/da_k  (MD) or the quaternion
+// gradient jax.grad returns (energy API).  Which reference role self plays (p = op_i / nn_i or
+// q = op_j / nn_j) only changes signs and which parameter block a cosine uses; those choices
+// are per-lane selects, so no pair is ever re-ordered in registers.  Optionally every
+// evaluation also emits dU/dparam for the flat parameter vector.
+//
+// Geometry and role conventions follow the reference term by term:
+//   bonded  (p = nn_i, q = nn_j):  dna1/fene.py:37-56, dna1/bonded_excluded_volume.py:84-114,
+//                                  dna1/stacking.py:192-289, dna2/stacking.py:19-39
+//   unbonded (p = op_i, q = op_j): dna1/unbonded_excluded_volume.py:105-146,
+//       dna1/hydrogen_bonding.py:232-306, dna1/cross_stacking.py:192-266,
+//       dna1/coaxial_stacking.py:181-260, dna2/coaxial_stacking.py:138-201, dna2/debye.py:82-110
+// All displacement vectors below are d = site_other - site_self (minimum image on the centres).
+#pragma once
+#include "oxdna_math.h"
+
+namespace mythos {
+
+enum OxTerm : int {
+  T_FENE = 0,
+  T_BEXC = 1,
+  T_STCK = 2,
+  T_NEXC = 3,
+  T_HB = 4,
+  T_CRST = 5,
+  T_CXST = 6,
+  T_DH = 7,
+  T_COUNT = 8
+};
+
+template <typename R>
+struct Nuc {
+  V3<R> c, a1, a2, a3;
+  int seq;
+  int is_end;
+};
+
+// axes from an (un-normalised) quaternion, mythos/energy/utils.py:18-36
+template <typename R>
+__device__ __forceinline__ void quat_axes(R q0, R q1, R q2, R q3, V3<R>& a1, V3<R>& a2, V3<R>& a3) {
+  a1 = {q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, R(2) * (q1 * q2 + q0 * q3), R(2) * (q1 * q3 - q0 * q2)};
+  a2 = {R(2) * (q1 * q2 - q0 * q3), q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, R(2) * (q2 * q3 + q0 * q1)};
+  a3 = {R(2) * (q1 * q3 + q0 * q2), R(2) * (q2 * q3 - q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3};
+}
+
+// 4x4 sequence-weight lookup as a select chain over scalar registers: a dynamic index into the
+// by-value parameter block would force the whole block into scratch memory.
+template <typename R>
+__device__ __forceinline__ R weight_lookup(const OxParams<R>& P, int base, int k) {
+  R w = P[base];
+#pragma unroll
+  for (int t = 1; t < 16; ++t) w = (k == t) ? P[base + t] : w;
+  return w;
+}
+
+template <typename R>
+struct SelfGrad {  // gradient of U with respect to the owner's centre and axes
+  V3<R> dc, g1, g2, g3;
+};
+
+// gd = dV/dd with d = site_other - site_self and site_self = c + al*a1 + be*a2
+template <typename R>
+__device__ __forceinline__ void acc_self_site(SelfGrad<R>& sg, V3<R> gd, R al, R be) {
+  axpy(sg.dc, R(-1), gd);
+  axpy(sg.g1, -al, gd);
+  axpy(sg.g2, -be, gd);
+}
+
+template <typename R>
+__device__ __forceinline__ V3<R> site_disp(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o, R als, R bes, R alo, R beo) {
+  V3<R> d = dco;
+  axpy(d, alo, o.a1);
+  axpy(d, beo, o.a2);
+  axpy(d, -als, s.a1);
+  axpy(d, -bes, s.a2);
+  return d;
+}
+
+// cosine c = sg * (u . n) with n = d / r:  dc/dd = (sg*u - c*n) / r
+template <typename R>
+__device__ __forceinline__ void acc_dir(V3<R>& gd, R coef, R sg, R c, V3<R> u, V3<R> n, R inv_r) {
+  axpy(gd, coef * sg * inv_r, u);
+  axpy(gd, -coef * c * inv_r, n);
+}
+
+// one radial f3 site pair: energy, self gradient, parameter partials
+template <typename R, bool GRAD, class PG>
+__device__ __forceinline__ R f3_site_pair(const OxParams<R>& P, int ie, const F3P<R>& fp, V3<R> d, R als, R bes,
+                                          SelfGrad<R>& sg, PG& pg) {
+  const R r = m_sqrt(dot(d, d));
+  const FD<R> v = f3_eval(r, P[ie], fp);
+  if constexpr (GRAD)
+    if (v.d != R(0)) acc_self_site(sg, (v.d / r) * d, als, bes);
+  f3_pgrad(r, P[ie], ie, fp, R(1), pg);
+  return v.f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bonded pair: FENE + bonded excluded volume + stacking.   role_p: self is nn_i of the bond.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int MODEL, bool GRAD, class PG>
+__device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                            bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
+  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_d1 = (MODEL == 2) ? P[GEO_BACK_DNA1] : g_k1;
+
+  // ---- FENE on the backbone sites (symmetric)
+  {
+    const V3<R> d = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const R r = m_sqrt(dot(d, d));
+    const FD<R> v = fene_eval(r, P);
+    e[T_FENE] += wgt * v.f;
+    if constexpr (GRAD) acc_self_site(sg, (v.d / r) * d, g_k1, g_k2);
+    fene_pgrad(r, P, v.d, pg);
+  }
+  // ---- bonded excluded volume: base-base, back_p-base_q, base_p-back_q
+  {
+    R eb = f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params(P, BEXC_BASE_RSTAR),
+                                     site_disp(dco, s, o, g_ba, R(0), g_ba, R(0)), g_ba, R(0), sg, pg);
+    // self backbone - other base: "back_p - base_q" if self is p, else "base_p - back_q"
+    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
+                                    site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, sg, pg);
+    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BASE_BACK_RSTAR, BEXC_BACK_BASE_RSTAR),
+                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), sg, pg);
+    e[T_BEXC] += wgt * eb;
+  }
+  // ---- stacking.  Reference: dr = site_p - site_q, theta5 = pi - acos(dr.a3_q / r),
+  //      theta6 = pi - acos(a3_p.dr / r), -cos(phi1) = a2_p.dr_b / r_b, -cos(phi2) = a2_q.dr_b / r_b.
+  //      With d = other - self:  dr = -d if self is p, +d if self is q  ->  sign sgm.
+  {
+    const V3<R> ds = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
+    const R rs = m_sqrt(dot(ds, ds));
+    const FD<R> F1 = f1_eval(rs, P, STCK_RLOW);
+    if (F1.f == R(0) && F1.d == R(0)) return;
+    const R sgm = role_p ? R(-1) : R(1);
+    const R irs = R(1) / rs;
+    const V3<R> ns = irs * ds;
+    const R c4 = dot(s.a3, o.a3);
+    const R cs = sgm * dot(s.a3, ns);  // cosine built from self's normal : theta6 if p, theta5 if q
+    const R co = sgm * dot(o.a3, ns);  // cosine built from other's normal: theta5 if p, theta6 if q
+    const FD<R> t4 = acos_clamped(c4);
+    FD<R> ts = acos_clamped(cs), to = acos_clamped(co);
+    ts.f = R(kPi) - ts.f;
+    ts.d = -ts.d;
+    to.f = R(kPi) - to.f;
+    to.d = -to.d;
+    const F4P<R> p4 = f4_params(P, STCK_TH4_T0);
+    const F4P<R> ps = f4_params_sel(P, role_p, STCK_TH6_T0, STCK_TH5_T0);
+    const F4P<R> po = f4_params_sel(P, role_p, STCK_TH5_T0, STCK_TH6_T0);
+    const FD<R> A4 = f4_eval(t4.f, p4);
+    if (A4.f == R(0)) return;
+    const FD<R> As = f4_eval(ts.f, ps);
+    if (As.f == R(0)) return;
+    const FD<R> Ao = f4_eval(to.f, po);
+    if (Ao.f == R(0)) return;
+    const V3<R> db = site_disp(dco, s, o, g_d1, R(0), g_d1, R(0));
+    const R irb = m_rsqrt(dot(db, db));
+    const V3<R> nb = irb * db;
+    const R xs = sgm * dot(s.a2, nb);  // -cos(phi1) if p, -cos(phi2) if q
+    const R xo = sgm * dot(o.a2, nb);
+    const F5P<R> qs = f5_params_sel(P, role_p, STCK_PHI1_XS, STCK_PHI2_XS);
+    const F5P<R> qo = f5_params_sel(P, role_p, STCK_PHI2_XS, STCK_PHI1_XS);
+    const FD<R> Bs = f5_eval(xs, qs);
+    if (Bs.f == R(0)) return;
+    const FD<R> Bo = f5_eval(xo, qo);
+    if (Bo.f == R(0)) return;
+    const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
+    const R w = weight_lookup(P, STCK_EPS_00, wk);
+    const R ang = A4.f * As.f * Ao.f;
+    const R phi = Bs.f * Bo.f;
+    const R v = F1.f * ang * phi;
+    e[T_STCK] += wgt * w * v;
+    if constexpr (PG::on) {
+      pg.add(STCK_EPS_00 + wk, v);
+      f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
+      f4_pgrad(t4.f, p4, w * F1.f * As.f * Ao.f * phi, pg);
+      f4_pgrad(ts.f, ps, w * F1.f * A4.f * Ao.f * phi, pg);
+      f4_pgrad(to.f, po, w * F1.f * A4.f * As.f * phi, pg);
+      f5_pgrad(xs, qs, w * F1.f * ang * Bo.f, pg);
+      f5_pgrad(xo, qo, w * F1.f * ang * Bs.f, pg);
+    }
+    if constexpr (GRAD) {
+      const R wf = w * F1.f;
+      V3<R> gds{R(0), R(0), R(0)}, gdb{R(0), R(0), R(0)};
+      axpy(gds, w * F1.d * ang * phi, ns);
+      axpy(sg.g3, wf * As.f * Ao.f * phi * A4.d * t4.d, o.a3);
+      const R ks = wf * A4.f * Ao.f * phi * As.d * ts.d;
+      axpy(sg.g3, ks * sgm, ns);
+      acc_dir(gds, ks, sgm, cs, s.a3, ns, irs);
+      const R ko = wf * A4.f * As.f * phi * Ao.d * to.d;
+      acc_dir(gds, ko, sgm, co, o.a3, ns, irs);
+      const R kxs = wf * ang * Bo.f * Bs.d;
+      axpy(sg.g2, kxs * sgm, nb);
+      acc_dir(gdb, kxs, sgm, xs, s.a2, nb, irb);
+      const R kxo = wf * ang * Bs.f * Bo.d;
+      acc_dir(gdb, kxo, sgm, xo, o.a2, nb, irb);
+      acc_self_site(sg, gds, g_st, R(0));
+      acc_self_site(sg, gdb, g_d1, R(0));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// unbonded pair: excluded volume (4 x f3) + Debye + H-bond + cross-stacking + coaxial stacking.
+// role_p: self is op_i of the ordered pair.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int MODEL, bool GRAD, class PG>
+__device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                              bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
+  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+
+  // ---- backbone-backbone: excluded volume and (dna2) Debye-Hueckel share the distance
+  {
+    const V3<R> d = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const R r = m_sqrt(dot(d, d));
+    const F3P<R> fp = f3_params(P, NEXC_BACKBONE_RSTAR);
+    const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
+    e[T_NEXC] += wgt * v.f;
+    R dVdr = v.d;
+    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, R(1), pg);
+    if constexpr (MODEL == 2) {
+      const FD<R> dh = debye_eval(r, P);
+      R mult = R(1);
+      if (P[DH_HALF_CHARGED_ENDS] != R(0)) mult = (s.is_end ? R(0.5) : R(1)) * (o.is_end ? R(0.5) : R(1));
+      e[T_DH] += wgt * mult * dh.f;
+      dVdr += mult * dh.d;
+      debye_pgrad(r, P, mult, pg);
+    }
+    if constexpr (GRAD)
+      if (dVdr != R(0)) acc_self_site(sg, (dVdr / r) * d, g_k1, g_k2);
+  }
+  // ---- self backbone - other base ("back_p - base_q" if self is p) and self base - other backbone
+  {
+    R en = f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
+                                     site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, sg, pg);
+    en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
+                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), sg, pg);
+    e[T_NEXC] += wgt * en;
+  }
+  // ---- base-base: excluded volume, then H-bond and cross-stacking on the same vector.
+  //      Reference: dr = base_q - base_p (= +d if self is p, -d if q);
+  //      theta1 = acos(-a1p.a1q) theta2 = acos(-a1q.n) theta3 = acos(a1p.n)
+  //      theta4 = acos(a3p.a3q)  theta7 = acos(-a3q.n) theta8 = pi - acos(a3p.n)
+  //      In self/other form the cosines are  a1s.n, -a1o.n, a3s.n, -a3o.n  for either role; the role
+  //      decides which angle (and parameter block) each of them is.
+  {
+    const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
+    const R r = m_sqrt(dot(d, d));
+    const F3P<R> fp = f3_params(P, NEXC_BASE_RSTAR);
+    const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
+    e[T_NEXC] += wgt * v.f;
+    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, R(1), pg);
+    V3<R> gd{R(0), R(0), R(0)};
+    bool any = false;
+    if (v.d != R(0)) {
+      axpy(gd, v.d / r, d);
+      any = true;
+    }
+    const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
+    const R whb = weight_lookup(P, HYDR_EPS_00, wk);
+    const FD<R> F1 = (whb != R(0) || PG::on) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
+    const FD<R> F2 = f2_eval(r, P, CRST_RLOW);
+    const bool hb_on = (F1.f != R(0) || F1.d != R(0));
+    const bool cr_on = (F2.f != R(0) || F2.d != R(0));
+    if (hb_on || cr_on) {
+      const R ir = R(1) / r;
+      const V3<R> n = ir * d;
+      const R c1 = -dot(s.a1, o.a1);
+      const R c4 = dot(s.a3, o.a3);
+      const R cs1 = dot(s.a1, n);   // theta3 if p, theta2 if q
+      const R co1 = -dot(o.a1, n);  // theta2 if p, theta3 if q
+      const R cs3 = dot(s.a3, n);   // theta8 (pi - acos) if p, theta7 if q
+      const R co3 = -dot(o.a3, n);  // theta7 if p, theta8 (pi - acos) if q
+      const FD<R> t1 = acos_clamped(c1), t4 = acos_clamped(c4);
+      const FD<R> ts1 = acos_clamped(cs1), to1 = acos_clamped(co1);
+      FD<R> ts3 = acos_clamped(cs3), to3 = acos_clamped(co3);
+      if (role_p) {
+        ts3.f = R(kPi) - ts3.f;
+        ts3.d = -ts3.d;
+      } else {
+        to3.f = R(kPi) - to3.f;
+        to3.d = -to3.d;
+      }
+      R k1 = R(0), k4 = R(0), ks1 = R(0), ko1 = R(0), ks3 = R(0), ko3 = R(0), krad = R(0);
+      if (hb_on) {
+        const F4P<R> p1 = f4_params(P, HYDR_TH1_T0), p4 = f4_params(P, HYDR_TH4_T0);
+        const F4P<R> ps1 = f4_params_sel(P, role_p, HYDR_TH3_T0, HYDR_TH2_T0);
+        const F4P<R> po1 = f4_params_sel(P, role_p, HYDR_TH2_T0, HYDR_TH3_T0);
+        const F4P<R> ps3 = f4_params_sel(P, role_p, HYDR_TH8_T0, HYDR_TH7_T0);
+        const F4P<R> po3 = f4_params_sel(P, role_p, HYDR_TH7_T0, HYDR_TH8_T0);
+        const FD<R> A1 = f4_eval(t1.f, p1), A4 = f4_eval(t4.f, p4);
+        const FD<R> As1 = f4_eval(ts1.f, ps1), Ao1 = f4_eval(to1.f, po1);
+        const FD<R> As3 = f4_eval(ts3.f, ps3), Ao3 = f4_eval(to3.f, po3);
+        const R ang = A1.f * A4.f * As1.f * Ao1.f * As3.f * Ao3.f;
+        if (ang != R(0)) {
+          const R vhb = F1.f * ang;
+          e[T_HB] += wgt * whb * vhb;
+          const R o1 = A4.f * As1.f * Ao1.f * As3.f * Ao3.f, o4 = A1.f * As1.f * Ao1.f * As3.f * Ao3.f;
+          const R os1 = A1.f * A4.f * Ao1.f * As3.f * Ao3.f, oo1 = A1.f * A4.f * As1.f * As3.f * Ao3.f;
+          const R os3 = A1.f * A4.f * As1.f * Ao1.f * Ao3.f, oo3 = A1.f * A4.f * As1.f * Ao1.f * As3.f;
+          const R wf = whb * F1.f;
+          if constexpr (PG::on) {
+            pg.add(HYDR_EPS_00 + wk, vhb);
+            f1_pgrad(r, P, HYDR_RLOW, whb * ang, pg);
+            f4_pgrad(t1.f, p1, wf * o1, pg);
+            f4_pgrad(t4.f, p4, wf * o4, pg);
+            f4_pgrad(ts1.f, ps1, wf * os1, pg);
+            f4_pgrad(to1.f, po1, wf * oo1, pg);
+            f4_pgrad(ts3.f, ps3, wf * os3, pg);
+            f4_pgrad(to3.f, po3, wf * oo3, pg);
+          }
+          if constexpr (GRAD) {
+            krad += whb * F1.d * ang;
+            k1 += wf * o1 * A1.d * t1.d;
+            k4 += wf * o4 * A4.d * t4.d;
+            ks1 += wf * os1 * As1.d * ts1.d;
+            ko1 += wf * oo1 * Ao1.d * to1.d;
+            ks3 += wf * os3 * As3.d * ts3.d;
+            ko3 += wf * oo3 * Ao3.d * to3.d;
+          }
+        }
+      }
+      if (cr_on) {
+        const F4P<R> p1 = f4_params(P, CRST_TH1_T0);
+        const F4P<R> ps1 = f4_params_sel(P, role_p, CRST_TH3_T0, CRST_TH2_T0);
+        const F4P<R> po1 = f4_params_sel(P, role_p, CRST_TH2_T0, CRST_TH3_T0);
+        const FD<R> A1 = f4_eval(t1.f, p1), As1 = f4_eval(ts1.f, ps1), Ao1 = f4_eval(to1.f, po1);
+        const R a123 = A1.f * As1.f * Ao1.f;
+        if (a123 != R(0)) {
+          const F4P<R> p4 = f4_params(P, CRST_TH4_T0);
+          const F4P<R> ps3 = f4_params_sel(P, role_p, CRST_TH8_T0, CRST_TH7_T0);
+          const F4P<R> po3 = f4_params_sel(P, role_p, CRST_TH7_T0, CRST_TH8_T0);
+          const FD<R> A4a = f4_eval(t4.f, p4), A4b = f4_eval(R(kPi) - t4.f, p4);
+          const FD<R> Sa = f4_eval(ts3.f, ps3), Sb = f4_eval(R(kPi) - ts3.f, ps3);
+          const FD<R> Oa = f4_eval(to3.f, po3), Ob = f4_eval(R(kPi) - to3.f, po3);
+          const R H4 = A4a.f + A4b.f, Hs = Sa.f + Sb.f, Ho = Oa.f + Ob.f;
+          const R ang = a123 * H4 * Hs * Ho;
+          if (ang != R(0)) {
+            e[T_CRST] += wgt * F2.f * ang;
+            const R hh = H4 * Hs * Ho;
+            const R o1 = As1.f * Ao1.f * hh, os1 = A1.f * Ao1.f * hh, oo1 = A1.f * As1.f * hh;
+            const R o4 = a123 * Hs * Ho, os3 = a123 * H4 * Ho, oo3 = a123 * H4 * Hs;
+            if constexpr (PG::on) {
+              f2_pgrad(r, P, CRST_RLOW, ang, pg);
+              f4_pgrad(t1.f, p1, F2.f * o1, pg);
+              f4_pgrad(ts1.f, ps1, F2.f * os1, pg);
+              f4_pgrad(to1.f, po1, F2.f * oo1, pg);
+              f4_pgrad(t4.f, p4, F2.f * o4, pg);
+              f4_pgrad(R(kPi) - t4.f, p4, F2.f * o4, pg);
+              f4_pgrad(ts3.f, ps3, F2.f * os3, pg);
+              f4_pgrad(R(kPi) - ts3.f, ps3, F2.f * os3, pg);
+              f4_pgrad(to3.f, po3, F2.f * oo3, pg);
+              f4_pgrad(R(kPi) - to3.f, po3, F2.f * oo3, pg);
+            }
+            if constexpr (GRAD) {
+              krad += F2.d * ang;
+              k1 += F2.f * o1 * A1.d * t1.d;
+              ks1 += F2.f * os1 * As1.d * ts1.d;
+              ko1 += F2.f * oo1 * Ao1.d * to1.d;
+              k4 += F2.f * o4 * (A4a.d - A4b.d) * t4.d;
+              ks3 += F2.f * os3 * (Sa.d - Sb.d) * ts3.d;
+              ko3 += F2.f * oo3 * (Oa.d - Ob.d) * to3.d;
+            }
+          }
+        }
+      }
+      if constexpr (GRAD) {
+        if (krad != R(0) || k1 != R(0) || k4 != R(0) || ks1 != R(0) || ko1 != R(0) || ks3 != R(0) || ko3 != R(0)) {
+          any = true;
+          axpy(gd, krad, n);
+          axpy(sg.g1, -k1, o.a1);
+          axpy(sg.g3, k4, o.a3);
+          axpy(sg.g1, ks1, n);
+          acc_dir(gd, ks1, R(1), cs1, s.a1, n, ir);
+          acc_dir(gd, ko1, R(-1), co1, o.a1, n, ir);
+          axpy(sg.g3, ks3, n);
+          acc_dir(gd, ks3, R(1), cs3, s.a3, n, ir);
+          acc_dir(gd, ko3, R(-1), co3, o.a3, n, ir);
+        }
+      }
+    }
+    if constexpr (GRAD)
+      if (any) acc_self_site(sg, gd, g_ba, R(0));
+  }
+  // ---- coaxial stacking on the stacking sites.  Reference: dr = stack_q - stack_p,
+  //      theta5 = acos(a3p.n), theta6 = acos(-a3q.n); self/other cosines a3s.n and -a3o.n.
+  {
+    const V3<R> d = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
+    const R r = m_sqrt(dot(d, d));
+    const FD<R> F2 = f2_eval(r, P, CXST_RLOW);
+    if (F2.f == R(0) && F2.d == R(0)) return;
+    const R ir = R(1) / r;
+    const V3<R> n = ir * d;
+    const R c4 = dot(s.a3, o.a3);
+    const R c1 = -dot(s.a1, o.a1);
+    const R cs = dot(s.a3, n);   // theta5 if p, theta6 if q
+    const R co = -dot(o.a3, n);  // theta6 if p, theta5 if q
+    const FD<R> t4 = acos_clamped(c4), t1 = acos_clamped(c1), ts = acos_clamped(cs), to = acos_clamped(co);
+    const F4P<R> p4 = f4_params(P, CXST_TH4_T0), p1 = f4_params(P, CXST_TH1_T0);
+    const F4P<R> ps = f4_params_sel(P, role_p, CXST_TH5_T0, CXST_TH6_T0);
+    const F4P<R> po = f4_params_sel(P, role_p, CXST_TH6_T0, CXST_TH5_T0);
+    const FD<R> A4 = f4_eval(t4.f, p4);
+    if (A4.f == R(0)) return;
+    const FD<R> Sa = f4_eval(ts.f, ps), Sb = f4_eval(R(kPi) - ts.f, ps);
+    const R Hs = Sa.f + Sb.f;
+    if (Hs == R(0)) return;
+    const FD<R> Oa = f4_eval(to.f, po), Ob = f4_eval(R(kPi) - to.f, po);
+    const R Ho = Oa.f + Ob.f;
+    if (Ho == R(0)) return;
+    const FD<R> A1a = f4_eval(t1.f, p1);
+    FD<R> A1b;
+    R dH1;
+    if constexpr (MODEL == 1) {
+      A1b = f4_eval(R(2 * kPi) - t1.f, p1);
+      dH1 = A1a.d - A1b.d;
+    } else {
+      A1b = f6_eval(t1.f, P, CXST_F6_A);
+      dH1 = A1a.d + A1b.d;
+    }
+    const R H1 = A1a.f + A1b.f;
+    if (H1 == R(0)) return;
+    R phi = R(1);
+    FD<R> Bs{R(1), R(0)}, Bo{R(1), R(0)};
+    R xs = R(0), xo = R(0), irb = R(0);
+    V3<R> nb{R(0), R(0), R(0)};
+    F5P<R> qs{}, qo{};
+    if constexpr (MODEL == 1) {
+      // cos(phi3) = n.(nb x a1q), cos(phi4) = n.(nb x a1p): both vectors flip with the role, the
+      // triple product does not.
+      const V3<R> db = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+      irb = m_rsqrt(dot(db, db));
+      nb = irb * db;
+      xs = dot(n, cross(nb, s.a1));
+      xo = dot(n, cross(nb, o.a1));
+      qs = f5_params_sel(P, role_p, CXST_PHI4_XS, CXST_PHI3_XS);
+      qo = f5_params_sel(P, role_p, CXST_PHI3_XS, CXST_PHI4_XS);
+      Bs = f5_eval(xs, qs);
+      Bo = f5_eval(xo, qo);
+      phi = Bs.f * Bo.f;
+      if (phi == R(0)) return;
+    }
+    const R ang = A4.f * H1 * Hs * Ho;
+    e[T_CXST] += wgt * F2.f * ang * phi;
+    if constexpr (PG::on) {
+      f2_pgrad(r, P, CXST_RLOW, ang * phi, pg);
+      const R s4 = F2.f * H1 * Hs * Ho * phi, s1 = F2.f * A4.f * Hs * Ho * phi;
+      const R ss = F2.f * A4.f * H1 * Ho * phi, so = F2.f * A4.f * H1 * Hs * phi;
+      f4_pgrad(t4.f, p4, s4, pg);
+      f4_pgrad(t1.f, p1, s1, pg);
+      if constexpr (MODEL == 1) {
+        f4_pgrad(R(2 * kPi) - t1.f, p1, s1, pg);
+        f5_pgrad(xs, qs, F2.f * ang * Bo.f, pg);
+        f5_pgrad(xo, qo, F2.f * ang * Bs.f, pg);
+      } else {
+        f6_pgrad(t1.f, P, CXST_F6_A, s1, pg);
+      }
+      f4_pgrad(ts.f, ps, ss, pg);
+      f4_pgrad(R(kPi) - ts.f, ps, ss, pg);
+      f4_pgrad(to.f, po, so, pg);
+      f4_pgrad(R(kPi) - to.f, po, so, pg);
+    }
+    if constexpr (GRAD) {
+      V3<R> gd{R(0), R(0), R(0)};
+      axpy(gd, F2.d * ang * phi, n);
+      axpy(sg.g3, F2.f * H1 * Hs * Ho * phi * A4.d * t4.d, o.a3);
+      axpy(sg.g1, -(F2.f * A4.f * Hs * Ho * phi * dH1 * t1.d), o.a1);
+      const R ks = F2.f * A4.f * H1 * Ho * phi * (Sa.d - Sb.d) * ts.d;
+      axpy(sg.g3, ks, n);
+      acc_dir(gd, ks, R(1), cs, s.a3, n, ir);
+      const R ko = F2.f * A4.f * H1 * Hs * phi * (Oa.d - Ob.d) * to.d;
+      acc_dir(gd, ko, R(-1), co, o.a3, n, ir);
+      if constexpr (MODEL == 1) {
+        // t = n.(nb x a):  dt/da = n x nb,  dt/dn = nb x a,  dt/dnb = a x n
+        V3<R> gn{R(0), R(0), R(0)}, gnb{R(0), R(0), R(0)};
+        const R kxs = F2.f * ang * Bo.f * Bs.d, kxo = F2.f * ang * Bs.f * Bo.d;
+        axpy(sg.g1, kxs, cross(n, nb));
+        axpy(gn, kxs, cross(nb, s.a1));
+        axpy(gnb, kxs, cross(s.a1, n));
+        axpy(gn, kxo, cross(nb, o.a1));
+        axpy(gnb, kxo, cross(o.a1, n));
+        axpy(gd, ir, gn);
+        axpy(gd, -ir * dot(gn, n), n);
+        V3<R> gdb{R(0), R(0), R(0)};
+        axpy(gdb, irb, gnb);
+        axpy(gdb, -irb * dot(gnb, nb), nb);
+        acc_self_site(sg, gdb, g_k1, g_k2);
+      }
+      acc_self_site(sg, gd, g_st, R(0));
+    }
+  }
+}
+
+}  // namespace mythos

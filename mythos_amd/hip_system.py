@@ -1,0 +1,231 @@
+"""Thin object wrappers over the C ABI handles (device memory is owned by torch tensors).
+
+``OxdnaSystem``  <-> mythos_system_t   (topology + parameters + neighbour rows)
+``LangevinIntegrator`` <-> mythos_sim_t
+
+These are plumbing: they validate shapes/dtypes/devices and forward pointers.  The reference-
+shaped API (EnergyFunction / Simulator protocols) lives in ``mythos_amd.energy`` and
+``mythos_amd.simulators`` on top of them.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from mythos_amd import _lib
+
+N_TERMS = 8
+TRACE_WIDTH = 10
+TERM_NAMES = (
+    "fene",
+    "bonded_excluded_volume",
+    "stacking",
+    "unbonded_excluded_volume",
+    "hydrogen_bonding",
+    "cross_stacking",
+    "coaxial_stacking",
+    "debye",
+)
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return 0
+    if dtype == torch.float64:
+        return 1
+    raise ValueError(f"unsupported dtype {dtype}: use torch.float32 or torch.float64")
+
+
+class OxdnaSystem:
+    """One oxDNA system on one GPU."""
+
+    def __init__(self, model: int, seq, is_end, bonded, box=None, dtype=torch.float32, device=None):
+        lib = _lib.load()
+        if _lib.device_count() == 0 or not torch.cuda.is_available():
+            raise _lib.MythosHipError("no HIP device visible: the mythos_amd HIP path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("OxdnaSystem needs a cuda (HIP) device")
+        self.dtype = dtype
+        self.model = int(model)
+        seq = np.ascontiguousarray(seq, dtype=np.int32)
+        self.n = int(seq.shape[0])
+        is_end = np.zeros(self.n, np.uint8) if is_end is None else np.ascontiguousarray(is_end, dtype=np.uint8)
+        bonded = np.ascontiguousarray(bonded, dtype=np.int32).reshape(-1, 2)
+        box_arr = None if box is None else np.ascontiguousarray(np.broadcast_to(np.asarray(box, np.float64), (3,)))
+        self.box = box_arr
+        self._h = lib.mythos_oxdna_create(
+            self.model,
+            self.n,
+            seq.ctypes.data_as(_lib.c_int_p),
+            is_end.ctypes.data_as(_lib.c_uint8_p),
+            int(bonded.shape[0]),
+            bonded.ctypes.data_as(_lib.c_int_p),
+            None if box_arr is None else box_arr.ctypes.data_as(_lib.c_double_p),
+            _dtype_code(dtype),
+            self.device.index or 0,
+        )
+        if not self._h:
+            raise _lib.MythosHipError(f"mythos_oxdna_create: {_lib.last_error()}")
+        self._lib = lib
+        self.n_params = lib.mythos_oxdna_param_count()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_oxdna_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    # ---- parameters / neighbours -------------------------------------------------------------
+    def set_params(self, flat) -> None:
+        flat = np.ascontiguousarray(torch.as_tensor(flat).detach().cpu().numpy(), dtype=np.float64)
+        _lib.check(
+            self._lib.mythos_oxdna_set_params(self._h, flat.ctypes.data_as(_lib.c_double_p), int(flat.shape[0])),
+            "set_params",
+        )
+
+    def set_neighbors(self, pairs) -> None:
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+        if pairs.ndim != 2 or (pairs.size and pairs.shape[1] != 2):
+            raise ValueError("pairs must have shape (P, 2)")
+        _lib.check(
+            self._lib.mythos_oxdna_set_neighbors(self._h, pairs.ctypes.data_as(_lib.c_int_p), int(pairs.shape[0])),
+            "set_neighbors",
+        )
+
+    def build_neighbors(self, center: torch.Tensor, r_cut: float, skin: float) -> None:
+        c = self._check(center, (self.n, 3), "center")
+        _lib.check(
+            self._lib.mythos_oxdna_build_neighbors(self._h, _lib.ptr(c), float(r_cut), float(skin), _stream(self.device)),
+            "build_neighbors",
+        )
+
+    def neighbor_stats(self) -> tuple[int, float]:
+        mx, mean = C.c_int(0), C.c_double(0.0)
+        _lib.check(self._lib.mythos_oxdna_neighbor_stats(self._h, C.byref(mx), C.byref(mean)), "neighbor_stats")
+        return mx.value, mean.value
+
+    # ---- energy --------------------------------------------------------------------------------
+    def _check(self, t: torch.Tensor, tail: tuple, name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor) or t.device != self.device:
+            raise ValueError(f"{name} must be a torch tensor on {self.device}")
+        if t.dtype != self.dtype:
+            raise ValueError(f"{name} must have dtype {self.dtype}, got {t.dtype}")
+        if tuple(t.shape[-len(tail):]) != tail:
+            raise ValueError(f"{name} must have trailing shape {tail}, got {tuple(t.shape)}")
+        return t.contiguous()
+
+    def energy(self, center, quat, *, grads=False, param_grads=False):
+        """Term energies (F, 8) [float64] and optionally dU/dcenter, dU/dquat, dU/dflat.
+
+        ``center`` (F, N, 3) or (N, 3); ``quat`` likewise with 4.
+        """
+        single = center.dim() == 2
+        c = self._check(center, (self.n, 3), "center")
+        q = self._check(quat, (self.n, 4), "quat")
+        if single:
+            c, q = c[None], q[None]
+        nf = c.shape[0]
+        if q.shape[0] != nf:
+            raise ValueError("center and quat disagree on the number of frames")
+        e = torch.empty((nf, N_TERMS), dtype=torch.float64, device=self.device)
+        gc = torch.empty_like(c) if grads else None
+        gq = torch.empty_like(q) if grads else None
+        gp = torch.empty((nf, self.n_params), dtype=torch.float64, device=self.device) if param_grads else None
+        _lib.check(
+            self._lib.mythos_oxdna_energy(
+                self._h, _lib.ptr(c), _lib.ptr(q), nf, _lib.ptr(e), _lib.ptr(gc), _lib.ptr(gq), _lib.ptr(gp),
+                _stream(self.device),
+            ),
+            "energy",
+        )
+        if single:
+            e = e[0]
+            gc = gc[0] if grads else None
+            gq = gq[0] if grads else None
+            gp = gp[0] if param_grads else None
+        return e, gc, gq, gp
+
+
+class LangevinIntegrator:
+    """BAOAB rigid-body Langevin dynamics bound to an :class:`OxdnaSystem`."""
+
+    def __init__(self, system: OxdnaSystem, dt, kT, gamma_t, gamma_r, mass=1.0, inertia=(1.0, 1.0, 1.0), seed=0):
+        self.system = system
+        self._lib = system._lib
+        inertia = np.ascontiguousarray(inertia, dtype=np.float64)
+        self._h = self._lib.mythos_langevin_create(
+            system._h, float(dt), float(kT), float(gamma_t), float(gamma_r), float(mass),
+            inertia.ctypes.data_as(_lib.c_double_p), C.c_uint64(int(seed) & (2**64 - 1)),
+        )
+        if not self._h:
+            raise _lib.MythosHipError(f"mythos_langevin_create: {_lib.last_error()}")
+        self.dt, self.kT = float(dt), float(kT)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_langevin_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def set_neighbor_policy(self, r_cut: float, skin: float, every: int) -> None:
+        _lib.check(
+            self._lib.mythos_langevin_set_neighbor_policy(self._h, float(r_cut), float(skin), int(every)),
+            "set_neighbor_policy",
+        )
+
+    def init_momenta(self):
+        s = self.system
+        p = torch.empty((s.n, 3), dtype=s.dtype, device=s.device)
+        ang = torch.empty((s.n, 3), dtype=s.dtype, device=s.device)
+        _lib.check(self._lib.mythos_langevin_init_momenta(self._h, _lib.ptr(p), _lib.ptr(ang), _stream(s.device)), "init_momenta")
+        return p, ang
+
+    def run(self, center, quat, p_lin, p_ang, n_steps: int, save_every: int = 0, want_energy: bool = True):
+        """Advance in place; returns (traj_center, traj_quat, e_trace) or Nones when save_every == 0."""
+        s = self.system
+        for t, tail, name in ((center, (s.n, 3), "center"), (quat, (s.n, 4), "quat"), (p_lin, (s.n, 3), "p_lin"), (p_ang, (s.n, 3), "p_ang")):
+            if s._check(t, tail, name).data_ptr() != t.data_ptr():
+                raise ValueError(f"{name} must be contiguous (it is updated in place)")
+        n_save = n_steps // save_every if save_every > 0 else 0
+        tc = torch.empty((n_save, s.n, 3), dtype=s.dtype, device=s.device) if n_save else None
+        tq = torch.empty((n_save, s.n, 4), dtype=s.dtype, device=s.device) if n_save else None
+        et = torch.zeros((n_save, TRACE_WIDTH), dtype=torch.float64, device=s.device) if (n_save and want_energy) else None
+        _lib.check(
+            self._lib.mythos_langevin_run(
+                self._h, _lib.ptr(center), _lib.ptr(quat), _lib.ptr(p_lin), _lib.ptr(p_ang), int(n_steps),
+                int(save_every), _lib.ptr(tc), _lib.ptr(tq), _lib.ptr(et), _stream(s.device),
+            ),
+            "langevin_run",
+        )
+        return tc, tq, et
+
+    @property
+    def step(self) -> int:
+        return int(self._lib.mythos_langevin_get_step(self._h))
+
+    @step.setter
+    def step(self, value: int) -> None:
+        _lib.check(self._lib.mythos_langevin_set_step(self._h, int(value)), "set_step")
+
+    def last_kernel_ms(self) -> tuple[float, int]:
+        ms, n = C.c_double(0.0), C.c_int(0)
+        _lib.check(self._lib.mythos_langevin_last_kernel_ms(self._h, C.byref(ms), C.byref(n)), "last_kernel_ms")
+        return ms.value, n.value

@@ -1,0 +1,216 @@
+"""GPU parity: HIP energies / forces / quaternion gradients / dU/dtheta through the C ABI
+vs the CPU oracle and the oxDNA golden files.
+
+Tolerances (BASELINE.json north_star): 1e-5 relative in fp64, 1e-3 in fp32; the golden-file
+comparisons use the reference's own tolerances (dna2/tests/test_integration.py:94..374).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd import _lib
+from mythos_amd.energy import flat_params as fp
+from mythos_amd.input import defaults
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (1, "simple-helix", False),
+    (1, "simple-coax", False),
+    (2, "simple-helix", False),
+    (2, "simple-coax", False),
+    (2, "simple-helix-half-charged-ends", True),
+]
+
+
+def _system(model, top, traj, hce, dtype, overrides=None):
+    from mythos_amd.hip_system import OxdnaSystem
+
+    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    for sec, d in (overrides or {}).items():
+        cfg[sec].update(d)
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=dtype)
+    s.set_params(flat)
+    s.set_neighbors(top.unbonded_neighbors)
+    return s
+
+
+def _frames(traj, dtype, dev, idx=None):
+    c = traj.center if idx is None else traj.center[idx]
+    q = traj.quaternions if idx is None else traj.quaternions[idx]
+    return torch.as_tensor(c, dtype=dtype, device=dev), torch.as_tensor(q, dtype=dtype, device=dev)
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), CASES)
+def test_fp64_terms_match_oracle_and_golden(model, name, hce):
+    top, traj, split, energy = H.load_golden(model, name)
+    s = _system(model, top, traj, hce, torch.float64)
+    c, q = _frames(traj, torch.float64, s.device)
+    e, _, _, _ = s.energy(c, q)
+    e = e.cpu().numpy() / top.n_nucleotides
+    P = H.oracle_params(model, half_charged_ends=hce)
+    ref = H.oracle_terms_traj(model, P, top, traj, use_axes=False)
+    nt = ref.shape[1]
+    np.testing.assert_allclose(e[:, :nt], ref, rtol=1e-9, atol=1e-11)
+    if model == 1:
+        assert np.all(e[:, 7] == 0.0)
+    for k in range(nt):
+        term = H.SPLIT_COLUMNS[1 + k]
+        if model == 1 and name == "simple-coax" and term == "stacking":
+            continue
+        np.testing.assert_allclose(np.around(e[:, k], 6), split[:, 1 + k], atol=H.TERM_ATOL[term], err_msg=term)
+    np.testing.assert_allclose(e.sum(1), energy, atol=1e-3 if model == 2 else 1e-4)
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), CASES)
+def test_fp32_terms_within_1e3(model, name, hce):
+    top, traj, split, _ = H.load_golden(model, name)
+    s = _system(model, top, traj, hce, torch.float32)
+    c, q = _frames(traj, torch.float32, s.device)
+    e, _, _, _ = s.energy(c, q)
+    e = e.cpu().numpy()
+    P = H.oracle_params(model, half_charged_ends=hce)
+    ref = H.oracle_terms_traj(model, P, top, traj, use_axes=False) * top.n_nucleotides
+    tot = np.abs(ref).sum(1, keepdims=True)
+    assert np.max(np.abs(e[:, : ref.shape[1]] - ref) / tot) < 1e-3
+    np.testing.assert_allclose(e.sum(1), ref.sum(1), rtol=1e-3)
+
+
+def _oracle_grads(model, P, top, traj, f):
+    from oracle import oxdna_oracle as orc
+
+    seq, is_end, b, u = H.topo_tensors(top)
+    return orc.energy_and_grads(
+        model, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, u, box=traj.box_size
+    )
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), CASES)
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_forces_and_quaternion_gradients(model, name, hce, dtype):
+    top, traj, _, _ = H.load_golden(model, name)
+    s = _system(model, top, traj, hce, dtype)
+    frames = [0, 17, 42, 99]
+    c, q = _frames(traj, dtype, s.device, frames)
+    e, gc, gq, _ = s.energy(c, q, grads=True)
+    P = H.oracle_params(model, half_charged_ends=hce)
+    tol = 1e-5 if dtype == torch.float64 else 1e-3
+    for k, f in enumerate(frames):
+        u, rc, rq = _oracle_grads(model, P, top, traj, f)
+        scale_c = rc.abs().max().item()
+        scale_q = rq.abs().max().item()
+        assert abs(e[k].sum().item() - u.item()) <= tol * abs(u.item())
+        assert (gc[k].cpu().double() - rc).abs().max().item() <= tol * scale_c
+        assert (gq[k].cpu().double() - rq).abs().max().item() <= tol * scale_q
+
+
+def test_energy_is_the_same_from_all_three_kernel_modes():
+    """energy-only, +gradient and +parameter-partial launches report the same energies (fp64
+    round-off only: the instantiations differ in FMA contraction) and each is run-to-run bitwise."""
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s = _system(2, top, traj, False, torch.float64)
+    c, q = _frames(traj, torch.float64, s.device, [3, 4])
+    e0, _, _, _ = s.energy(c, q)
+    e1, _, _, _ = s.energy(c, q, grads=True)
+    e2, _, _, _ = s.energy(c, q, grads=True, param_grads=True)
+    torch.testing.assert_close(e0, e1, rtol=1e-13, atol=1e-14)
+    torch.testing.assert_close(e0, e2, rtol=1e-13, atol=1e-14)
+    assert torch.equal(e0, s.energy(c, q)[0])
+    assert torch.equal(e1, s.energy(c, q, grads=True)[0])
+
+
+def _leaf_cfg(model):
+    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    leaves = {}
+    for sec, d in cfg.items():
+        if sec == "geometry":
+            continue
+        for k, v in d.items():
+            t = torch.tensor(float(v), dtype=torch.float64, requires_grad=True)
+            d[k] = t
+            leaves[(sec, k)] = t
+    return sim, cfg, leaves
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), [(1, "simple-helix", False), (2, "simple-helix", True), (2, "simple-coax", False), (1, "simple-coax", False)])
+def test_parameter_gradients_chain_rule(model, name, hce):
+    """dU/dtheta for every independent parameter: HIP partials + host chain rule vs oracle autograd
+    (the stand-in for jax.value_and_grad, mythos/optimization/objective.py:235)."""
+    from mythos_amd.hip_system import OxdnaSystem
+    from oracle import oxdna_oracle as orc
+
+    top, traj, _, _ = H.load_golden(model, name)
+    frames = [5, 60]
+    # ---- HIP side
+    sim, cfg, leaves = _leaf_cfg(model)
+    kt = torch.tensor(sim["kT"], dtype=torch.float64, requires_grad=True)
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=kt, salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
+    s.set_params(flat)
+    s.set_neighbors(top.unbonded_neighbors)
+    c, q = _frames(traj, torch.float64, s.device, frames)
+    e, _, _, gflat = s.energy(c, q, param_grads=True)
+    keys = list(leaves)
+    hip = []
+    for k in range(len(frames)):
+        g = torch.autograd.grad(flat, [leaves[kk] for kk in keys] + [kt], grad_outputs=gflat[k].cpu(), retain_graph=True, allow_unused=True)
+        hip.append([0.0 if x is None else float(x) for x in g])
+    # ---- oracle side (independent restatement of init_params)
+    sim2, cfg2, leaves2 = _leaf_cfg(model)
+    kt2 = torch.tensor(sim2["kT"], dtype=torch.float64, requires_grad=True)
+    P = orc.init_all(model, cfg2, kt=kt2, salt_conc=0.5, half_charged_ends=hce)
+    seq, is_end, b, u = H.topo_tensors(top)
+    for k, f in enumerate(frames):
+        U = orc.energy(model, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, u, box=traj.box_size)
+        g = torch.autograd.grad(U, [leaves2[kk] for kk in keys] + [kt2], retain_graph=True, allow_unused=True)
+        ref = np.array([0.0 if x is None else float(x) for x in g])
+        got = np.array(hip[k])
+        assert abs(e[k].sum().item() - U.item()) < 1e-9 * abs(U.item())
+        scale = np.abs(ref).max()
+        bad = np.abs(got - ref) > 1e-5 * np.maximum(np.abs(ref), 1e-3 * scale)
+        assert not bad.any(), [(keys[i] if i < len(keys) else "kt", got[i], ref[i]) for i in np.nonzero(bad)[0]]
+        assert np.count_nonzero(ref) >= 15  # the comparison is not vacuous
+
+
+def test_sequence_dependent_weights_fp64():
+    top, traj, split, _ = H.load_golden(1, "simple-helix-seq-dep")
+    ss = H.read_ss_weights(H.GOLDEN / "dna1" / "simple-helix-seq-dep" / "seq_dep.dat")
+    ov = {
+        "stacking": {"ss_stack_weights": torch.as_tensor(ss["ss_stack_weights"]), "eps_stack_kt_coeff": ss["eps_stack_kt_coeff"]},
+        "hydrogen_bonding": {"ss_hb_weights": torch.as_tensor(ss["ss_hb_weights"])},
+    }
+    s = _system(1, top, traj, False, torch.float64, overrides=ov)
+    c, q = _frames(traj, torch.float64, s.device)
+    e = s.energy(c, q)[0].cpu().numpy() / top.n_nucleotides
+    np.testing.assert_allclose(np.around(e[:, 2], 6), split[:, 3], atol=1e-6)
+    np.testing.assert_allclose(np.around(e[:, 4], 6), split[:, 5], atol=1e-3)
+
+
+def test_gpu_neighbor_build_reproduces_all_pairs_energy():
+    """A Verlet list with the interaction cut-off must give the all-pairs energy (compact support)."""
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s = _system(2, top, traj, False, torch.float64)
+    c, q = _frames(traj, torch.float64, s.device, [10])
+    e_all = s.energy(c, q)[0]
+    s.build_neighbors(c[0], r_cut=3.3, skin=0.2)
+    mx, mean = s.neighbor_stats()
+    assert 0 < mean <= mx <= 14
+    e_list = s.energy(c, q)[0]
+    np.testing.assert_allclose(e_list.cpu().numpy(), e_all.cpu().numpy(), rtol=1e-12, atol=1e-13)
+
+
+def test_error_conventions():
+    from mythos_amd.hip_system import OxdnaSystem
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
+    c, q = _frames(traj, torch.float64, s.device, [0])
+    with pytest.raises(_lib.MythosHipError):  # parameters / neighbours not set
+        s.energy(c, q)
+    with pytest.raises(ValueError):
+        s.set_params(np.zeros(3))
+    with pytest.raises(ValueError):
+        s.energy(c.float(), q.float())
