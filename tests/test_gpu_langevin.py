@@ -1,0 +1,192 @@
+"""GPU tests of the fused Langevin step kernel (mythos_langevin_run).
+
+The reference pins nothing here (its simulator tests use a fake integrator), so:
+ * step-by-step parity in fp64 against oracle/langevin_oracle.py fed with the same Philox stream,
+ * physics: NVE drift, equipartition, <U> vs oxDNA's own Langevin run (golden energy.dat),
+ * plumbing: determinism, save cadence, dynamic Verlet list == static all-pairs list.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd import _lib
+from mythos_amd.energy import flat_params as fp
+from mythos_amd.input import defaults
+from mythos_amd.utils import generators
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+KT = 296.15 * 0.1 / 300.0
+
+
+def _make(model, top, box, dtype, hce=False):
+    from mythos_amd.hip_system import OxdnaSystem
+
+    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=dtype)
+    s.set_params(flat)
+    return s, sim
+
+
+def _state(c, q, dtype, dev):
+    return torch.as_tensor(c, dtype=dtype, device=dev).contiguous(), torch.as_tensor(q, dtype=dtype, device=dev).contiguous()
+
+
+def test_step_by_step_parity_with_oracle_fp64():
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle.langevin_oracle import LangevinOracle
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s, sim = _make(2, top, traj.box_size, torch.float64)
+    s.set_neighbors(top.unbonded_neighbors)
+    gam_t, gam_r = KT / 2.5, KT / 7.5
+    integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.3, 0.8), seed=0x1234ABCD5678)
+    c, q = _state(traj.center[0], traj.quaternions[0], torch.float64, s.device)
+    p, L = integ.init_momenta()
+    x0, q0, p0, L0 = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    n_steps = 6
+    tc, tq, et = integ.run(c, q, p, L, n_steps, save_every=1)
+    orc = LangevinOracle(
+        2, H.oracle_params(2), H.topo_tensors(top), traj.box_size, 0.005, KT, gam_t, gam_r, 1.0, (1.0, 1.3, 0.8), seed=0x1234ABCD5678
+    )
+    x, qq, pp, LL = x0, q0, p0, L0
+    for k in range(n_steps):
+        x, qq, pp, LL, u = orc.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-10)
+        assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
+        ke_t, ke_r = orc.kinetic(pp, LL)
+        assert abs(et[k, 8].item() - ke_t) < 1e-9 * ke_t
+        assert abs(et[k, 9].item() - ke_r) < 1e-9 * ke_r
+    np.testing.assert_allclose(c.cpu().numpy(), x, atol=1e-10)
+    np.testing.assert_allclose(p.cpu().numpy(), pp, atol=1e-9)
+    np.testing.assert_allclose(L.cpu().numpy(), LL, atol=1e-9)
+    assert integ.step == n_steps
+
+
+def test_fp32_tracks_fp64_over_short_run():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    out = {}
+    for dtype in (torch.float64, torch.float32):
+        s, _ = _make(2, top, traj.box_size, dtype)
+        s.set_neighbors(top.unbonded_neighbors)
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=7)
+        c, q = _state(traj.center[0], traj.quaternions[0], dtype, s.device)
+        p = torch.zeros_like(c)
+        L = torch.zeros_like(c)
+        integ.run(c, q, p, L, 20)
+        out[dtype] = (c.double().cpu(), q.double().cpu())
+    assert (out[torch.float32][0] - out[torch.float64][0]).abs().max() < 1e-3
+    assert (out[torch.float32][1] - out[torch.float64][1]).abs().max() < 1e-3
+
+
+def test_determinism_and_seed_dependence():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s, _ = _make(2, top, traj.box_size, torch.float32)
+    s.set_neighbors(top.unbonded_neighbors)
+    res = []
+    for seed in (3, 3, 4):
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=seed)
+        c, q = _state(traj.center[0], traj.quaternions[0], torch.float32, s.device)
+        p, L = integ.init_momenta()
+        integ.run(c, q, p, L, 200)
+        res.append((c.clone(), q.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert not torch.equal(res[0][0], res[2][0])
+
+
+def test_split_runs_equal_one_run():
+    """run(a) then run(b) continues the RNG stream: same result as run(a + b)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s, _ = _make(2, top, traj.box_size, torch.float64)
+    s.set_neighbors(top.unbonded_neighbors)
+    outs = []
+    for plan in ((50,), (20, 30)):
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=11)
+        c, q = _state(traj.center[0], traj.quaternions[0], torch.float64, s.device)
+        p, L = integ.init_momenta()
+        for n in plan:
+            integ.run(c, q, p, L, n)
+        outs.append(c.clone())
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-11)
+
+
+def test_nve_energy_conservation_fp64():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s, _ = _make(2, top, traj.box_size, torch.float64)
+    s.set_neighbors(top.unbonded_neighbors)
+    integ = LangevinIntegrator(s, dt=0.002, kT=KT, gamma_t=0.0, gamma_r=0.0, seed=5)
+    c, q = _state(traj.center[0], traj.quaternions[0], torch.float64, s.device)
+    p, L = integ.init_momenta()
+    _, _, et = integ.run(c, q, p, L, 4000, save_every=100)
+    tot = et.sum(1).cpu().numpy()
+    n = top.n_nucleotides
+    assert np.ptp(tot) / n < 2e-3, tot / n  # bounded fluctuation, no drift
+    assert abs(tot[-1] - tot[0]) / n < 2e-3
+
+
+def test_equipartition_and_mean_potential_energy():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, energy = H.load_golden(2, "simple-helix")
+    s, _ = _make(2, top, traj.box_size, torch.float32)
+    s.set_neighbors(top.unbonded_neighbors)
+    # oxDNA's golden run: T = 296.15 K, dt 0.003, diff_coeff 2.5 (tests/golden/dna2/simple-helix/input)
+    integ = LangevinIntegrator(s, dt=0.003, kT=KT, gamma_t=KT / 2.5 * 20, gamma_r=KT / 7.5 * 60, seed=2024)
+    c, q = _state(traj.center[-1], traj.quaternions[-1], torch.float32, s.device)
+    p, L = integ.init_momenta()
+    integ.run(c, q, p, L, 20000)
+    _, _, et = integ.run(c, q, p, L, 200000, save_every=100)
+    et = et.cpu().numpy()
+    n = top.n_nucleotides
+    ke_t, ke_r = et[:, 8].mean(), et[:, 9].mean()
+    assert abs(ke_t / (1.5 * n * KT) - 1.0) < 0.05, ke_t / (1.5 * n * KT)
+    assert abs(ke_r / (1.5 * n * KT) - 1.0) < 0.05, ke_r / (1.5 * n * KT)
+    u = et[:, :8].sum(1).mean() / n
+    assert abs(u - energy.mean()) < 0.06, (u, energy.mean())
+
+
+def test_dynamic_verlet_list_matches_static_all_pairs():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(48, model=2, seed=3)
+    outs = []
+    for dynamic in (False, True):
+        s, _ = _make(2, top, None, torch.float64, hce=True)
+        integ = LangevinIntegrator(s, dt=0.003, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=99)
+        if dynamic:
+            integ.set_neighbor_policy(r_cut=3.3, skin=0.6, every=10)
+        else:
+            s.set_neighbors(top.unbonded_neighbors)
+        c, q = _state(c0, q0, torch.float64, s.device)
+        p, L = integ.init_momenta()
+        integ.run(c, q, p, L, 60)
+        outs.append(c.clone())
+        if dynamic:
+            mx, mean = s.neighbor_stats()
+            assert mean < top.n_nucleotides - 3
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-9)
+
+
+def test_skin_violation_is_reported():
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(16, model=2, seed=3)
+    s, _ = _make(2, top, None, torch.float32, hce=True)
+    integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=1)
+    integ.set_neighbor_policy(r_cut=3.3, skin=0.002, every=1000)
+    c, q = _state(c0, q0, torch.float32, s.device)
+    p, L = integ.init_momenta()
+    with pytest.raises(_lib.MythosHipError, match="skin"):
+        integ.run(c, q, p, L, 200)
