@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MD steps/s of an oxDNA2 12 kbp duplex (24 000 nucleotides, Debye-Hueckel,
+Langevin) per GPU, one independent replica per GPU (BASELINE.json metric / configs[3]).
+
+    python bench.py --gpus 1 --steps 2000 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin.hip).
+The timed region is one ``mythos_langevin_run`` call of K steps with the state resident in HBM,
+bracketed by barrier + synchronize; value = N_gpus * K / max-over-ranks time.  For N > 1 the
+replicas' observables (energy trace) are all-gathered over RCCL inside the timed region.
+
+Rank 0 prints ONE JSON line with the fields of the driver contract plus
+  roofline      HBM roofline of the step kernel (algorithmic bytes / HIP-event kernel time)
+  cpu_baseline  the CPU oracle (torch fp64 restatement, all host cores) timed on a bounded sample
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from mythos_amd import _lib  # noqa: E402
+from mythos_amd.energy import flat_params as fp  # noqa: E402
+from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem  # noqa: E402
+from mythos_amd.input import defaults  # noqa: E402
+from mythos_amd.utils import generators  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+OXDNA_TIME_UNIT_PS = 3.03  # oxDNA simulation time unit
+R_CUT = 3.25  # largest centre-centre interaction range: Debye r_cut 2.2867 + 2 * |backbone offset| 0.4814
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--bp", type=int, default=12000, help="base pairs of the duplex (12000 = headline config)")
+    ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--skin", type=float, default=0.5)
+    ap.add_argument("--rebuild-every", type=int, default=25)
+    ap.add_argument("--dt", type=float, default=0.005)
+    ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
+    ap.add_argument("--cpu-steps", type=int, default=-1, help="CPU-baseline sample size in steps (-1: auto, 0: skip)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_step(n: int, nbar: float, word: int) -> float:
+    """read+write {center 3, quat 4, p 3, L 4} words, 13 B topology,
+    4 B per directed neighbour entry."""
+    return n * (2 * 14 * word + 13 + 4.0 * nbar)
+
+
+def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray) -> dict:
+    """Time the CPU oracle (torch fp64, vectorised over the same Verlet pair list) on the host."""
+    from oracle.langevin_oracle import LangevinOracle
+    from tests import helpers as H
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    P = H.oracle_params(2, half_charged_ends=True)
+    tt = (
+        torch.as_tensor(top.seq, dtype=torch.long),
+        torch.as_tensor(top.is_end, dtype=torch.long),
+        torch.as_tensor(top.bonded_neighbors, dtype=torch.long),
+        torch.as_tensor(pairs, dtype=torch.long),
+    )
+    kT = sim["kT"]
+    o = LangevinOracle(2, P, tt, None, sim["dt"], kT, kT / sim["diff_coef"], kT / sim["rot_diff_coef"], seed=0)
+    x, q = c0.copy(), q0.copy()
+    p, L = np.zeros_like(x), np.zeros_like(x)
+    o.run(x, q, p, L, 1)  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    o.run(x, q, p, L, n_steps)
+    dt = time.perf_counter() - t0
+    return {
+        "value": n_steps / dt,
+        "unit": "steps/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{n_steps} Langevin steps of the same {top.n_nucleotides}-nt system, torch-fp64 oracle over the "
+        f"same Verlet pair list ({len(pairs)} pairs), {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    word = 4 if args.dtype == "f32" else 8
+    sim, cfg = defaults.default_configs_for("dna2")
+    sim["dt"] = args.dt
+    kT = sim["kT"]
+    top, c0, q0 = generators.ideal_duplex(args.bp, model=2, seed=1234)
+    n = top.n_nucleotides
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=sim["salt_conc"], half_charged_ends=True), _lib.param_names())
+    system = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype, device=dev)
+    system.set_params(flat)
+    integ = LangevinIntegrator(
+        system, dt=sim["dt"], kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"],
+        mass=sim["nucleotide_mass"], inertia=sim["moment_of_inertia"], seed=rank,
+    )
+    integ.set_neighbor_policy(R_CUT, args.skin, args.rebuild_every)
+    c = torch.as_tensor(c0, dtype=dtype, device=dev).contiguous()
+    q = torch.as_tensor(q0, dtype=dtype, device=dev).contiguous()
+    p, L = integ.init_momenta()
+
+    # ---- warm-up (untimed): also thermalises the ideal helix
+    integ.run(c, q, p, L, args.warmup)
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    _, _, et = integ.run(c, q, p, L, args.steps, save_every=args.save_every)
+    gathered = None
+    if dist is not None:
+        obs = et if et is not None else torch.zeros((1, 10), dtype=torch.float64, device=dev)
+        gathered = [torch.empty_like(obs) for _ in range(world)]
+        dist.all_gather(gathered, obs)  # RCCL over xGMI: per-replica observables
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    timing = integ.last_kernel_ms()
+    mx, nbar = system.neighbor_stats()
+    assert torch.isfinite(c).all(), "state diverged"
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        alg = algorithmic_bytes_per_step(n, nbar, word)
+        kms = timing["kernel_ms"]
+        achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out = {
+            "metric": "MD steps/sec per GPU, oxDNA2 12 kbp duplex",
+            "value": steps_per_s,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"oxDNA2 {args.bp} bp ideal B-duplex ({n} nt), Debye-Hueckel salt 0.5, half-charged ends, "
+                f"Langevin dt {sim['dt']}, kT {kT:.6f}, free space, 1 replica per GPU",
+                "replicas": world,
+                "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": nbar, "max_row": mx},
+                "ns_per_day": steps_per_s / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "md_step_kernel",
+                "kernel_ms": kms,
+                "loop_ms_per_launch": timing["loop_ms_per_launch"],
+                "algorithmic_bytes_per_launch": alg,
+            },
+        }
+        cpu_steps = args.cpu_steps
+        if cpu_steps < 0:
+            cpu_steps = 3 if n > 8000 else 20
+        if cpu_steps > 0 and world == 1:
+            from mythos_amd.simulators.neighbors import verlet_pairs_numpy
+
+            pairs = verlet_pairs_numpy(c0, top.bonded_neighbors, R_CUT + 0.1)
+            out["cpu_baseline"] = cpu_baseline(top, c0, q0, sim, cpu_steps, pairs)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -136,9 +136,13 @@ int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin
 int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
 int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 
-/* timing hook for bench.py: average device time (ms) of the last run's force+integrate kernel
- * launches measured with HIP events on the launch stream, and the launch count */
-int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* avg_ms, int* launches);
+/* timing hook for bench.py, HIP events on the launch stream of the last run:
+ *   kernel_ms            mean duration of the step kernel over up to 64 launches that were each
+ *                        bracketed by their own event pair (spread evenly over the run)
+ *   loop_ms_per_launch   (last event - first event) / launches: includes neighbour rebuilds and
+ *                        inter-kernel gaps */
+int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, double* loop_ms_per_launch,
+                                   int* launches, int* samples);
 
 /* ---- MARTINI 2/3 ------------------------------------------------------------------------------
  * Replaces mythos/energy/martini/m2/{lj,bond,angle}.py and m3/angle.py.

@@ -62,7 +62,7 @@ def load() -> C.CDLL:
         "mythos_langevin_run": (C.c_int, [V, V, V, V, V, C.c_int, C.c_int, V, V, V, V]),
         "mythos_langevin_get_step": (C.c_int64, [V]),
         "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
-        "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, C.POINTER(C.c_int)]),
+        "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mythos_martini_create": (
             V,
             [C.c_int, c_int_p, C.c_int, c_double_p, c_double_p, C.c_int, c_int_p, c_double_p, c_double_p, C.c_int,

@@ -340,8 +340,13 @@ struct mythos_sim {
   double* d_epart = nullptr;
   int epart_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double last_avg_ms = 0;
+  // sampled per-launch timing: every kSampleStride-th step launch is bracketed by its own event pair
+  static constexpr int kMaxSamples = 64;
+  hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
+  double last_avg_ms = 0;     // (ev1 - ev0) / launches: includes rebuilds and inter-kernel gaps
+  double last_kernel_ms = 0;  // mean over the sampled single-launch intervals
   int last_launches = 0;
+  int last_samples = 0;
 };
 
 namespace mythos {
@@ -394,7 +399,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   if (dynamic_list)
     if (int rc = rebuild(cur)) return rc;
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
-  int launches = 0;
+  int launches = 0, samples = 0;
+  const int sample_stride = std::max(1, (n_steps + 1) / mythos_sim::kMaxSamples);
   for (int k = 0; k <= n_steps; ++k) {
     const bool last = (k == n_steps);
     const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
@@ -406,6 +412,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     R* tc = (save && traj_center) ? traj_center + (size_t)sidx * n * 3 : nullptr;
     R* tq = (save && traj_quat) ? traj_quat + (size_t)sidx * n * 4 : nullptr;
     const V4* ref = (const V4*)sys->d_ref_pos;
+    const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
+    if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, G, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, n,
                          pos[cur], qt[cur], pos[cur ^ 1], qt[cur ^ 1], mom, ang, sys->d_meta, sys->d_rows,
@@ -419,6 +427,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
                          sys->d_row_len, sys->row_stride, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k),
                          ref, sim->d_flags, tc, tq, sim->d_epart);
     }
+    if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sb[samples++], st));
     ++launches;
     cur ^= 1;
   }
@@ -434,6 +443,14 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
   sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
   sim->last_launches = launches;
+  double acc = 0;
+  for (int k = 0; k < samples; ++k) {
+    float t = 0;
+    MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[k], sim->sb[k]));
+    acc += t;
+  }
+  sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  sim->last_samples = samples;
   sim->step += n_steps;
   if (flags & 2) {
     set_error("mythos_langevin_run: NaN in the state (time step too large or overlapping start configuration)");
@@ -485,6 +502,8 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
        hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * kTraceWidth * sizeof(double)) == hipSuccess &&
        hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
+  for (int k = 0; ok && k < mythos_sim::kMaxSamples; ++k)
+    ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;
   if (ok && !sys->d_ref_pos) ok = hipMalloc(&sys->d_ref_pos, v4) == hipSuccess;
   if (!ok) {
     set_error("mythos_langevin_create: device allocation failed");
@@ -506,6 +525,10 @@ void mythos_langevin_destroy(mythos_sim_t* s) {
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (int k = 0; k < mythos_sim::kMaxSamples; ++k) {
+    if (s->sa[k]) (void)hipEventDestroy(s->sa[k]);
+    if (s->sb[k]) (void)hipEventDestroy(s->sb[k]);
+  }
   delete s;
 }
 
@@ -580,13 +603,16 @@ int mythos_langevin_set_step(mythos_sim_t* s, int64_t step) {
   return MYTHOS_OK;
 }
 
-int mythos_langevin_last_kernel_ms(const mythos_sim_t* s, double* avg_ms, int* launches) {
+int mythos_langevin_last_kernel_ms(const mythos_sim_t* s, double* kernel_ms, double* loop_ms_per_launch,
+                                   int* launches, int* samples) {
   if (!s) {
     set_error("mythos_langevin_last_kernel_ms: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (avg_ms) *avg_ms = s->last_avg_ms;
+  if (kernel_ms) *kernel_ms = s->last_kernel_ms;
+  if (loop_ms_per_launch) *loop_ms_per_launch = s->last_avg_ms;
   if (launches) *launches = s->last_launches;
+  if (samples) *samples = s->last_samples;
   return MYTHOS_OK;
 }
 

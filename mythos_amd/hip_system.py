@@ -225,7 +225,11 @@ class LangevinIntegrator:
     def step(self, value: int) -> None:
         _lib.check(self._lib.mythos_langevin_set_step(self._h, int(value)), "set_step")
 
-    def last_kernel_ms(self) -> tuple[float, int]:
-        ms, n = C.c_double(0.0), C.c_int(0)
-        _lib.check(self._lib.mythos_langevin_last_kernel_ms(self._h, C.byref(ms), C.byref(n)), "last_kernel_ms")
-        return ms.value, n.value
+    def last_kernel_ms(self) -> dict:
+        """HIP-event timings of the last run (see include/mythos_hip.h)."""
+        k, loop, n, ns = C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)
+        _lib.check(
+            self._lib.mythos_langevin_last_kernel_ms(self._h, C.byref(k), C.byref(loop), C.byref(n), C.byref(ns)),
+            "last_kernel_ms",
+        )
+        return {"kernel_ms": k.value, "loop_ms_per_launch": loop.value, "launches": n.value, "samples": ns.value}

@@ -1,0 +1,75 @@
+"""Neighbour helpers with the reference's ``NeighborHelper`` protocol
+(mythos/simulators/jax_md/utils.py:31-67): ``.idx`` (pairs), ``.allocate(locs)``, ``.update(locs)``.
+
+``NoNeighborList`` carries a fixed (P, 2) pair array exactly like the reference's class.
+``VerletNeighborList`` asks the HIP integrator to maintain a GPU Verlet list (cell build in
+mythos_amd/csrc/neighbors.hip) instead of the reference's O(N^2) jax_md list
+(mythos/utils/neighbors.py:12-59, which every shipped example bypasses).
+"""
+
+from __future__ import annotations
+
+import dataclasses as dc
+
+import numpy as np
+
+
+def verlet_pairs_numpy(center: np.ndarray, bonded: np.ndarray, r_list: float, box=None) -> np.ndarray:
+    """Host-side i<j pair list within ``r_list`` minus bonded pairs, sorted lexicographically."""
+    from scipy.spatial import cKDTree
+
+    c = np.asarray(center, dtype=np.float64)
+    if box is not None:
+        box = np.broadcast_to(np.asarray(box, dtype=np.float64), (3,))
+        c = np.mod(c, box)
+        tree = cKDTree(c, boxsize=box)
+    else:
+        tree = cKDTree(c)
+    pairs = tree.query_pairs(r_list, output_type="ndarray").astype(np.int64)
+    if pairs.size == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    pairs.sort(axis=1)
+    n = c.shape[0]
+    key = pairs[:, 0] * n + pairs[:, 1]
+    b = np.sort(np.asarray(bonded, dtype=np.int64).reshape(-1, 2), axis=1)
+    keep = ~np.isin(key, b[:, 0] * n + b[:, 1])
+    pairs = pairs[keep]
+    order = np.argsort(pairs[:, 0] * n + pairs[:, 1], kind="stable")
+    return pairs[order].astype(np.int32)
+
+
+@dc.dataclass
+class NoNeighborList:
+    """A fixed pair list (reference: NoNeighborList, simulators/jax_md/utils.py:48-67)."""
+
+    unbonded_nbrs: np.ndarray
+
+    @property
+    def idx(self) -> np.ndarray:
+        return self.unbonded_nbrs
+
+    def allocate(self, locs) -> "NoNeighborList":  # noqa: ARG002
+        return self
+
+    def update(self, locs) -> "NoNeighborList":  # noqa: ARG002
+        return self
+
+
+@dc.dataclass
+class VerletNeighborList:
+    """GPU-maintained Verlet list: cut-off ``r_cutoff`` + skin ``dr_threshold``, rebuilt every
+    ``rebuild_every`` steps inside the HIP run loop (reference: NeighborList, utils.py:70-126)."""
+
+    r_cutoff: float = 3.25
+    dr_threshold: float = 0.5
+    rebuild_every: int = 25
+
+    @property
+    def idx(self):
+        return None
+
+    def allocate(self, locs) -> "VerletNeighborList":  # noqa: ARG002
+        return self
+
+    def update(self, locs) -> "VerletNeighborList":  # noqa: ARG002
+        return self

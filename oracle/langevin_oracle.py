@@ -138,5 +138,26 @@ class LangevinOracle:
         self.step_index += 1
         return x, q, p, L, u
 
+    def run(self, x, q, p, L, n_steps):
+        """n_steps of the same map, one force evaluation per step (the closing kick of a step and
+        the opening kick of the next share F).  Arrays are updated in place; returns the U trace."""
+        h = 0.5 * self.dt
+        us = []
+        u, F, tau = self.forces(x, q)
+        for _ in range(n_steps):
+            pp = p + h * F
+            LL = L + h * tau
+            xx, qq, LL = drift(x, q, pp, LL, h, self.mass, self.inertia)
+            z = normals6(self.seed, x.shape[0], self.step_index)
+            pp = self.c1_t * pp + self.c2_t * z[:, :3]
+            LL = self.c1_r * LL + self.c2_r[None, :] * z[:, 3:]
+            xx, qq, LL = drift(xx, qq, pp, LL, h, self.mass, self.inertia)
+            qq = qq / np.linalg.norm(qq, axis=1, keepdims=True)
+            u, F, tau = self.forces(xx, qq)
+            x[:], q[:], p[:], L[:] = xx, qq, pp + h * F, LL + h * tau
+            self.step_index += 1
+            us.append(u)
+        return np.array(us)
+
     def kinetic(self, p, L):
         return 0.5 * (p**2).sum() / self.mass, 0.5 * ((L**2) / self.inertia[None, :]).sum()
