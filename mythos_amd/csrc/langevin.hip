@@ -136,49 +136,235 @@ __device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const L
 }
 
 constexpr int kMdBlock = 256;
-constexpr int kTraceWidth = T_COUNT + 2;  // 8 energy terms + KE_trans + KE_rot
+constexpr int kMdG = 8;                    // lanes per nucleotide
+constexpr int kMdPPB = kMdBlock / kMdG;    // nucleotides per workgroup
+constexpr int kMdMaxItems = 32;            // flagged unbonded neighbours per nucleotide (phase 2)
+constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
+
+// Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
+// produced the positions so that neighbour visits never redo the quaternion -> axes algebra:
+//   p0 = (centre, meta)   p1 = (a1, 0)   p2 = (a3, 0)   p3 = (backbone offset k1 a1 + k2 a2, 0)
+//   q  = quaternion
+template <typename R>
+struct Frame {
+  typename Vec4T<R>::type *p0, *p1, *p2, *p3, *q;
+};
+
+// squared cut-offs of the radial pass, derived on the host from the parameter vector
+template <typename R>
+struct MdCut {
+  R rbb2;    // backbone-backbone: max(Debye r_cut, excluded-volume r_c)^2
+  R rcom2;   // centre-centre distance below which the base / stack site terms can act
+};
+
+template <typename R>
+__device__ __forceinline__ V3<R> xyz(const typename Vec4T<R>::type& v) {
+  return V3<R>{v.x, v.y, v.z};
+}
+
+// radial f3 on a site pair given d and r^2: returns energy, accumulates dV/dd into g
+template <typename R>
+__device__ __forceinline__ R f3_radial(R eps, const F3P<R>& fp, V3<R> d, R r2, V3<R>& g) {
+  if (r2 >= fp.rc * fp.rc) return R(0);
+  const R r = m_sqrt(r2);
+  const FD<R> v = f3_eval(r, eps, fp);
+  axpy(g, v.d / r, d);
+  return v.f;
+}
 
 // One MD step (see file header).  kick_close: multiple of dt*F that closes the previous step
 // (0 for the first kernel of a run, 1/2 otherwise); do_step = 0 for the closing-only kernel.
-template <typename R, int MODEL, int G, bool SAVE>
-__global__ __launch_bounds__(kMdBlock, (sizeof(R) == 4 ? 4 : 2)) void md_step_kernel(
-    const OxParams<R> P, const BoxT<R> box, const LangevinConst<R> K, int n,
-    const typename Vec4T<R>::type* __restrict__ pos_in, const typename Vec4T<R>::type* __restrict__ quat_in,
-    typename Vec4T<R>::type* __restrict__ pos_out, typename Vec4T<R>::type* __restrict__ quat_out,
-    typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
-    const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
-    R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos,
-    int* __restrict__ flags, R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part) {
+//
+// Work decomposition: 8 lanes per nucleotide, 32 nucleotides per 256-thread workgroup.
+//   phase 1 (radial): the lanes stride over the nucleotide's unbonded row; per neighbour they read
+//           32 B (centre + backbone offset), evaluate Debye-Hueckel and the four excluded-volume
+//           site pairs with early-outs on squared distances, and flag the few neighbours whose
+//           base-base / stack-stack distance lies in the support of an angular term;
+//   phase 2 (angular): the two bonded neighbours (FENE, bonded excluded volume, stacking) and the
+//           flagged ones (H-bond, cross-stacking, coaxial stacking) are evaluated densely, one per
+//           lane; the list of flagged slots lives in LDS;
+//   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
+template <typename R, int MODEL, bool SAVE>
+__global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
+    const OxParams<R> P, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
+    const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
+    const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride, R kick_close, int do_step,
+    uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
+    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part) {
   using V4 = typename Vec4T<R>::type;
-  constexpr int PPB = kMdBlock / G;
+  constexpr int G = kMdG, PPB = kMdPPB;
+  __shared__ unsigned short items[PPB][kMdMaxItems];
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
   const int i = blockIdx.x * PPB + grp;
+  const bool valid = i < n;
+  const int ii = valid ? i : n - 1;  // out-of-range groups shadow the last nucleotide and discard
+
+  const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK], g_k1 = P[GEO_BACK_A1];
+  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+
+  // ---- owner state
+  Nuc<R> self;
+  V3<R> offb_s;
+  {
+    const V4 s0 = in.p0[ii], s1 = in.p1[ii], s2 = in.p2[ii], s3 = in.p3[ii];
+    self.c = xyz<R>(s0);
+    self.a1 = xyz<R>(s1);
+    self.a3 = xyz<R>(s2);
+    self.a2 = cross(self.a3, self.a1);
+    offb_s = xyz<R>(s3);
+    const int m = (int)s0.w;
+    self.seq = m & 3;
+    self.is_end = (m >> 2) & 1;
+  }
+  const int* __restrict__ row = rows + (size_t)ii * row_stride;
+  const int len = valid ? row_len[ii] : 0;
 
   R e[T_COUNT];
 #pragma unroll
   for (int k = 0; k < T_COUNT; ++k) e[k] = R(0);
+  V3<R> gbk{R(0), R(0), R(0)}, gba{R(0), R(0), R(0)};  // sum of dV/dd acting on self's backbone / base site
+
+  // ---- phase 1: radial pass over the unbonded slots
+  const F3P<R> f_bb = f3_params(P, NEXC_BACKBONE_RSTAR), f_base = f3_params(P, NEXC_BASE_RSTAR);
+  const R eps_n = P[NEXC_EPS];
+  const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
+  int n_items = 0;
+  const int lane64 = threadIdx.x & 63;
+  const int gshift = lane64 & ~(G - 1);
+  for (int s0 = ROW_BONDED_SLOTS; s0 < len; s0 += G) {
+    const int s = s0 + lane;
+    bool flag = false;
+    if (s < len) {
+      const int entry = row[s];
+      const int j = entry & ROW_INDEX_MASK;
+      const bool role_p = (entry & ROW_ROLE_Q) == 0;
+      const V4 o0 = in.p0[j], o3 = in.p3[j];
+      const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
+      const V3<R> offb_o = xyz<R>(o3);
+      // backbone - backbone: excluded volume + Debye-Hueckel
+      {
+        const V3<R> d = dco + offb_o - offb_s;
+        const R r2 = dot(d, d);
+        if (r2 < cut.rbb2) {
+          const R r = m_sqrt(r2);
+          const FD<R> v = f3_eval(r, eps_n, f_bb);
+          R dVdr = v.d;
+          R en = v.f;
+          if constexpr (MODEL == 2) {
+            const FD<R> dh = debye_eval(r, P);
+            R mult = R(1);
+            if (half_ends) {
+              const int mo = (int)o0.w;
+              mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
+            }
+            dVdr += mult * dh.d;
+            if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
+          }
+          if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
+          axpy(gbk, dVdr / r, d);
+        }
+      }
+      if (dot(dco, dco) < cut.rcom2) {
+        const V3<R> a1o = xyz<R>(in.p1[j]);
+        R en = R(0);
+        // self backbone - other base ("back_p - base_q" if self is p) ; self base - other backbone
+        {
+          V3<R> d = dco - offb_s;
+          axpy(d, g_ba, a1o);
+          en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
+        }
+        {
+          V3<R> d = dco + offb_o;
+          axpy(d, -g_ba, self.a1);
+          en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
+        }
+        const V3<R> da = a1o - self.a1;
+        {
+          V3<R> d = dco;
+          axpy(d, g_ba, da);
+          const R r2 = dot(d, d);
+          en += f3_radial(eps_n, f_base, d, r2, gba);
+          flag = hb_crst_support(P, m_sqrt(r2));
+        }
+        {
+          V3<R> d = dco;
+          axpy(d, g_st, da);
+          flag = flag || cxst_support(P, m_sqrt(dot(d, d)));
+        }
+        if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
+      }
+    }
+    // append the flagged slots of this group to its LDS list, in slot order
+    const unsigned long long bal = __ballot(flag);
+    const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
+    if (flag) {
+      const int pos = n_items + __popc(gm & ((1u << lane) - 1u));
+      if (pos < kMdMaxItems) items[grp][pos] = (unsigned short)s;
+    }
+    n_items += __popc(gm);
+  }
+  if (n_items > kMdMaxItems) {
+    if (lane == 0) atomicOr(flags, 4);
+    n_items = kMdMaxItems;
+  }
+  __syncthreads();
+
+  // ---- phase 2: bonded neighbours (virtual items 0, 1) and flagged unbonded neighbours
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
-  Nuc<R> self;
-  R qs[4] = {R(1), R(0), R(0), R(0)};
-  if (i < n) {
-    Vec4Loader<R> ld{pos_in, quat_in, meta};
-    ld.load(i, self, qs);
+  {
     NoPG pg;
-    gather_row<R, MODEL, true, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
+    const int total = valid ? ROW_BONDED_SLOTS + n_items : 0;
+    for (int t = lane; t < total; t += G) {
+      const bool bonded = t < ROW_BONDED_SLOTS;
+      const int s = bonded ? t : (int)items[grp][t - ROW_BONDED_SLOTS];
+      const int entry = row[s];
+      if (entry < 0) continue;
+      const int j = entry & ROW_INDEX_MASK;
+      const bool role_p = bonded ? (s == 1) : ((entry & ROW_ROLE_Q) == 0);
+      Nuc<R> o;
+      const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
+      o.c = xyz<R>(o0);
+      o.a1 = xyz<R>(o1);
+      o.a3 = xyz<R>(o2);
+      o.a2 = cross(o.a3, o.a1);
+      const int mo = (int)o0.w;
+      o.seq = mo & 3;
+      o.is_end = (mo >> 2) & 1;
+      const V3<R> dco = min_image(o.c - self.c, box);
+      if (bonded)
+        bonded_pair<R, MODEL, true, NoPG>(P, self, o, dco, role_p, R(0.5), e, sg, pg);
+      else
+        unbonded_angular<R, MODEL, true, NoPG>(P, self, o, dco, role_p, R(0.5), e, sg, pg);
+    }
   }
-  group_reduce<G, R, true>(e, sg);
+  // site gradients of phase 1 -> centre / axis gradients
+  {
+    const V3<R> gsum = gbk + gba;
+    sg.dc = sg.dc - gsum;
+    axpy(sg.g1, -g_k1, gbk);
+    axpy(sg.g1, -g_ba, gba);
+    axpy(sg.g2, -g_k2, gbk);
+  }
+  if constexpr (SAVE) {
+    group_reduce<G, R, true>(e, sg);
+  } else {
+    group_reduce_v3<G>(sg.dc);
+    group_reduce_v3<G>(sg.g1);
+    group_reduce_v3<G>(sg.g2);
+    group_reduce_v3<G>(sg.g3);
+  }
 
   double ke_t = 0.0, ke_r = 0.0;
-  if (lane == 0 && i < n) {
-    // force and body-frame torque at x_k
+  if (lane == 0 && valid) {
     const V3<R> F = -sg.dc;
     const V3<R> tl = axes_grad_to_torque(self, sg);
     const R tb[3] = {dot(self.a1, tl), dot(self.a2, tl), dot(self.a3, tl)};
-    V4 pm = mom[i], lm = ang[i];
+    const V4 pm = mom[i], lm = ang[i], qv = in.q[i];
     R p[3] = {pm.x, pm.y, pm.z}, L[3] = {lm.x, lm.y, lm.z};
+    R qs[4] = {qv.x, qv.y, qv.z, qv.w};
     const R kc = kick_close * K.dt;
     p[0] += kc * F.x;
     p[1] += kc * F.y;
@@ -203,6 +389,7 @@ __global__ __launch_bounds__(kMdBlock, (sizeof(R) == 4 ? 4 : 2)) void md_step_ke
       }
     }
     R x[3] = {self.c.x, self.c.y, self.c.z};
+    V3<R> n1 = self.a1, n2 = self.a2, n3 = self.a3;
     if (do_step) {
       p[0] += K.half_dt * F.x;
       p[1] += K.half_dt * F.y;
@@ -232,16 +419,21 @@ __global__ __launch_bounds__(kMdBlock, (sizeof(R) == 4 ? 4 : 2)) void md_step_ke
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags, 1);
       }
       if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
+      quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
     }
-    pos_out[i] = V4{x[0], x[1], x[2], R(0)};
-    quat_out[i] = V4{qs[0], qs[1], qs[2], qs[3]};
+    const V4 s0 = in.p0[i];
+    out.p0[i] = V4{x[0], x[1], x[2], s0.w};
+    out.p1[i] = V4{n1.x, n1.y, n1.z, R(0)};
+    out.p2[i] = V4{n3.x, n3.y, n3.z, R(0)};
+    out.p3[i] = V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)};
+    out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
     mom[i] = V4{p[0], p[1], p[2], R(0)};
     ang[i] = V4{L[0], L[1], L[2], R(0)};
   }
   if constexpr (SAVE) {
     if (lane == 0) {
 #pragma unroll
-      for (int k = 0; k < T_COUNT; ++k) e_lds[grp][k] = (i < n) ? double(e[k]) : 0.0;
+      for (int k = 0; k < T_COUNT; ++k) e_lds[grp][k] = valid ? double(e[k]) : 0.0;
       e_lds[grp][T_COUNT] = ke_t;
       e_lds[grp][T_COUNT + 1] = ke_r;
     }
@@ -262,31 +454,36 @@ __global__ void reduce_trace_kernel(const double* __restrict__ part, int n_block
   if (out) out[k] = s;
 }
 
-// ------------------------------------------------------------------ packed (N,3)/(N,4) <-> vec4
+// ------------------------------------------------------------------ packed (N,3)/(N,4) <-> frame
 template <typename R>
-__global__ void pack_state_kernel(int n, const R* __restrict__ c, const R* __restrict__ q, const R* __restrict__ p,
-                                  const R* __restrict__ l, typename Vec4T<R>::type* pos,
-                                  typename Vec4T<R>::type* quat, typename Vec4T<R>::type* mom,
-                                  typename Vec4T<R>::type* ang) {
+__global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c, const R* __restrict__ q,
+                                  const R* __restrict__ p, const R* __restrict__ l, const int* __restrict__ meta,
+                                  const Frame<R> f, typename Vec4T<R>::type* mom, typename Vec4T<R>::type* ang) {
   using V4 = typename Vec4T<R>::type;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  pos[i] = V4{c[3 * i], c[3 * i + 1], c[3 * i + 2], R(0)};
   // the kernels assume unit quaternions (torque form); normalise on entry
   R q0 = q[4 * i], q1 = q[4 * i + 1], q2 = q[4 * i + 2], q3 = q[4 * i + 3];
   const R inv = m_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-  quat[i] = V4{q0 * inv, q1 * inv, q2 * inv, q3 * inv};
+  q0 *= inv, q1 *= inv, q2 *= inv, q3 *= inv;
+  V3<R> a1, a2, a3;
+  quat_axes(q0, q1, q2, q3, a1, a2, a3);
+  f.p0[i] = V4{c[3 * i], c[3 * i + 1], c[3 * i + 2], R(meta[i])};
+  f.p1[i] = V4{a1.x, a1.y, a1.z, R(0)};
+  f.p2[i] = V4{a3.x, a3.y, a3.z, R(0)};
+  f.p3[i] = V4{g_k1 * a1.x + g_k2 * a2.x, g_k1 * a1.y + g_k2 * a2.y, g_k1 * a1.z + g_k2 * a2.z, R(0)};
+  f.q[i] = V4{q0, q1, q2, q3};
   mom[i] = V4{p[3 * i], p[3 * i + 1], p[3 * i + 2], R(0)};
   ang[i] = V4{l[3 * i], l[3 * i + 1], l[3 * i + 2], R(0)};
 }
 template <typename R>
-__global__ void unpack_state_kernel(int n, const typename Vec4T<R>::type* pos, const typename Vec4T<R>::type* quat,
-                                    const typename Vec4T<R>::type* mom, const typename Vec4T<R>::type* ang,
-                                    R* __restrict__ c, R* __restrict__ q, R* __restrict__ p, R* __restrict__ l) {
+__global__ void unpack_state_kernel(int n, const Frame<R> f, const typename Vec4T<R>::type* mom,
+                                    const typename Vec4T<R>::type* ang, R* __restrict__ c, R* __restrict__ q,
+                                    R* __restrict__ p, R* __restrict__ l) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const auto a = pos[i];
-  const auto b = quat[i];
+  const auto a = f.p0[i];
+  const auto b = f.q[i];
   const auto m = mom[i];
   const auto w = ang[i];
   c[3 * i] = a.x, c[3 * i + 1] = a.y, c[3 * i + 2] = a.z;
@@ -334,8 +531,9 @@ struct mythos_sim {
   // neighbour policy
   double r_cut = 0, skin = 0;
   int rebuild_every = 0;
-  // device state (vec4, ping-pong positions / quaternions)
-  void *pos[2] = {nullptr, nullptr}, *quat[2] = {nullptr, nullptr}, *mom = nullptr, *ang = nullptr;
+  // device state: two ping-pong frames of 5 vec4 arrays each (p0, p1, p2, p3, q) + momenta
+  void* frame[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  void *mom = nullptr, *ang = nullptr;
   int* d_flags = nullptr;
   double* d_epart = nullptr;
   int epart_blocks = 0;
@@ -369,31 +567,55 @@ static LangevinConst<R> make_const(const mythos_sim* s) {
   return K;
 }
 
+template <typename R>
+static MdCut<R> make_cut(const mythos_system* sys) {
+  const OxParams<double>& P = sys->pd;
+  const double off_back = std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model == 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
+  const double off_base = std::fabs(P[GEO_BASE]), off_stack = std::fabs(P[GEO_STACK]);
+  double rbb = P[NEXC_BACKBONE_RC];
+  if (sys->model == 2) rbb = std::max(rbb, (double)P[DH_RCUT]);
+  double rcom = std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]) + off_back + off_base;
+  rcom = std::max(rcom, P[NEXC_BASE_RC] + 2 * off_base);
+  rcom = std::max(rcom, std::max((double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH]) + 2 * off_base);
+  rcom = std::max(rcom, P[CXST_RCHIGH] + 2 * off_stack);
+  rcom *= 1.0 + 1e-6;
+  MdCut<R> c;
+  c.rbb2 = R(rbb * rbb);
+  c.rcom2 = R(rcom * rcom);
+  return c;
+}
+
+template <typename R>
+static Frame<R> frame_of(const mythos_sim* sim, int k) {
+  using V4 = typename Vec4T<R>::type;
+  return Frame<R>{(V4*)sim->frame[k][0], (V4*)sim->frame[k][1], (V4*)sim->frame[k][2], (V4*)sim->frame[k][3],
+                  (V4*)sim->frame[k][4]};
+}
+
 template <typename R, int MODEL>
 static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, int n_steps, int save_every,
                      R* traj_center, R* traj_quat, double* e_trace, hipStream_t st) {
   using V4 = typename Vec4T<R>::type;
-  constexpr int G = 16;
-  constexpr int PPB = kMdBlock / G;
   mythos_system* sys = sim->sys;
   const int n = sys->n;
-  const int blocks = (n + PPB - 1) / PPB;
+  const int blocks = (n + kMdPPB - 1) / kMdPPB;
   const int tb = (n + 255) / 256;
   const OxParams<R>& P = params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
   const LangevinConst<R> K = make_const<R>(sim);
-  V4* pos[2] = {(V4*)sim->pos[0], (V4*)sim->pos[1]};
-  V4* qt[2] = {(V4*)sim->quat[0], (V4*)sim->quat[1]};
+  const MdCut<R> cut = make_cut<R>(sys);
+  const Frame<R> fr[2] = {frame_of<R>(sim, 0), frame_of<R>(sim, 1)};
   V4* mom = (V4*)sim->mom;
   V4* ang = (V4*)sim->ang;
+  const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
   MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, sizeof(int), st));
-  hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, center, quat, p_lin, p_ang, pos[0], qt[0],
-                     mom, ang);
+  hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
+                     sys->d_meta, fr[0], mom, ang);
   int cur = 0;
   const bool dynamic_list = sim->rebuild_every > 0;
   auto rebuild = [&](int buf) -> int {
-    if (int rc = rows_build_device(sys, pos[buf], true, sim->r_cut, sim->skin, st)) return rc;
-    MYTHOS_HIP_TRY(hipMemcpyAsync(sys->d_ref_pos, pos[buf], (size_t)n * sizeof(V4), hipMemcpyDeviceToDevice, st));
+    if (int rc = rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, st)) return rc;
+    MYTHOS_HIP_TRY(hipMemcpyAsync(sys->d_ref_pos, fr[buf].p0, (size_t)n * sizeof(V4), hipMemcpyDeviceToDevice, st));
     return 0;
   };
   if (dynamic_list)
@@ -415,17 +637,15 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, G, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, n,
-                         pos[cur], qt[cur], pos[cur ^ 1], qt[cur ^ 1], mom, ang, sys->d_meta, sys->d_rows,
-                         sys->d_row_len, sys->row_stride, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k),
-                         ref, sim->d_flags, tc, tq, sim->d_epart);
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, G, false>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, n,
-                         pos[cur], qt[cur], pos[cur ^ 1], qt[cur ^ 1], mom, ang, sys->d_meta, sys->d_rows,
-                         sys->d_row_len, sys->row_stride, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k),
-                         ref, sim->d_flags, tc, tq, sim->d_epart);
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart);
     }
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sb[samples++], st));
     ++launches;
@@ -433,8 +653,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
   MYTHOS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos[cur], qt[cur], mom, ang, center,
-                     quat, p_lin, p_ang);
+  hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, fr[cur], mom, ang, center, quat, p_lin,
+                     p_ang);
   int flags = 0, ov = 0;
   MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
   MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, sys->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -459,6 +679,11 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   if (ov != 0) {
     set_error("mythos_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
               std::to_string(sys->row_stride) + "); rebuild with mythos_oxdna_build_neighbors first");
+    return MYTHOS_ERR_OVERFLOW;
+  }
+  if (flags & 4) {
+    set_error("mythos_langevin_run: more than " + std::to_string(kMdMaxItems) +
+              " neighbours of one nucleotide are inside the range of an angular term");
     return MYTHOS_ERR_OVERFLOW;
   }
   if (flags & 1) {
@@ -492,12 +717,10 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
   for (int k = 0; k < 3; ++k) s->inertia[k] = inertia ? inertia[k] : 1.0;
   s->seed = seed;
   const size_t v4 = (sys->dtype == MYTHOS_F32 ? sizeof(float4) : sizeof(double4)) * (size_t)sys->n;
-  constexpr int PPB = kMdBlock / 16;
-  s->epart_blocks = (sys->n + PPB - 1) / PPB;
+  s->epart_blocks = (sys->n + kMdPPB - 1) / kMdPPB;
   bool ok = true;
-  for (int k = 0; k < 2; ++k) {
-    ok = ok && hipMalloc(&s->pos[k], v4) == hipSuccess && hipMalloc(&s->quat[k], v4) == hipSuccess;
-  }
+  for (int k = 0; k < 2; ++k)
+    for (int a = 0; a < 5; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
        hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * kTraceWidth * sizeof(double)) == hipSuccess &&
@@ -515,10 +738,9 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
 
 void mythos_langevin_destroy(mythos_sim_t* s) {
   if (!s) return;
-  for (int k = 0; k < 2; ++k) {
-    if (s->pos[k]) (void)hipFree(s->pos[k]);
-    if (s->quat[k]) (void)hipFree(s->quat[k]);
-  }
+  for (int k = 0; k < 2; ++k)
+    for (int a = 0; a < 5; ++a)
+      if (s->frame[k][a]) (void)hipFree(s->frame[k][a]);
   if (s->mom) (void)hipFree(s->mom);
   if (s->ang) (void)hipFree(s->ang);
   if (s->d_flags) (void)hipFree(s->d_flags);

@@ -208,13 +208,25 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
   }
 }
 
+// radial supports of the angular unbonded terms: H-bond / cross-stacking act on the base-base
+// distance, coaxial stacking on the stack-stack distance
+template <typename R>
+__device__ __forceinline__ bool hb_crst_support(const OxParams<R>& P, R r) {
+  return (P[HYDR_RCLOW] < r && r < P[HYDR_RCHIGH]) || (P[CRST_RCLOW] < r && r < P[CRST_RCHIGH]);
+}
+template <typename R>
+__device__ __forceinline__ bool cxst_support(const OxParams<R>& P, R r) {
+  return P[CXST_RCLOW] < r && r < P[CXST_RCHIGH];
+}
+
 // ------------------------------------------------------------------------------------------------
-// unbonded pair: excluded volume (4 x f3) + Debye + H-bond + cross-stacking + coaxial stacking.
+// unbonded pair, radial part: excluded volume (4 x f3) + Debye.  Returns true if any of the
+// angular terms (H-bond, cross-stacking, coaxial stacking) can be non-zero for this pair.
 // role_p: self is op_i of the ordered pair.
 // ------------------------------------------------------------------------------------------------
 template <typename R, int MODEL, bool GRAD, class PG>
-__device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
-                                              bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+__device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                                bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
 
@@ -246,12 +258,8 @@ __device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>
                                     site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), sg, pg);
     e[T_NEXC] += wgt * en;
   }
-  // ---- base-base: excluded volume, then H-bond and cross-stacking on the same vector.
-  //      Reference: dr = base_q - base_p (= +d if self is p, -d if q);
-  //      theta1 = acos(-a1p.a1q) theta2 = acos(-a1q.n) theta3 = acos(a1p.n)
-  //      theta4 = acos(a3p.a3q)  theta7 = acos(-a3q.n) theta8 = pi - acos(a3p.n)
-  //      In self/other form the cosines are  a1s.n, -a1o.n, a3s.n, -a3o.n  for either role; the role
-  //      decides which angle (and parameter block) each of them is.
+  // ---- base-base excluded volume
+  bool angular;
   {
     const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
     const R r = m_sqrt(dot(d, d));
@@ -259,12 +267,37 @@ __device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, R(1), pg);
+    if constexpr (GRAD)
+      if (v.d != R(0)) acc_self_site(sg, (v.d / r) * d, g_ba, R(0));
+    angular = hb_crst_support(P, r);
+  }
+  {
+    const V3<R> d = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
+    angular = angular || cxst_support(P, m_sqrt(dot(d, d)));
+  }
+  return angular;
+}
+
+// ------------------------------------------------------------------------------------------------
+// unbonded pair, angular part: H-bond + cross-stacking (base-base vector) and coaxial stacking.
+//      Reference: dr = base_q - base_p (= +d if self is p, -d if q);
+//      theta1 = acos(-a1p.a1q) theta2 = acos(-a1q.n) theta3 = acos(a1p.n)
+//      theta4 = acos(a3p.a3q)  theta7 = acos(-a3q.n) theta8 = pi - acos(a3p.n)
+//      In self/other form the cosines are  a1s.n, -a1o.n, a3s.n, -a3o.n  for either role; the role
+//      decides which angle (and parameter block) each of them is.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int MODEL, bool GRAD, class PG>
+__device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
+  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  (void)g_k1;
+  (void)g_k2;
+  {
+    const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
+    const R r = m_sqrt(dot(d, d));
     V3<R> gd{R(0), R(0), R(0)};
     bool any = false;
-    if (v.d != R(0)) {
-      axpy(gd, v.d / r, d);
-      any = true;
-    }
     const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
     const R whb = weight_lookup(P, HYDR_EPS_00, wk);
     const FD<R> F1 = (whb != R(0) || PG::on) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
@@ -497,6 +530,14 @@ __device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>
       acc_self_site(sg, gd, g_st, R(0));
     }
   }
+}
+
+// whole unbonded pair (energy API path)
+template <typename R, int MODEL, bool GRAD, class PG>
+__device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                              bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  if (unbonded_radial<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg))
+    unbonded_angular<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg);
 }
 
 }  // namespace mythos
