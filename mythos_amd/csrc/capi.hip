@@ -127,6 +127,7 @@ void mythos_oxdna_destroy(mythos_system_t* s) {
   if (s->d_rows) (void)hipFree(s->d_rows);
   if (s->d_row_len) (void)hipFree(s->d_row_len);
   if (s->d_overflow) (void)hipFree(s->d_overflow);
+  if (s->d_cell) (void)hipFree(s->d_cell);
   if (s->d_ref_pos) (void)hipFree(s->d_ref_pos);
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->d_pgpart) (void)hipFree(s->d_pgpart);

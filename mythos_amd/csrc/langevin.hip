@@ -22,6 +22,7 @@
 // DESIGN.md; the working set of a 12 kbp duplex (~3 MB) is L2 / Infinity-Cache resident.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "oxdna_gather.h"
 
@@ -138,7 +139,7 @@ __device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const L
 constexpr int kMdBlock = 256;
 constexpr int kMdG = 8;                    // lanes per nucleotide
 constexpr int kMdPPB = kMdBlock / kMdG;    // nucleotides per workgroup
-constexpr int kMdMaxItems = 32;            // flagged unbonded neighbours per nucleotide (phase 2)
+constexpr int kMdMaxItems = 18;            // flagged unbonded neighbours per nucleotide (phase 2)
 constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 
 // Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
@@ -190,10 +191,16 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride, R kick_close, int do_step,
     uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
-    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part) {
+    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate) {
   using V4 = typename Vec4T<R>::type;
   constexpr int G = kMdG, PPB = kMdPPB;
+  constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
+  constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
   __shared__ unsigned short items[PPB][kMdMaxItems];
+  __shared__ int item_cnt[PPB];
+  __shared__ int max_cnt;
+  __shared__ R self_lds[PPB][13];
+  __shared__ R res[PPB][kSlots][RW];
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
 
-  // ---- owner state
+  // ---- owner state (also parked in LDS for the block-wide angular pass)
   Nuc<R> self;
   V3<R> offb_s;
   {
@@ -217,9 +224,15 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     const int m = (int)s0.w;
     self.seq = m & 3;
     self.is_end = (m >> 2) & 1;
+    if (lane == 0) {
+      R* sl = self_lds[grp];
+      sl[0] = s0.x, sl[1] = s0.y, sl[2] = s0.z, sl[3] = s1.x, sl[4] = s1.y, sl[5] = s1.z;
+      sl[6] = s2.x, sl[7] = s2.y, sl[8] = s2.z, sl[9] = s0.w;
+    }
   }
+  if (threadIdx.x == 0) max_cnt = 0;
   const int* __restrict__ row = rows + (size_t)ii * row_stride;
-  const int len = valid ? row_len[ii] : 0;
+  const int len = (valid && !(ablate & 1)) ? row_len[ii] : 0;
 
   R e[T_COUNT];
 #pragma unroll
@@ -233,114 +246,205 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   int n_items = 0;
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
-  for (int s0 = ROW_BONDED_SLOTS; s0 < len; s0 += G) {
-    const int s = s0 + lane;
-    bool flag = false;
-    if (s < len) {
-      const int entry = row[s];
-      const int j = entry & ROW_INDEX_MASK;
-      const bool role_p = (entry & ROW_ROLE_Q) == 0;
-      const V4 o0 = in.p0[j], o3 = in.p3[j];
-      const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
-      const V3<R> offb_o = xyz<R>(o3);
-      // backbone - backbone: excluded volume + Debye-Hueckel
-      {
-        const V3<R> d = dco + offb_o - offb_s;
-        const R r2 = dot(d, d);
-        if (r2 < cut.rbb2) {
-          const R r = m_sqrt(r2);
-          const FD<R> v = f3_eval(r, eps_n, f_bb);
-          R dVdr = v.d;
-          R en = v.f;
-          if constexpr (MODEL == 2) {
-            const FD<R> dh = debye_eval(r, P);
-            R mult = R(1);
-            if (half_ends) {
-              const int mo = (int)o0.w;
-              mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
+  // Software pipeline: the lane's row entries are fetched kEnt at a time, and the neighbour
+  // state (centre, backbone offset) of entry k+1 is requested before entry k is evaluated, so the
+  // L2 / Infinity-Cache round trips overlap the arithmetic instead of serialising with it.
+  constexpr int kEnt = 6;
+  for (int base = ROW_BONDED_SLOTS; base < len; base += kEnt * G) {
+    int ent[kEnt];
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k) {
+      const int s = base + k * G + lane;
+      ent[k] = (s < len) ? row[s] : -1;
+    }
+    V4 n0{}, n3{};
+    if (ent[0] >= 0) {
+      const int j = ent[0] & ROW_INDEX_MASK;
+      n0 = in.p0[j];
+      n3 = in.p3[j];
+    }
+#pragma unroll
+    for (int k = 0; k < kEnt; ++k) {
+      if (base + k * G >= len) break;  // uniform per group
+      const int s = base + k * G + lane;
+      const int entry = ent[k];
+      const V4 o0 = n0, o3 = n3;
+      if (k + 1 < kEnt) {
+        if (ent[k + 1] >= 0) {
+          const int jn = ent[k + 1] & ROW_INDEX_MASK;
+          n0 = in.p0[jn];
+          n3 = in.p3[jn];
+        }
+      }
+      bool flag = false;
+      if (entry >= 0) {
+        const int j = entry & ROW_INDEX_MASK;
+        const bool role_p = (entry & ROW_ROLE_Q) == 0;
+        const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
+        const V3<R> offb_o = xyz<R>(o3);
+        const bool close = dot(dco, dco) < cut.rcom2;
+        V4 o1{};
+        if (close) o1 = in.p1[j];  // requested before the backbone arithmetic below
+        // backbone - backbone: excluded volume + Debye-Hueckel
+        {
+          const V3<R> d = dco + offb_o - offb_s;
+          const R r2 = dot(d, d);
+          if (r2 < cut.rbb2) {
+            const R r = m_sqrt(r2);
+            const FD<R> v = f3_eval(r, eps_n, f_bb);
+            R dVdr = v.d;
+            R en = v.f;
+            if constexpr (MODEL == 2) {
+              const FD<R> dh = debye_eval(r, P);
+              R mult = R(1);
+              if (half_ends) {
+                const int mo = (int)o0.w;
+                mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
+              }
+              dVdr += mult * dh.d;
+              if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
             }
-            dVdr += mult * dh.d;
-            if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
+            if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
+            axpy(gbk, dVdr / r, d);
+          }
+        }
+        if (close) {
+          const V3<R> a1o = xyz<R>(o1);
+          R en = R(0);
+          // self backbone - other base ("back_p - base_q" if self is p) ; self base - other backbone
+          {
+            V3<R> d = dco - offb_s;
+            axpy(d, g_ba, a1o);
+            en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
+          }
+          {
+            V3<R> d = dco + offb_o;
+            axpy(d, -g_ba, self.a1);
+            en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
+          }
+          const V3<R> da = a1o - self.a1;
+          {
+            V3<R> d = dco;
+            axpy(d, g_ba, da);
+            const R r2 = dot(d, d);
+            en += f3_radial(eps_n, f_base, d, r2, gba);
+            flag = hb_crst_support(P, m_sqrt(r2));
+          }
+          {
+            V3<R> d = dco;
+            axpy(d, g_st, da);
+            flag = flag || cxst_support(P, m_sqrt(dot(d, d)));
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
-          axpy(gbk, dVdr / r, d);
         }
       }
-      if (dot(dco, dco) < cut.rcom2) {
-        const V3<R> a1o = xyz<R>(in.p1[j]);
-        R en = R(0);
-        // self backbone - other base ("back_p - base_q" if self is p) ; self base - other backbone
-        {
-          V3<R> d = dco - offb_s;
-          axpy(d, g_ba, a1o);
-          en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
-        }
-        {
-          V3<R> d = dco + offb_o;
-          axpy(d, -g_ba, self.a1);
-          en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
-        }
-        const V3<R> da = a1o - self.a1;
-        {
-          V3<R> d = dco;
-          axpy(d, g_ba, da);
-          const R r2 = dot(d, d);
-          en += f3_radial(eps_n, f_base, d, r2, gba);
-          flag = hb_crst_support(P, m_sqrt(r2));
-        }
-        {
-          V3<R> d = dco;
-          axpy(d, g_st, da);
-          flag = flag || cxst_support(P, m_sqrt(dot(d, d)));
-        }
-        if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
+      // append the flagged slots of this group to its LDS list, in slot order
+      const unsigned long long bal = __ballot(flag);
+      const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
+      if (flag) {
+        const int pos = n_items + __popc(gm & ((1u << lane) - 1u));
+        if (pos < kMdMaxItems) items[grp][pos] = (unsigned short)s;
       }
+      n_items += __popc(gm);
     }
-    // append the flagged slots of this group to its LDS list, in slot order
-    const unsigned long long bal = __ballot(flag);
-    const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
-    if (flag) {
-      const int pos = n_items + __popc(gm & ((1u << lane) - 1u));
-      if (pos < kMdMaxItems) items[grp][pos] = (unsigned short)s;
-    }
-    n_items += __popc(gm);
   }
   if (n_items > kMdMaxItems) {
     if (lane == 0) atomicOr(flags, 4);
     n_items = kMdMaxItems;
   }
+  __syncthreads();  // max_cnt = 0 and self_lds are visible
+  if (lane == 0) {
+    item_cnt[grp] = valid ? n_items : 0;
+    atomicMax(&max_cnt, valid ? n_items : 0);
+  }
   __syncthreads();
 
-  // ---- phase 2: bonded neighbours (virtual items 0, 1) and flagged unbonded neighbours
-  SelfGrad<R> sg;
-  sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
+  // ---- phase 2: angular pass, work items spread over the whole workgroup so that every wavefront
+  //      runs ONE code path: wave 0 takes the 2 x 32 bonded neighbours (FENE, bonded excluded volume,
+  //      stacking), waves 1-3 take the flagged unbonded neighbours, 6 per nucleotide per sweep
+  //      (H-bond, cross-stacking, coaxial stacking).  Results go to res[owner][slot] in LDS.
   {
     NoPG pg;
-    const int total = valid ? ROW_BONDED_SLOTS + n_items : 0;
-    for (int t = lane; t < total; t += G) {
-      const bool bonded = t < ROW_BONDED_SLOTS;
-      const int s = bonded ? t : (int)items[grp][t - ROW_BONDED_SLOTS];
-      const int entry = row[s];
-      if (entry < 0) continue;
-      const int j = entry & ROW_INDEX_MASK;
-      const bool role_p = bonded ? (s == 1) : ((entry & ROW_ROLE_Q) == 0);
-      Nuc<R> o;
-      const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
-      o.c = xyz<R>(o0);
-      o.a1 = xyz<R>(o1);
-      o.a3 = xyz<R>(o2);
-      o.a2 = cross(o.a3, o.a1);
-      const int mo = (int)o0.w;
-      o.seq = mo & 3;
-      o.is_end = (mo >> 2) & 1;
-      const V3<R> dco = min_image(o.c - self.c, box);
-      if (bonded)
-        bonded_pair<R, MODEL, true, NoPG>(P, self, o, dco, role_p, R(0.5), e, sg, pg);
-      else
-        unbonded_angular<R, MODEL, true, NoPG>(P, self, o, dco, role_p, R(0.5), e, sg, pg);
+    constexpr int kPerSweep = (kMdBlock - 64) / PPB;  // 6
+    const bool bonded_wave = threadIdx.x < 64;
+    const int n_sweeps = (max_cnt + kPerSweep - 1) / kPerSweep;
+    for (int sweep = 0; sweep < ((ablate & 2) ? 0 : (bonded_wave ? 1 : n_sweeps)); ++sweep) {
+      int p, idx;
+      if (bonded_wave) {
+        p = threadIdx.x >> 1;
+        idx = threadIdx.x & 1;
+      } else {
+        const int u = threadIdx.x - 64;
+        p = u / kPerSweep;
+        idx = ROW_BONDED_SLOTS + sweep * kPerSweep + (u - p * kPerSweep);
+      }
+      const int ip = blockIdx.x * PPB + p;
+      const bool active = ip < n && idx < ROW_BONDED_SLOTS + item_cnt[p];
+      if (!active) continue;
+      const int sl = bonded_wave ? idx : (int)items[p][idx - ROW_BONDED_SLOTS];
+      const int entry = rows[(size_t)ip * row_stride + sl];
+      R* out_r = res[p][idx];
+      SelfGrad<R> g;
+      g.dc = g.g1 = g.g2 = g.g3 = V3<R>{R(0), R(0), R(0)};
+      R ee[T_COUNT];
+#pragma unroll
+      for (int k = 0; k < T_COUNT; ++k) ee[k] = R(0);
+      if (entry >= 0) {
+        const int j = entry & ROW_INDEX_MASK;
+        const bool role_p = bonded_wave ? (sl == 1) : ((entry & ROW_ROLE_Q) == 0);
+        Nuc<R> me, o;
+        const R* ms = self_lds[p];
+        me.c = V3<R>{ms[0], ms[1], ms[2]};
+        me.a1 = V3<R>{ms[3], ms[4], ms[5]};
+        me.a3 = V3<R>{ms[6], ms[7], ms[8]};
+        me.a2 = cross(me.a3, me.a1);
+        const int mm = (int)ms[9];
+        me.seq = mm & 3;
+        me.is_end = (mm >> 2) & 1;
+        const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
+        o.c = xyz<R>(o0);
+        o.a1 = xyz<R>(o1);
+        o.a3 = xyz<R>(o2);
+        o.a2 = cross(o.a3, o.a1);
+        const int mo = (int)o0.w;
+        o.seq = mo & 3;
+        o.is_end = (mo >> 2) & 1;
+        const V3<R> dco = min_image(o.c - me.c, box);
+        if (bonded_wave)
+          bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        else
+          unbonded_angular<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+      }
+      out_r[0] = g.dc.x, out_r[1] = g.dc.y, out_r[2] = g.dc.z;
+      out_r[3] = g.g1.x, out_r[4] = g.g1.y, out_r[5] = g.g1.z;
+      out_r[6] = g.g2.x, out_r[7] = g.g2.y, out_r[8] = g.g2.z;
+      out_r[9] = g.g3.x, out_r[10] = g.g3.y, out_r[11] = g.g3.z;
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int k = 0; k < T_COUNT; ++k) out_r[12 + k] = ee[k];
+      }
     }
   }
-  // site gradients of phase 1 -> centre / axis gradients
+  __syncthreads();
+
+  // ---- fold: each group gathers its owner's result rows (one per lane), adds the radial-pass
+  //      site gradients, and reduces over its 8 lanes in a fixed order
+  SelfGrad<R> sg;
+  sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
+  if (valid) {
+    const int total = ROW_BONDED_SLOTS + n_items;
+    for (int t = lane; t < total; t += G) {
+      const R* rr = res[grp][t];
+      sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
+      sg.g1 = sg.g1 + V3<R>{rr[3], rr[4], rr[5]};
+      sg.g2 = sg.g2 + V3<R>{rr[6], rr[7], rr[8]};
+      sg.g3 = sg.g3 + V3<R>{rr[9], rr[10], rr[11]};
+      if constexpr (SAVE) {
+#pragma unroll
+        for (int k = 0; k < T_COUNT; ++k) e[k] += rr[12 + k];
+      }
+    }
+  }
   {
     const V3<R> gsum = gbk + gba;
     sg.dc = sg.dc - gsum;
@@ -355,6 +459,23 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     group_reduce_v3<G>(sg.g1);
     group_reduce_v3<G>(sg.g2);
     group_reduce_v3<G>(sg.g3);
+  }
+
+  // ---- thermostat noise for this (nucleotide, step): the two Philox blocks and the three
+  //      Box-Muller pairs are produced by lanes 0..2 of the group side by side, then handed to lane 0
+  R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+  if (do_step && !(ablate & 4)) {
+    uint32_t c[4] = {(uint32_t)ii, uint32_t(step), uint32_t(step >> 32), (uint32_t)(lane & 1)};
+    philox4x32(c, uint32_t(seed), uint32_t(seed >> 32));
+    const bool hi = (lane == 2);
+    R za, zb;
+    box_muller(hi ? c[2] : c[0], hi ? c[3] : c[1], za, zb);
+    z[0] = za;
+    z[1] = zb;
+    z[2] = __shfl(za, 2, G);
+    z[3] = __shfl(zb, 2, G);
+    z[4] = __shfl(za, 1, G);
+    z[5] = __shfl(zb, 1, G);
   }
 
   double ke_t = 0.0, ke_r = 0.0;
@@ -390,7 +511,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     }
     R x[3] = {self.c.x, self.c.y, self.c.z};
     V3<R> n1 = self.a1, n2 = self.a2, n3 = self.a3;
-    if (do_step) {
+    if (do_step && !(ablate & 4)) {
       p[0] += K.half_dt * F.x;
       p[1] += K.half_dt * F.y;
       p[2] += K.half_dt * F.z;
@@ -398,8 +519,6 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
       L[1] += K.half_dt * tb[1];
       L[2] += K.half_dt * tb[2];
       drift(x, qs, p, L, K.half_dt, K);
-      R z[6];
-      normals6(seed, (uint32_t)i, step, 0u, z);
       p[0] = K.c1_t * p[0] + K.c2_t * z[0];
       p[1] = K.c1_t * p[1] + K.c2_t * z[1];
       p[2] = K.c1_t * p[2] + K.c2_t * z[2];
@@ -612,6 +731,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
                      sys->d_meta, fr[0], mom, ang);
   int cur = 0;
+  const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
+  const int ablate = abl ? atoi(abl) : 0;
   const bool dynamic_list = sim->rebuild_every > 0;
   auto rebuild = [&](int buf) -> int {
     if (int rc = rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, st)) return rc;
@@ -639,13 +760,13 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sb[samples++], st));
     ++launches;

@@ -60,6 +60,8 @@ struct mythos_system {
 
   // Verlet build scratch
   int* d_overflow = nullptr;  // [1] set when a row would exceed row_stride
+  int* d_cell = nullptr;      // hashed cell list scratch: cnt[H] start[H+1] slot_of[n] bucket[n]
+  size_t cell_cap = 0;
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)
 
   // parameters

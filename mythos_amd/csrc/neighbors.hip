@@ -5,6 +5,7 @@
 // with per-nucleotide rows (see mythos_internal.h for the slot encoding).  Rows are written in
 // ascending neighbour order so every downstream sum is reproducible.
 #include <algorithm>
+#include <cmath>
 
 #include "oxdna_gather.h"
 
@@ -101,36 +102,270 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Hashed cell list (O(N)): cells of edge >= r_list are hashed into a power-of-two table, so the
+// grid never has to cover a bounding box (a 12 kbp duplex is ~5000 length units long and one
+// cell thin).  Buckets may mix cells that collide in the hash; a candidate is accepted only for
+// the neighbour cell it really lies in, which also removes duplicates.  Buckets are sorted by
+// index after the atomic fill and rows are filled in (cell order, bucket order), so the list is
+// reproducible run to run.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+struct CellGrid {
+  R inv[3];   // 1 / cell edge
+  R ibox[3];  // 1 / box edge (periodic)
+  int nc[3];  // cells per box edge (periodic) or 0 (free space)
+  int hmask;
+};
+
+template <typename R>
+__device__ __forceinline__ void cell_of(const CellGrid<R>& g, R x, R y, R z, int& cx, int& cy, int& cz) {
+  const R p[3] = {x, y, z};
+  int c[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (g.nc[k] > 0) {
+      R f = p[k] * g.ibox[k];
+      f -= floor(f);
+      int v = (int)(f * R(g.nc[k]));
+      c[k] = v >= g.nc[k] ? g.nc[k] - 1 : v;
+    } else {
+      c[k] = (int)floor(p[k] * g.inv[k]);
+    }
+  }
+  cx = c[0], cy = c[1], cz = c[2];
+}
+
+__device__ __forceinline__ int cell_hash(int cx, int cy, int cz, int hmask) {
+  return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & hmask;
+}
+
+template <typename R, bool VEC4>
+__global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGrid<R> g, int* __restrict__ slot_of,
+                                  int* __restrict__ cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  constexpr int S = VEC4 ? 4 : 3;
+  int cx, cy, cz;
+  cell_of(g, pos[S * i], pos[S * i + 1], pos[S * i + 2], cx, cy, cz);
+  const int h = cell_hash(cx, cy, cz, g.hmask);
+  slot_of[i] = h;
+  atomicAdd(&cnt[h], 1);
+}
+
+// exclusive scan of cnt[0..m) into start[0..m], one workgroup; cnt is cleared for reuse as a cursor
+__global__ __launch_bounds__(1024) void cell_scan_kernel(int m, int* __restrict__ cnt, int* __restrict__ start) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (m + 1023) / 1024;
+  const int lo = t * per, hi = min(m, lo + per);
+  int s = 0;
+  for (int k = lo; k < hi; ++k) s += cnt[k];
+  part[t] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (t >= o) ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int k = lo; k < hi; ++k) {
+    start[k] = run;
+    run += cnt[k];
+    cnt[k] = 0;
+  }
+  if (t == 1023) start[m] = part[1023];
+}
+
+__global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, const int* __restrict__ start,
+                                 int* __restrict__ cursor, int* __restrict__ bucket) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int h = slot_of[i];
+  bucket[start[h] + atomicAdd(&cursor[h], 1)] = i;
+}
+
+__global__ void cell_sort_kernel(int m, const int* __restrict__ start, int* __restrict__ bucket) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= m) return;
+  const int lo = start[h], hi = start[h + 1];
+  for (int a = lo + 1; a < hi; ++a) {  // insertion sort: buckets hold a few tens of entries
+    const int v = bucket[a];
+    int b = a - 1;
+    while (b >= lo && bucket[b] > v) {
+      bucket[b + 1] = bucket[b];
+      --b;
+    }
+    bucket[b + 1] = v;
+  }
+}
+
+// one wavefront per nucleotide: lanes 0..26 look up the 27 neighbour cells, the candidate lists
+// are concatenated by a wave prefix sum and swept 64 at a time with ballot compaction
+template <typename R, bool VEC4>
+__global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* __restrict__ pos, const BoxT<R> box,
+                                                                const CellGrid<R> g, R rc2,
+                                                                const int* __restrict__ partners,
+                                                                const int* __restrict__ start,
+                                                                const int* __restrict__ bucket, int* __restrict__ rows,
+                                                                int* __restrict__ row_len, int row_stride,
+                                                                int* __restrict__ overflow) {
+  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= n) return;
+  constexpr int S = VEC4 ? 4 : 3;
+  const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
+  int cx, cy, cz;
+  cell_of(g, ci.x, ci.y, ci.z, cx, cy, cz);
+  int cnt = 0;
+  if (lane < 27) {
+    int c[3] = {cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (g.nc[k] > 0) c[k] = (c[k] + g.nc[k]) % g.nc[k];
+    const int h = cell_hash(c[0], c[1], c[2], g.hmask);
+    const int st = start[h];
+    cnt = start[h + 1] - st;
+    s_st[w][lane] = st;
+    s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
+  }
+  int inc = cnt;  // inclusive wave prefix sum
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane < 27) s_pre[w][lane + 1] = inc;
+  if (lane == 0) s_pre[w][0] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = __shfl(inc, 26, 64);
+  int* row = rows + (size_t)i * row_stride;
+  const int b0 = partners[2 * i], b1 = partners[2 * i + 1];
+  int out = ROW_BONDED_SLOTS;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    bool hit = false;
+    int j = -1;
+    if (t < total) {
+      int lo = 0, hi = 27;  // largest cell index with s_pre[cell] <= t
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_pre[w][mid] <= t) lo = mid; else hi = mid;
+      }
+      j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
+      if (j != i && j != b0 && j != b1) {
+        const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
+        int jx, jy, jz;
+        cell_of(g, xj, yj, zj, jx, jy, jz);
+        if (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]) {
+          V3<R> d{xj - ci.x, yj - ci.y, zj - ci.z};
+          d = min_image(d, box);
+          hit = dot(d, d) < rc2;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int slot = out + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < row_stride) row[slot] = (j < i) ? (j | ROW_ROLE_Q) : j;
+    }
+    out += __popcll(m);
+  }
+  if (lane == 0) {
+    row[0] = b0;
+    row[1] = b1;
+    if (out > row_stride) {
+      atomicMax(overflow, out);
+      out = row_stride;
+    }
+    row_len[i] = out;
+  }
+}
+
+static int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+template <typename R>
+static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, hipStream_t st) {
+  const int n = sys->n;
+  CellGrid<R> g;
+  bool ok = true;
+  for (int k = 0; k < 3; ++k) {
+    if (sys->has_box) {
+      const int nc = (int)std::floor(sys->box[k] / rl);
+      if (nc < 3) ok = false;
+      g.nc[k] = std::max(nc, 1);
+      g.ibox[k] = R(1.0 / sys->box[k]);
+      g.inv[k] = R(g.nc[k] / sys->box[k]);
+    } else {
+      g.nc[k] = 0;
+      g.ibox[k] = R(1);
+      g.inv[k] = R(1.0 / rl);
+    }
+  }
+  const int blocks_ap = (n * 64 + 255) / 256;
+  int* d_partners = sys->d_row_len + n;
+  const BoxT<R> box = make_box<R>(sys);
+  if (!ok || n < 512) {  // tiny systems / boxes under three cells: the all-pairs sweep is exact and cheap
+    if (vec4)
+      hipLaunchKernelGGL((build_rows_allpairs_kernel<R, true>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
+                         R(rl * rl), d_partners, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+    else
+      hipLaunchKernelGGL((build_rows_allpairs_kernel<R, false>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
+                         R(rl * rl), d_partners, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+    return 0;
+  }
+  const int H = next_pow2(2 * n);
+  g.hmask = H - 1;
+  const size_t need = (size_t)2 * H + 2 + (size_t)2 * n;  // cnt[H] start[H+1] slot_of[n] bucket[n]
+  if (need > sys->cell_cap) {
+    if (sys->d_cell) (void)hipFree(sys->d_cell);
+    sys->d_cell = nullptr;
+    sys->cell_cap = 0;
+    MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
+    sys->cell_cap = need;
+  }
+  int* cnt = sys->d_cell;
+  int* start = cnt + H;
+  int* slot_of = start + H + 1;
+  int* bucket = slot_of + n;
+  MYTHOS_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)H * sizeof(int), st));
+  const int tb = (n + 255) / 256;
+  if (vec4)
+    hipLaunchKernelGGL((cell_count_kernel<R, true>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
+  else
+    hipLaunchKernelGGL((cell_count_kernel<R, false>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
+  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, H, cnt, start);
+  hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, slot_of, start, cnt, bucket);
+  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, start, bucket);
+  const int wb = (n + 3) / 4;
+  if (vec4)
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
+                       d_partners, start, bucket, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+  else
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
+                       d_partners, start, bucket, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+  return 0;
+}
+
 int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
                       hipStream_t stream) {
-  const int n = sys->n;
   if (sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
   const double rl = r_cut + skin;
-  int* d_partners = sys->d_row_len + n;  // [n][2], uploaded at creation
-  const int blocks = (n * 64 + 255) / 256;
   MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, sizeof(int), stream));
-  if (sys->dtype == MYTHOS_F32) {
-    const BoxT<float> box = make_box<float>(sys);
-    if (center_is_vec4)
-      hipLaunchKernelGGL((build_rows_allpairs_kernel<float, true>), dim3(blocks), dim3(256), 0, stream, n,
-                         (const float*)center, box, float(rl * rl), d_partners, sys->d_rows, sys->d_row_len,
-                         sys->row_stride, sys->d_overflow);
-    else
-      hipLaunchKernelGGL((build_rows_allpairs_kernel<float, false>), dim3(blocks), dim3(256), 0, stream, n,
-                         (const float*)center, box, float(rl * rl), d_partners, sys->d_rows, sys->d_row_len,
-                         sys->row_stride, sys->d_overflow);
-  } else {
-    const BoxT<double> box = make_box<double>(sys);
-    if (center_is_vec4)
-      hipLaunchKernelGGL((build_rows_allpairs_kernel<double, true>), dim3(blocks), dim3(256), 0, stream, n,
-                         (const double*)center, box, rl * rl, d_partners, sys->d_rows, sys->d_row_len,
-                         sys->row_stride, sys->d_overflow);
-    else
-      hipLaunchKernelGGL((build_rows_allpairs_kernel<double, false>), dim3(blocks), dim3(256), 0, stream, n,
-                         (const double*)center, box, rl * rl, d_partners, sys->d_rows, sys->d_row_len,
-                         sys->row_stride, sys->d_overflow);
-  }
+  int rc;
+  if (sys->dtype == MYTHOS_F32)
+    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, stream);
+  else
+    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, stream);
+  if (rc) return rc;
   MYTHOS_HIP_TRY(hipGetLastError());
   sys->nbrs_set = true;
   return 0;

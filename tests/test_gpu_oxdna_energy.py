@@ -214,3 +214,36 @@ def test_error_conventions():
         s.set_params(np.zeros(3))
     with pytest.raises(ValueError):
         s.energy(c.float(), q.float())
+
+
+@pytest.mark.parametrize("periodic", [False, True])
+def test_hashed_cell_list_reproduces_all_pairs_energy(periodic):
+    """N >= 512 takes the hashed cell-list build; its rows must give the all-pairs energy, in free
+    space (one long duplex) and in a periodic box (a bundle of short duplexes straddling the faces)."""
+    from mythos_amd.hip_system import OxdnaSystem
+    from mythos_amd.utils import generators
+
+    if periodic:
+        top, c0, q0 = generators.duplex_bundle(12, 36, spacing=6.5, seed=5)
+        box = np.array([39.0, 39.0, 39.0])
+        c0 = c0 + np.array([-3.0, 17.0, 36.5])  # unwrapped coordinates crossing the faces
+    else:
+        top, c0, q0 = generators.ideal_duplex(400, seed=5)
+        box = None
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], half_charged_ends=True), _lib.param_names())
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=torch.float64)
+    s.set_params(flat)
+    c = torch.as_tensor(c0, dtype=torch.float64, device=s.device)
+    q = torch.as_tensor(q0, dtype=torch.float64, device=s.device)
+    s.set_neighbors(top.unbonded_neighbors)
+    e_all, gc_all, _, _ = s.energy(c, q, grads=True)
+    s.build_neighbors(c, r_cut=3.25, skin=0.4)
+    mx, mean = s.neighbor_stats()
+    assert 10 < mean < 80
+    e_cell, gc_cell, _, _ = s.energy(c, q, grads=True)
+    np.testing.assert_allclose(e_cell.cpu().numpy(), e_all.cpu().numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(gc_cell.cpu().numpy(), gc_all.cpu().numpy(), rtol=0, atol=1e-10)
+    # rebuilding gives the identical list (bitwise identical energies)
+    s.build_neighbors(c, r_cut=3.25, skin=0.4)
+    assert torch.equal(s.energy(c, q, grads=True)[0], e_cell)
