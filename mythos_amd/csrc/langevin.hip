@@ -165,11 +165,11 @@ __device__ __forceinline__ V3<R> xyz(const typename Vec4T<R>::type& v) {
 
 // radial f3 on a site pair given d and r^2: returns energy, accumulates dV/dd into g
 template <typename R>
-__device__ __forceinline__ R f3_radial(R eps, const F3P<R>& fp, V3<R> d, R r2, V3<R>& g) {
+__device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R r2, V3<R>& g) {
   if (r2 >= fp.rc * fp.rc) return R(0);
   const R r = m_sqrt(r2);
   const FD<R> v = f3_eval(r, eps, fp);
-  axpy(g, v.d / r, d);
+  axpy(g, tw * v.d / r, d);
   return v.f;
 }
 
@@ -242,6 +242,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   // ---- phase 1: radial pass over the unbonded slots
   const F3P<R> f_bb = f3_params(P, NEXC_BACKBONE_RSTAR), f_base = f3_params(P, NEXC_BASE_RSTAR);
   const R eps_n = P[NEXC_EPS];
+  const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
   const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
   int n_items = 0;
   const int lane64 = threadIdx.x & 63;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
           if (r2 < cut.rbb2) {
             const R r = m_sqrt(r2);
             const FD<R> v = f3_eval(r, eps_n, f_bb);
-            R dVdr = v.d;
+            R dVdr = tw_n * v.d;
             R en = v.f;
             if constexpr (MODEL == 2) {
               const FD<R> dh = debye_eval(r, P);
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
                 const int mo = (int)o0.w;
                 mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
               }
-              dVdr += mult * dh.d;
+              dVdr += tw_dh * mult * dh.d;
               if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
             }
             if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
@@ -315,19 +316,19 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
           {
             V3<R> d = dco - offb_s;
             axpy(d, g_ba, a1o);
-            en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
+            en += f3_radial(eps_n, tw_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
           }
           {
             V3<R> d = dco + offb_o;
             axpy(d, -g_ba, self.a1);
-            en += f3_radial(eps_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
+            en += f3_radial(eps_n, tw_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
           }
           const V3<R> da = a1o - self.a1;
           {
             V3<R> d = dco;
             axpy(d, g_ba, da);
             const R r2 = dot(d, d);
-            en += f3_radial(eps_n, f_base, d, r2, gba);
+            en += f3_radial(eps_n, tw_n, f_base, d, r2, gba);
             flag = hb_crst_support(P, m_sqrt(r2));
           }
           {

@@ -379,21 +379,21 @@ __device__ __forceinline__ FD<R> fene_eval(R r, const OxParams<R>& P) {
   return o;
 }
 template <typename R, class PG>
-__device__ __forceinline__ void fene_pgrad(R r, const OxParams<R>& P, R dVdr, PG& pg) {
+__device__ __forceinline__ void fene_pgrad(R r, const OxParams<R>& P, R dVdr, R scale, PG& pg) {
   if constexpr (!PG::on) return;
   const R eps = P[FENE_EPS], x = r - P[FENE_R0], delta = P[FENE_DELTA];
   const R diff = m_sqrt(x * x + R(1e-10));
-  pg.add(FENE_R0, -dVdr);
+  pg.add(FENE_R0, -scale * dVdr);
   if (diff > P[FENE_XMAX]) {
     const R ld = m_log(diff);
-    pg.add(FENE_FMAX, P[FENE_XMAX] * ld);
-    pg.add(FENE_FINF, -P[FENE_XMAX] * ld + diff);
-    pg.add(FENE_XMAX, (P[FENE_FMAX] - P[FENE_FINF]) * ld);
-    pg.add(FENE_CONST, R(1));
+    pg.add(FENE_FMAX, scale * P[FENE_XMAX] * ld);
+    pg.add(FENE_FINF, scale * (-P[FENE_XMAX] * ld + diff));
+    pg.add(FENE_XMAX, scale * (P[FENE_FMAX] - P[FENE_FINF]) * ld);
+    pg.add(FENE_CONST, scale);
   } else {
     const R d2 = delta * delta;
-    pg.add(FENE_EPS, R(-0.5) * m_log(R(1) - x * x / d2));
-    pg.add(FENE_DELTA, -eps * x * x / (delta * (d2 - x * x)));
+    pg.add(FENE_EPS, scale * R(-0.5) * m_log(R(1) - x * x / d2));
+    pg.add(FENE_DELTA, -scale * eps * x * x / (delta * (d2 - x * x)));
   }
 }
 

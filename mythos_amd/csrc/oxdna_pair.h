@@ -93,12 +93,12 @@ __device__ __forceinline__ void acc_dir(V3<R>& gd, R coef, R sg, R c, V3<R> u, V
 // one radial f3 site pair: energy, self gradient, parameter partials
 template <typename R, bool GRAD, class PG>
 __device__ __forceinline__ R f3_site_pair(const OxParams<R>& P, int ie, const F3P<R>& fp, V3<R> d, R als, R bes,
-                                          SelfGrad<R>& sg, PG& pg) {
+                                          R tw, SelfGrad<R>& sg, PG& pg) {
   const R r = m_sqrt(dot(d, d));
   const FD<R> v = f3_eval(r, P[ie], fp);
   if constexpr (GRAD)
-    if (v.d != R(0)) acc_self_site(sg, (v.d / r) * d, als, bes);
-  f3_pgrad(r, P[ie], ie, fp, R(1), pg);
+    if (v.d != R(0)) acc_self_site(sg, (tw * v.d / r) * d, als, bes);
+  f3_pgrad(r, P[ie], ie, fp, tw, pg);
   return v.f;
 }
 
@@ -118,18 +118,18 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
     const R r = m_sqrt(dot(d, d));
     const FD<R> v = fene_eval(r, P);
     e[T_FENE] += wgt * v.f;
-    if constexpr (GRAD) acc_self_site(sg, (v.d / r) * d, g_k1, g_k2);
-    fene_pgrad(r, P, v.d, pg);
+    if constexpr (GRAD) acc_self_site(sg, (P[TW_FENE] * v.d / r) * d, g_k1, g_k2);
+    fene_pgrad(r, P, v.d, P[TW_FENE], pg);
   }
   // ---- bonded excluded volume: base-base, back_p-base_q, base_p-back_q
   {
     R eb = f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params(P, BEXC_BASE_RSTAR),
-                                     site_disp(dco, s, o, g_ba, R(0), g_ba, R(0)), g_ba, R(0), sg, pg);
+                                     site_disp(dco, s, o, g_ba, R(0), g_ba, R(0)), g_ba, R(0), P[TW_BEXC], sg, pg);
     // self backbone - other base: "back_p - base_q" if self is p, else "base_p - back_q"
     eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
-                                    site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, sg, pg);
+                                    site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_BEXC], sg, pg);
     eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BASE_BACK_RSTAR, BEXC_BACK_BASE_RSTAR),
-                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), sg, pg);
+                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_BEXC], sg, pg);
     e[T_BEXC] += wgt * eb;
   }
   // ---- stacking.  Reference: dr = site_p - site_q, theta5 = pi - acos(dr.a3_q / r),
@@ -173,13 +173,14 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
     const FD<R> Bo = f5_eval(xo, qo);
     if (Bo.f == R(0)) return;
     const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
-    const R w = weight_lookup(P, STCK_EPS_00, wk);
+    const R wseq = weight_lookup(P, STCK_EPS_00, wk);
     const R ang = A4.f * As.f * Ao.f;
     const R phi = Bs.f * Bo.f;
     const R v = F1.f * ang * phi;
-    e[T_STCK] += wgt * w * v;
+    e[T_STCK] += wgt * wseq * v;
+    const R w = wseq * P[TW_STCK];  // gradients carry the term weight
     if constexpr (PG::on) {
-      pg.add(STCK_EPS_00 + wk, v);
+      pg.add(STCK_EPS_00 + wk, P[TW_STCK] * v);
       f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
       f4_pgrad(t4.f, p4, w * F1.f * As.f * Ao.f * phi, pg);
       f4_pgrad(ts.f, ps, w * F1.f * A4.f * Ao.f * phi, pg);
@@ -237,15 +238,15 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
     const F3P<R> fp = f3_params(P, NEXC_BACKBONE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
-    R dVdr = v.d;
-    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, R(1), pg);
+    R dVdr = P[TW_NEXC] * v.d;
+    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
     if constexpr (MODEL == 2) {
       const FD<R> dh = debye_eval(r, P);
       R mult = R(1);
       if (P[DH_HALF_CHARGED_ENDS] != R(0)) mult = (s.is_end ? R(0.5) : R(1)) * (o.is_end ? R(0.5) : R(1));
       e[T_DH] += wgt * mult * dh.f;
-      dVdr += mult * dh.d;
-      debye_pgrad(r, P, mult, pg);
+      dVdr += P[TW_DH] * mult * dh.d;
+      debye_pgrad(r, P, P[TW_DH] * mult, pg);
     }
     if constexpr (GRAD)
       if (dVdr != R(0)) acc_self_site(sg, (dVdr / r) * d, g_k1, g_k2);
@@ -253,9 +254,9 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
   // ---- self backbone - other base ("back_p - base_q" if self is p) and self base - other backbone
   {
     R en = f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
-                                     site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, sg, pg);
+                                     site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_NEXC], sg, pg);
     en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
-                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), sg, pg);
+                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_NEXC], sg, pg);
     e[T_NEXC] += wgt * en;
   }
   // ---- base-base excluded volume
@@ -266,9 +267,9 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
     const F3P<R> fp = f3_params(P, NEXC_BASE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
-    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, R(1), pg);
+    f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
     if constexpr (GRAD)
-      if (v.d != R(0)) acc_self_site(sg, (v.d / r) * d, g_ba, R(0));
+      if (v.d != R(0)) acc_self_site(sg, (P[TW_NEXC] * v.d / r) * d, g_ba, R(0));
     angular = hb_crst_support(P, r);
   }
   {
@@ -340,10 +341,11 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
           const R o1 = A4.f * As1.f * Ao1.f * As3.f * Ao3.f, o4 = A1.f * As1.f * Ao1.f * As3.f * Ao3.f;
           const R os1 = A1.f * A4.f * Ao1.f * As3.f * Ao3.f, oo1 = A1.f * A4.f * As1.f * As3.f * Ao3.f;
           const R os3 = A1.f * A4.f * As1.f * Ao1.f * Ao3.f, oo3 = A1.f * A4.f * As1.f * Ao1.f * As3.f;
-          const R wf = whb * F1.f;
+          const R whg = whb * P[TW_HB];
+          const R wf = whg * F1.f;
           if constexpr (PG::on) {
-            pg.add(HYDR_EPS_00 + wk, vhb);
-            f1_pgrad(r, P, HYDR_RLOW, whb * ang, pg);
+            pg.add(HYDR_EPS_00 + wk, P[TW_HB] * vhb);
+            f1_pgrad(r, P, HYDR_RLOW, whg * ang, pg);
             f4_pgrad(t1.f, p1, wf * o1, pg);
             f4_pgrad(t4.f, p4, wf * o4, pg);
             f4_pgrad(ts1.f, ps1, wf * os1, pg);
@@ -352,7 +354,7 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
             f4_pgrad(to3.f, po3, wf * oo3, pg);
           }
           if constexpr (GRAD) {
-            krad += whb * F1.d * ang;
+            krad += whg * F1.d * ang;
             k1 += wf * o1 * A1.d * t1.d;
             k4 += wf * o4 * A4.d * t4.d;
             ks1 += wf * os1 * As1.d * ts1.d;
@@ -379,29 +381,30 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
           const R ang = a123 * H4 * Hs * Ho;
           if (ang != R(0)) {
             e[T_CRST] += wgt * F2.f * ang;
+            const FD<R> F2w{P[TW_CRST] * F2.f, P[TW_CRST] * F2.d};
             const R hh = H4 * Hs * Ho;
             const R o1 = As1.f * Ao1.f * hh, os1 = A1.f * Ao1.f * hh, oo1 = A1.f * As1.f * hh;
             const R o4 = a123 * Hs * Ho, os3 = a123 * H4 * Ho, oo3 = a123 * H4 * Hs;
             if constexpr (PG::on) {
-              f2_pgrad(r, P, CRST_RLOW, ang, pg);
-              f4_pgrad(t1.f, p1, F2.f * o1, pg);
-              f4_pgrad(ts1.f, ps1, F2.f * os1, pg);
-              f4_pgrad(to1.f, po1, F2.f * oo1, pg);
-              f4_pgrad(t4.f, p4, F2.f * o4, pg);
-              f4_pgrad(R(kPi) - t4.f, p4, F2.f * o4, pg);
-              f4_pgrad(ts3.f, ps3, F2.f * os3, pg);
-              f4_pgrad(R(kPi) - ts3.f, ps3, F2.f * os3, pg);
-              f4_pgrad(to3.f, po3, F2.f * oo3, pg);
-              f4_pgrad(R(kPi) - to3.f, po3, F2.f * oo3, pg);
+              f2_pgrad(r, P, CRST_RLOW, P[TW_CRST] * ang, pg);
+              f4_pgrad(t1.f, p1, F2w.f * o1, pg);
+              f4_pgrad(ts1.f, ps1, F2w.f * os1, pg);
+              f4_pgrad(to1.f, po1, F2w.f * oo1, pg);
+              f4_pgrad(t4.f, p4, F2w.f * o4, pg);
+              f4_pgrad(R(kPi) - t4.f, p4, F2w.f * o4, pg);
+              f4_pgrad(ts3.f, ps3, F2w.f * os3, pg);
+              f4_pgrad(R(kPi) - ts3.f, ps3, F2w.f * os3, pg);
+              f4_pgrad(to3.f, po3, F2w.f * oo3, pg);
+              f4_pgrad(R(kPi) - to3.f, po3, F2w.f * oo3, pg);
             }
             if constexpr (GRAD) {
-              krad += F2.d * ang;
-              k1 += F2.f * o1 * A1.d * t1.d;
-              ks1 += F2.f * os1 * As1.d * ts1.d;
-              ko1 += F2.f * oo1 * Ao1.d * to1.d;
-              k4 += F2.f * o4 * (A4a.d - A4b.d) * t4.d;
-              ks3 += F2.f * os3 * (Sa.d - Sb.d) * ts3.d;
-              ko3 += F2.f * oo3 * (Oa.d - Ob.d) * to3.d;
+              krad += F2w.d * ang;
+              k1 += F2w.f * o1 * A1.d * t1.d;
+              ks1 += F2w.f * os1 * As1.d * ts1.d;
+              ko1 += F2w.f * oo1 * Ao1.d * to1.d;
+              k4 += F2w.f * o4 * (A4a.d - A4b.d) * t4.d;
+              ks3 += F2w.f * os3 * (Sa.d - Sb.d) * ts3.d;
+              ko3 += F2w.f * oo3 * (Oa.d - Ob.d) * to3.d;
             }
           }
         }
@@ -483,16 +486,17 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
     }
     const R ang = A4.f * H1 * Hs * Ho;
     e[T_CXST] += wgt * F2.f * ang * phi;
+    const FD<R> F2w{P[TW_CXST] * F2.f, P[TW_CXST] * F2.d};
     if constexpr (PG::on) {
-      f2_pgrad(r, P, CXST_RLOW, ang * phi, pg);
-      const R s4 = F2.f * H1 * Hs * Ho * phi, s1 = F2.f * A4.f * Hs * Ho * phi;
-      const R ss = F2.f * A4.f * H1 * Ho * phi, so = F2.f * A4.f * H1 * Hs * phi;
+      f2_pgrad(r, P, CXST_RLOW, P[TW_CXST] * ang * phi, pg);
+      const R s4 = F2w.f * H1 * Hs * Ho * phi, s1 = F2w.f * A4.f * Hs * Ho * phi;
+      const R ss = F2w.f * A4.f * H1 * Ho * phi, so = F2w.f * A4.f * H1 * Hs * phi;
       f4_pgrad(t4.f, p4, s4, pg);
       f4_pgrad(t1.f, p1, s1, pg);
       if constexpr (MODEL == 1) {
         f4_pgrad(R(2 * kPi) - t1.f, p1, s1, pg);
-        f5_pgrad(xs, qs, F2.f * ang * Bo.f, pg);
-        f5_pgrad(xo, qo, F2.f * ang * Bs.f, pg);
+        f5_pgrad(xs, qs, F2w.f * ang * Bo.f, pg);
+        f5_pgrad(xo, qo, F2w.f * ang * Bs.f, pg);
       } else {
         f6_pgrad(t1.f, P, CXST_F6_A, s1, pg);
       }
@@ -503,18 +507,18 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
     }
     if constexpr (GRAD) {
       V3<R> gd{R(0), R(0), R(0)};
-      axpy(gd, F2.d * ang * phi, n);
-      axpy(sg.g3, F2.f * H1 * Hs * Ho * phi * A4.d * t4.d, o.a3);
-      axpy(sg.g1, -(F2.f * A4.f * Hs * Ho * phi * dH1 * t1.d), o.a1);
-      const R ks = F2.f * A4.f * H1 * Ho * phi * (Sa.d - Sb.d) * ts.d;
+      axpy(gd, F2w.d * ang * phi, n);
+      axpy(sg.g3, F2w.f * H1 * Hs * Ho * phi * A4.d * t4.d, o.a3);
+      axpy(sg.g1, -(F2w.f * A4.f * Hs * Ho * phi * dH1 * t1.d), o.a1);
+      const R ks = F2w.f * A4.f * H1 * Ho * phi * (Sa.d - Sb.d) * ts.d;
       axpy(sg.g3, ks, n);
       acc_dir(gd, ks, R(1), cs, s.a3, n, ir);
-      const R ko = F2.f * A4.f * H1 * Hs * phi * (Oa.d - Ob.d) * to.d;
+      const R ko = F2w.f * A4.f * H1 * Hs * phi * (Oa.d - Ob.d) * to.d;
       acc_dir(gd, ko, R(-1), co, o.a3, n, ir);
       if constexpr (MODEL == 1) {
         // t = n.(nb x a):  dt/da = n x nb,  dt/dn = nb x a,  dt/dnb = a x n
         V3<R> gn{R(0), R(0), R(0)}, gnb{R(0), R(0), R(0)};
-        const R kxs = F2.f * ang * Bo.f * Bs.d, kxo = F2.f * ang * Bs.f * Bo.d;
+        const R kxs = F2w.f * ang * Bo.f * Bs.d, kxo = F2w.f * ang * Bs.f * Bo.d;
         axpy(sg.g1, kxs, cross(n, nb));
         axpy(gn, kxs, cross(nb, s.a1));
         axpy(gnb, kxs, cross(s.a1, n));

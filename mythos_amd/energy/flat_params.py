@@ -112,12 +112,18 @@ HB_WEIGHTS_SA = torch.tensor(
 )
 
 
-def derive_flat(model: int, sections: dict, *, kt, salt_conc=0.5, half_charged_ends=True) -> dict[str, torch.Tensor]:
+TERM_WEIGHT_NAMES = ("TW_FENE", "TW_BEXC", "TW_STCK", "TW_NEXC", "TW_HB", "TW_CRST", "TW_CXST", "TW_DH")
+
+
+def derive_flat(
+    model: int, sections: dict, *, kt, salt_conc=0.5, half_charged_ends=True, term_weights=None
+) -> dict[str, torch.Tensor]:
     """Name -> fp64 tensor for every entry of the kernels' flat parameter vector.
 
     ``sections`` is TOML-shaped: {"fene": {...}, "stacking": {...}, ...} with the reference's
     parameter names; values may be floats or (requires_grad) tensors.  ``stacking`` may hold
-    ``ss_stack_weights`` (4,4) and ``hydrogen_bonding`` ``ss_hb_weights`` (4,4).
+    ``ss_stack_weights`` (4,4) and ``hydrogen_bonding`` ``ss_hb_weights`` (4,4).  ``term_weights`` (8,)
+    scale the gradients of the eight terms (ComposedEnergyFunction.weights); energies stay unweighted.
     """
     S = {sec: {k: (_t(v) if v is not None else None) for k, v in d.items()} for sec, d in sections.items()}
     kt = _t(kt)
@@ -232,6 +238,9 @@ def derive_flat(model: int, sections: dict, *, kt, salt_conc=0.5, half_charged_e
         for j in range(4):
             out[f"STCK_EPS_{i}{j}"] = eps_stack[i, j]
             out[f"HYDR_EPS_{i}{j}"] = eps_hb[i, j]
+    tw = torch.ones(8, dtype=F64) if term_weights is None else _t(term_weights).to(F64)
+    for k, name in enumerate(TERM_WEIGHT_NAMES):
+        out[name] = tw[k]
     return out
 
 

@@ -1,0 +1,95 @@
+"""DiffTRe reweighting math (mythos/optimization/objective.py:139-235) on torch tensors, plus the
+replica-sharded form that combines per-GPU partial sums with RCCL all-reduces.
+
+``compute_loss_and_grad`` is the counterpart of ``jax.value_and_grad(compute_loss, has_aux=True)``
+(:235): the energies of the stored frames are differentiated with respect to the optimisation
+parameters by the HIP kernels (dU/dparam) and ``torch.autograd`` carries the chain rule through the
+softmax weights and the loss.
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable
+
+import torch
+
+
+def compute_weights_and_neff(beta, new_energies, ref_energies):
+    """w = softmax(-beta (E_new - E_ref)), n_eff = exp(-sum w ln w) / n   (:139-163)."""
+    new_energies = torch.as_tensor(new_energies, dtype=torch.float64)
+    ref_energies = torch.as_tensor(ref_energies, dtype=torch.float64, device=new_energies.device)
+    beta = torch.as_tensor(beta, dtype=torch.float64, device=new_energies.device)
+    diffs = new_energies - ref_energies
+    boltz = torch.exp(-beta * diffs)
+    weights = boltz / torch.sum(boltz)
+    n_eff = torch.exp(-torch.sum(weights * torch.log(weights)))
+    return weights, n_eff / weights.shape[0]
+
+
+def compute_min_segment_neff(temperature, new_energies, ref_energies) -> float:
+    """Minimum normalised n_eff over temperature segments (:166-195)."""
+    temperature = torch.as_tensor(temperature)
+    out = []
+    for t in torch.unique(temperature):
+        mask = temperature == t
+        _, neff = compute_weights_and_neff(1.0 / t, new_energies[mask], ref_energies[mask])
+        out.append(float(neff))
+    return min(out)
+
+
+def compute_loss(opt_params: dict, energy_fn, beta, loss_fn: Callable, ref_states, ref_energies, observables: list):
+    """(:198-232) -> loss, (neff, measured_value, new_energies)."""
+    energy_fn = energy_fn.with_params(opt_params)
+    new_energies = energy_fn.map(ref_states)
+    weights, neff = compute_weights_and_neff(beta, new_energies, ref_energies)
+    loss, (measured_value, _) = loss_fn(ref_states, weights, energy_fn, opt_params, observables)
+    return loss, (neff, measured_value, new_energies)
+
+
+def compute_loss_and_grad(opt_params: dict, energy_fn, beta, loss_fn, ref_states, ref_energies, observables):
+    """((loss, aux), grads) like jax.value_and_grad(compute_loss, has_aux=True) (:235)."""
+    leaves = {k: torch.as_tensor(v, dtype=torch.float64).detach().clone().requires_grad_(True) for k, v in opt_params.items()}
+    loss, aux = compute_loss(leaves, energy_fn, beta, loss_fn, ref_states, ref_energies, observables)
+    grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+    gdict = {k: (torch.zeros_like(leaves[k]) if g is None else g) for k, g in zip(leaves, grads)}
+    return (loss.detach(), tuple(a.detach() if isinstance(a, torch.Tensor) else a for a in aux)), gdict
+
+
+# ------------------------------------------------------------------------------------------------
+# replica-sharded reweighting: every rank holds the frames of its own replicas
+# ------------------------------------------------------------------------------------------------
+def distributed_weights_and_neff(beta, new_energies, ref_energies, group=None):
+    """Globally normalised weights of THIS rank's frames and the global n_eff.
+
+    Two collectives: all-reduce(MAX) of the exponent for a stable softmax, then
+    all-reduce(SUM) of [sum exp, sum exp * x, count] from which Z and the entropy follow.
+    """
+    import torch.distributed as dist
+
+    x = -torch.as_tensor(beta, dtype=torch.float64, device=new_energies.device) * (
+        new_energies.to(torch.float64) - torch.as_tensor(ref_energies, dtype=torch.float64, device=new_energies.device)
+    )
+    m = x.max().detach().reshape(1) if x.numel() else torch.full((1,), -float("inf"), dtype=torch.float64, device=x.device)
+    if dist.is_initialized():
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
+    ex = torch.exp(x - m)
+    sums = torch.stack([ex.sum().detach(), (ex * (x - m)).sum().detach(), torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
+    if dist.is_initialized():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    z, sx, n = sums[0], sums[1], sums[2]
+    weights = ex / z
+    entropy = torch.log(z) - sx / z  # -sum w ln w over ALL frames
+    return weights, torch.exp(entropy) / n
+
+
+def reweighted_mean_and_grad(observable, energies_grad, weights, beta):
+    """<O>_w and d<O>_w/dtheta = -beta ( <O g>_w - <O>_w <g>_w ) for per-frame dU/dtheta rows g (S, K)
+    (closed form of the DiffTRe gradient, SURVEY.md section 8a last row)."""
+    w = weights.to(torch.float64)
+    o = observable.to(torch.float64)
+    g = energies_grad.to(torch.float64)
+    mean_o = (w * o).sum()
+    mean_g = (w[:, None] * g).sum(0)
+    mean_og = ((w * o)[:, None] * g).sum(0)
+    b = torch.as_tensor(beta, dtype=torch.float64, device=w.device)
+    return mean_o, -b * (mean_og - mean_o * mean_g)

@@ -1,0 +1,132 @@
+"""CPU-side tests of the drop-in surface: configurations, composed-function bookkeeping, the C ABI
+symbol table and the replica-sharding collectives (gloo, world_size 2)."""
+
+import os
+import re
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd import _lib
+from mythos_amd.energy import dna1, dna2
+from mythos_amd.energy.configuration import BaseConfiguration
+from mythos_amd.input import topology
+from mythos_amd.optimization import objective
+from tests import helpers as H
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    header = (ROOT / "include" / "mythos_hip.h").read_text()
+    declared = set(re.findall(r"\b(mythos_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes found in include/mythos_hip.h"
+    lib = _lib.load()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.DECLARED_SYMBOLS)
+    assert lib.mythos_version().decode().startswith("mythos_amd")
+    assert lib.mythos_oxdna_param_name(-1) is None
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from mythos_amd.hip_system import OxdnaSystem
+
+    with pytest.raises(_lib.MythosHipError):
+        OxdnaSystem(2, [0, 1, 2, 3], None, [[0, 1], [1, 2], [2, 3]])
+
+
+def test_configuration_semantics():
+    cfg = dna2.FeneConfiguration.from_dict({"eps_backbone": 2.0, "r0_backbone": 0.7564, "delta_backbone": 0.25, "fmax": 500.0, "finf": 4.0}, ("*",))
+    assert set(cfg.opt_params) == {"eps_backbone", "r0_backbone", "delta_backbone", "fmax", "finf"}
+    with pytest.raises(ValueError, match="not initialized"):
+        dna2.FeneConfiguration(eps_backbone=2.0)
+    with pytest.raises(ValueError, match="permitted for optimization"):
+        dna2.BondedExcludedVolumeConfiguration.from_dict(
+            {"eps_exc": 2.0, "dr_star_base": 0.32, "sigma_base": 0.33, "sigma_back_base": 0.515, "sigma_base_back": 0.515,
+             "dr_star_back_base": 0.5, "dr_star_base_back": 0.5}, ("b_base",))
+    merged = cfg | {"fmax": 400.0}
+    assert merged.fmax == 400.0 and cfg.fmax == 500.0
+    assert isinstance(merged, BaseConfiguration)
+    d = cfg.to_dictionary(include_dependent=True, exclude_non_optimizable=False)
+    assert list(d) == list(dna2.FeneConfiguration.required_params)
+
+
+def test_composed_namespace_and_dependents():
+    top = topology.from_oxdna_file(H.GOLDEN / "dna2" / "simple-helix" / "generated.top")
+    ef = dna2.create_default_energy_fn(top)
+    assert len(ef.opt_params()) == 103  # 110 entries, 103 unique names
+    assert "kt" not in ef.opt_params()
+    # shared names reach every term that has them (energy/base.py:278-299)
+    ef2 = ef.with_params(kt=0.11, eps_exc=2.5)
+    assert float(ef2.energy_fns[2].params.kt) == 0.11 and float(ef2.energy_fns[7].params.kt) == 0.11
+    assert float(ef2.energy_fns[1].params.eps_exc) == 2.5 and float(ef2.energy_fns[3].params.eps_exc) == 2.5
+    with pytest.raises(ValueError, match="not used"):
+        ef.with_params(does_not_exist=1.0)
+    pd = ef.params_dict()
+    assert float(pd["b_low_stack"]) == pytest.approx(-68.1857, rel=1e-5)  # model.h STCK_BLOW
+    assert "b_low_coax" not in pd  # dna2 coaxial dependents are not declared (dna2/coaxial_stacking.py:56-76)
+    noopt = ef.with_noopt("a_hb")
+    assert "a_hb" not in noopt.opt_params() and "a_hb" in ef.opt_params()
+    assert len(ef.without_terms("Debye").energy_fns) == 7
+    assert len(dna1.create_default_energy_fn(top).energy_fns) == 7
+
+
+def test_difftre_weights_known_answer():
+    """mythos/optimization/tests/test_objective.py:188-204."""
+    w, neff = objective.compute_weights_and_neff(1, np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 3.0]))
+    assert np.allclose(w.numpy(), [1 / 3, 1 / 3, 1 / 3]) and np.allclose(float(neff), 1.0)
+    t = torch.tensor([0.1, 0.1, 0.2, 0.2])
+    e = torch.tensor([1.0, 2.0, 3.0, 4.0], dtype=torch.float64)
+    assert objective.compute_min_segment_neff(t, e, e) == pytest.approx(1.0)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, os.environ["MYTHOS_ROOT"])
+import torch, torch.distributed as dist
+from mythos_amd import distributed as md
+from mythos_amd.optimization import objective
+rank, world, _ = md.init("gloo")
+assert world == 2
+ids = md.shard_replicas(5, rank, world)
+assert ids == ([0, 2, 4] if rank == 0 else [1, 3])
+local = torch.tensor([[float(i), 10.0 * i] for i in ids], dtype=torch.float64)
+allv = md.all_gather_observables(local)
+assert allv.shape == (5, 2) and torch.equal(allv[:, 0], torch.arange(5, dtype=torch.float64)), allv
+g = torch.Generator().manual_seed(7)
+e_new = torch.randn(10, generator=g, dtype=torch.float64) * 3
+e_ref = torch.randn(10, generator=g, dtype=torch.float64) * 3
+w_all, neff_all = objective.compute_weights_and_neff(0.7, e_new, e_ref)
+mine = slice(0, 6) if rank == 0 else slice(6, 10)
+w, neff = objective.distributed_weights_and_neff(0.7, e_new[mine], e_ref[mine])
+assert torch.allclose(w, w_all[mine], rtol=1e-12), (w, w_all[mine])
+assert abs(float(neff) - float(neff_all)) < 1e-12
+s = md.all_reduce_sum(torch.tensor([float(rank + 1)]))
+assert float(s) == 3.0
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_replica_sharding_collectives_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MYTHOS_ROOT=str(ROOT), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2")
+    procs = [
+        subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        for r in range(2)
+    ]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o

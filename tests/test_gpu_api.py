@@ -1,0 +1,193 @@
+"""GPU tests through the reference-shaped Python surface.  They read like the reference's
+mythos/energy/dna{1,2}/tests/test_integration.py: build each term with default parameters and a
+periodic box of 20, ``energy_fn.map(states)``, divide by N, round to 6 decimals, compare with the
+``split_energy.dat`` column."""
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd.energy import dna1, dna2
+from mythos_amd.energy.base import Quaternion, RigidBody, space
+from mythos_amd.optimization import objective
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+KT = 296.15 * 0.1 / 300.0
+
+
+def _states(traj, dtype=torch.float64):
+    dev = torch.device("cuda", 0)
+    return RigidBody(
+        center=torch.as_tensor(traj.center, dtype=dtype, device=dev),
+        orientation=Quaternion(vec=torch.as_tensor(traj.quaternions, dtype=dtype, device=dev)),
+    )
+
+
+def _setup(model, name):
+    top, traj, split, energy = H.load_golden(model, name)
+    mod = dna1 if model == 1 else dna2
+    displacement_fn, _ = space.periodic(20.0)
+    return top, traj, split, energy, mod, mod.default_configs()[1], mod.default_transform_fn(), displacement_fn
+
+
+TERM_CASES = [
+    (2, "simple-helix", "Fene", "FeneConfiguration", "fene", {}),
+    (2, "simple-helix", "BondedExcludedVolume", "BondedExcludedVolumeConfiguration", "bonded_excluded_volume", {}),
+    (2, "simple-helix", "Stacking", "StackingConfiguration", "stacking", {"kt": KT}),
+    (2, "simple-helix", "UnbondedExcludedVolume", "UnbondedExcludedVolumeConfiguration", "unbonded_excluded_volume", {}),
+    (2, "simple-helix", "HydrogenBonding", "HydrogenBondingConfiguration", "hydrogen_bonding", {}),
+    (2, "simple-helix", "CrossStacking", "CrossStackingConfiguration", "cross_stacking", {}),
+    (2, "simple-coax", "CoaxialStacking", "CoaxialStackingConfiguration", "coaxial_stacking", {}),
+    (2, "simple-helix", "Debye", "DebyeConfiguration", "debye", {"kt": KT, "salt_conc": 0.5, "half_charged_ends": False}),
+    (1, "simple-helix", "Stacking", "StackingConfiguration", "stacking", {"kt": KT}),
+    (1, "simple-coax", "CoaxialStacking", "CoaxialStackingConfiguration", "coaxial_stacking", {}),
+    (1, "simple-helix", "HydrogenBonding", "HydrogenBondingConfiguration", "hydrogen_bonding", {}),
+]
+
+
+@pytest.mark.parametrize(("model", "name", "cls", "cfg_cls", "section", "extra"), TERM_CASES)
+def test_single_term_matches_split_energy(model, name, cls, cfg_cls, section, extra):
+    top, traj, split, _, mod, default_params, transform_fn, displacement_fn = _setup(model, name)
+    energy_config = getattr(mod, cfg_cls)(**{**default_params[section], **extra})
+    energy_fn = getattr(mod, cls)(
+        displacement_fn=displacement_fn, transform_fn=transform_fn, topology=top, params=energy_config.init_params()
+    )
+    energy = energy_fn.map(_states(traj)).cpu().numpy()
+    energy = np.around(energy / top.n_nucleotides, 6)
+    np.testing.assert_allclose(energy, split[:, H.SPLIT_COLUMNS.index(section)], atol=H.TERM_ATOL[section])
+
+
+@pytest.mark.parametrize(("model", "name", "hce"), [(1, "simple-helix", False), (2, "simple-helix", False), (2, "simple-helix-half-charged-ends", True)])
+def test_total_energy_default_fn(model, name, hce):
+    top, traj, _, energy, mod, _, _, displacement_fn = _setup(model, name)
+    energy_fn = mod.create_default_energy_fn(top, displacement_fn)
+    if model == 2:
+        energy_fn = energy_fn.with_params(half_charged_ends=hce)
+    states = _states(traj)
+    e = energy_fn.map(states).cpu().numpy() / top.n_nucleotides
+    np.testing.assert_allclose(e, energy, atol=1e-3 if model == 2 else 1e-4)
+    terms = energy_fn.compute_terms(states)
+    assert terms.shape == (100, len(energy_fn.energy_fns))
+    np.testing.assert_allclose(terms.sum(1).cpu().numpy() / top.n_nucleotides, e, atol=1e-12)
+    single = energy_fn(states[3])
+    assert single.dim() == 0 and abs(single.item() / top.n_nucleotides - e[3]) < 1e-12
+
+
+def test_kt_is_a_shared_parameter():
+    """with_params(kt=...) reaches stacking and Debye (dna2/tests/test_integration.py:366-369)."""
+    top, traj, _, _, mod, _, _, displacement_fn = _setup(2, "simple-helix")
+    ef = mod.create_default_energy_fn(top, displacement_fn)
+    st = _states(traj)[:2]
+    a = ef.compute_terms(st)
+    b = ef.with_params(kt=0.12).compute_terms(st)
+    changed = (a - b).abs().max(0).values.cpu().numpy() > 1e-9
+    assert changed.tolist() == [False, False, True, False, False, False, False, True]
+
+
+def test_weights_and_term_selection():
+    top, traj, _, _, mod, _, _, displacement_fn = _setup(2, "simple-helix")
+    ef = mod.create_default_energy_fn(top, displacement_fn)
+    st = _states(traj)[:3]
+    terms = ef.compute_terms(st)
+    w = torch.tensor([1.0, 0.5, 2.0, 1.0, 0.0, 1.0, 1.0, 3.0], dtype=torch.float64)
+    efw = ef.replace(weights=w)
+    torch.testing.assert_close(efw(st).cpu(), (terms.cpu() * w).sum(1), rtol=1e-12, atol=1e-12)
+    no_dh = ef.without_terms("Debye")
+    torch.testing.assert_close(no_dh(st).cpu(), terms[:, :7].sum(1).cpu(), rtol=1e-12, atol=1e-12)
+
+
+def test_autograd_positions_orientations_and_parameters():
+    """torch.autograd through the HIP op == oracle autograd (stand-in for jax.grad), incl. term weights."""
+    from oracle import oxdna_oracle as orc
+
+    top, traj, _, _, mod, _, _, displacement_fn = _setup(2, "simple-helix")
+    w = torch.tensor([1.0, 0.5, 2.0, 1.0, 0.7, 1.0, 1.0, 3.0], dtype=torch.float64)
+    ef = mod.create_default_energy_fn(top, displacement_fn).replace(weights=w)
+    st = _states(traj)[7]
+    c = st.center.clone().requires_grad_(True)
+    q = st.orientation.vec.clone().requires_grad_(True)
+    a_stack = torch.tensor(6.0, dtype=torch.float64, requires_grad=True)
+    eps_hb = torch.tensor(1.0678, dtype=torch.float64, requires_grad=True)
+    u = ef.with_params(a_stack=a_stack, eps_hb=eps_hb)(RigidBody(c, Quaternion(q)))
+    gc, gq, ga, ge = torch.autograd.grad(u, (c, q, a_stack, eps_hb))
+    # oracle with the same weights
+    a2 = torch.tensor(6.0, dtype=torch.float64, requires_grad=True)
+    e2 = torch.tensor(1.0678, dtype=torch.float64, requires_grad=True)
+    P = H.oracle_params(2, overrides={"stacking": {"a_stack": a2}, "hydrogen_bonding": {"eps_hb": e2}}, half_charged_ends=True)
+    seq, is_end, b, un = H.topo_tensors(top)
+    c2 = torch.as_tensor(traj.center[7]).requires_grad_(True)
+    q2 = torch.as_tensor(traj.quaternions[7]).requires_grad_(True)
+    u2 = (orc.energy_terms(2, P, c2, q2, seq, is_end, b, un, box=traj.box_size) * w).sum()
+    rc, rq, ra, re = torch.autograd.grad(u2, (c2, q2, a2, e2))
+    assert abs(u.item() - u2.item()) < 1e-9 * abs(u2.item())
+    assert (gc.cpu() - rc).abs().max() < 1e-7 * rc.abs().max()
+    assert (gq.cpu() - rq).abs().max() < 1e-7 * rq.abs().max()
+    assert abs(ga.item() - ra.item()) < 1e-7 * abs(ra.item())
+    assert abs(ge.item() - re.item()) < 1e-7 * abs(re.item())
+
+
+def test_difftre_loss_and_grad_matches_oracle():
+    """compute_loss_and_grad (objective.py:235) on 20 golden frames vs the same math on oracle energies."""
+    from oracle import oxdna_oracle as orc
+
+    top, traj, _, _, mod, _, _, displacement_fn = _setup(2, "simple-helix")
+    ef = mod.create_default_energy_fn(top, displacement_fn)
+    frames = list(range(0, 100, 5))
+    st = _states(traj)[frames]
+    ref_e = ef.map(st).detach()
+    target = torch.tensor(0.2, dtype=torch.float64)
+
+    def observable(states):  # mean COM distance of the first base pair, per frame
+        return (states.center[:, 0] - states.center[:, 15]).norm(dim=1).to(torch.float64)
+
+    def loss_fn(states, weights, energy_fn, opt_params, observables):  # noqa: ARG001
+        measured = (weights * observable(states)).sum()
+        return (measured - target.to(measured.device)) ** 2, (measured, None)
+
+    opt = {"eps_hb": 1.10, "a_stack": 6.2, "k_cross": 47.0}
+    (loss, (neff, measured, new_e)), grads = objective.compute_loss_and_grad(opt, ef, 1.0 / KT, loss_fn, st, ref_e, [])
+    assert 0.0 < float(neff) <= 1.0 and new_e.shape == (len(frames),)
+    # oracle
+    leaves = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in opt.items()}
+    P = H.oracle_params(2, half_charged_ends=True, overrides={
+        "hydrogen_bonding": {"eps_hb": leaves["eps_hb"]}, "stacking": {"a_stack": leaves["a_stack"]}, "cross_stacking": {"k_cross": leaves["k_cross"]}})
+    seq, is_end, b, un = H.topo_tensors(top)
+    es = torch.stack([
+        orc.energy(2, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, un, box=traj.box_size)
+        for f in frames
+    ])
+    w_o, _ = objective.compute_weights_and_neff(1.0 / KT, es, ref_e.cpu())
+    obs = torch.as_tensor(np.linalg.norm(traj.center[frames, 0] - traj.center[frames, 15], axis=1))
+    loss_o = ((w_o * obs).sum() - target) ** 2
+    g_o = torch.autograd.grad(loss_o, list(leaves.values()))
+    assert abs(loss.item() - loss_o.item()) < 1e-8 * max(1.0, abs(loss_o.item()))
+    for k, g in zip(leaves, g_o):
+        assert abs(grads[k].item() - g.item()) <= 1e-5 * max(abs(g.item()), 1e-8), (k, grads[k].item(), g.item())
+
+
+def test_simulator_run_surface():
+    from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList, VerletNeighborList
+
+    top, traj, _, _, mod, _, _, _ = _setup(2, "simple-helix")
+    disp, shift = space.free()
+    ef = mod.create_default_energy_fn(top, disp)
+    params = StaticSimulatorParams(
+        seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)),
+        gamma=(KT / 2.5, KT / 7.5), bonded_neighbors=top.bonded_neighbors, checkpoint_every=0, dt=5e-3, kT=KT,
+    )
+    init = _states(traj, torch.float32)[0]
+    for nb in (NoNeighborList(unbonded_nbrs=top.unbonded_neighbors), VerletNeighborList(3.25, 0.6, 20)):
+        sim = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin, neighbors=nb)
+        assert sim.exposes()[0].startswith("trajectory.HipMDSimulator.")
+        out = sim.run({"eps_hb": 1.05}, init, 50, key=3)
+        tr = out.observables[0]
+        assert tr.center.shape == (50, 16, 3) and tr.orientation.vec.shape == (50, 16, 4)
+        assert tr.temperature.shape == (50,) and torch.allclose(tr.temperature, torch.full((50,), KT, dtype=torch.float64, device=tr.temperature.device))
+        assert torch.isfinite(tr.center).all()
+        assert tr.slice(slice(10, 20)).length() == 10
+        # the stored frames are consistent with the energy function (same parameters)
+        e_traj = ef.with_params(eps_hb=1.05).map(RigidBody(tr.center, tr.orientation))
+        torch.testing.assert_close(e_traj.cpu(), tr.metadata["energy_terms"].sum(1).cpu(), rtol=2e-4, atol=1e-3)
