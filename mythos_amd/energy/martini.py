@@ -1,0 +1,276 @@
+"""MARTINI 2/3 energy functions with the reference's surface (mythos/energy/martini/base.py:46-208,
+m2/lj.py:14-157, m2/bond.py:15-71, m2/angle.py:16-129, m3/angle.py:8-11), evaluated by the HIP kernels
+of mythos_amd/csrc/martini.hip.
+
+    top = MartiniTopology.from_top("topol.top")
+    lj = LJ.from_topology(topology=top, params=LJConfiguration(**lj_params))
+    energies = lj.map(trajectory)            # trajectory.center (S, M, 3) nm, trajectory.box_size (S, 3)
+
+Energies are differentiable with respect to the positions through ``torch.autograd`` (the kernel
+returns dU/dpos); parameter gradients of the MARTINI terms are not wired yet ("next").
+"""
+
+from __future__ import annotations
+
+from typing import Any
+
+import numpy as np
+import torch
+
+from mythos_amd.input.gromacs import MartiniTopology
+
+LJ_SIGMA_PREFIX = "lj_sigma_"
+LJ_EPSILON_PREFIX = "lj_epsilon_"
+BOND_K_PREFIX = "bond_k_"
+BOND_R0_PREFIX = "bond_r0_"
+ANGLE_K_PREFIX = "angle_k_"
+ANGLE_THETA0_PREFIX = "angle_theta0_"
+
+
+class MartiniEnergyConfiguration:
+    """Dictionary-backed parameters with couplings (mythos/energy/martini/base.py:135-208)."""
+
+    def __init__(self, couplings: dict[str, list[str]] | None = None, **kwargs):
+        self.couplings = couplings or {}
+        targets = [v for vals in self.couplings.values() for v in vals]
+        if len(targets) != len(set(targets)):
+            raise ValueError("Parameters cannot appear in more than one coupling")
+        self.reversed_couplings = {v: k for k, vals in self.couplings.items() for v in vals}
+        self.params = {}
+        for key, value in kwargs.items():
+            if key in self.couplings:
+                for sub in self.couplings[key]:
+                    self.params[sub] = value
+            elif key not in self.reversed_couplings:
+                self.params[key] = value
+        self.__post_init__()
+
+    def __post_init__(self) -> None: ...
+
+    def init_params(self) -> "MartiniEnergyConfiguration":
+        return self
+
+    @property
+    def opt_params(self) -> dict:
+        out = {}
+        for key, value in self.params.items():
+            out[self.reversed_couplings.get(key, key)] = value
+        return out
+
+    def __getitem__(self, key: str):
+        if key in self.params:
+            return self.params[key]
+        if key in self.couplings:
+            return self.params[self.couplings[key][0]]
+        raise KeyError(f"Parameter '{key}' not found in configuration.")
+
+    def __contains__(self, key: str) -> bool:
+        return key in self.params or key in self.couplings
+
+    def __or__(self, other):
+        new = dict(self.params)
+        new.update(other.params if isinstance(other, MartiniEnergyConfiguration) else other)
+        return type(self)(couplings=self.couplings, **new)
+
+
+class LJConfiguration(MartiniEnergyConfiguration):
+    """``lj_sigma_A_B`` / ``lj_epsilon_A_B`` per bead-type pair (m2/lj.py:18-53)."""
+
+    def __post_init__(self) -> None:
+        bead_types = set()
+        for p in self.params:
+            if not p.startswith((LJ_SIGMA_PREFIX, LJ_EPSILON_PREFIX)):
+                raise ValueError(f"Unexpected parameter {p} for LJConfiguration")
+            bead_types.update(p.split("_")[2:4])
+        self.bead_types = tuple(sorted(bead_types))
+
+        def get(prefix, a, b):
+            v = self.params.get(f"lj_{prefix}_{a}_{b}", self.params.get(f"lj_{prefix}_{b}_{a}"))
+            if v is None:
+                raise ValueError(f"Missing LJ {prefix} parameter for pair {a}_{b} ({b}_{a})")
+            return float(v)
+
+        self.sigmas = np.array([[get("sigma", i, j) for j in self.bead_types] for i in self.bead_types])
+        self.epsilons = np.array([[get("epsilon", i, j) for j in self.bead_types] for i in self.bead_types])
+
+
+class BondConfiguration(MartiniEnergyConfiguration):
+    """``bond_k_NAME`` / ``bond_r0_NAME`` pairs (m2/bond.py:18-31)."""
+
+    def __post_init__(self) -> None:
+        for p in self.params:
+            if not p.startswith((BOND_K_PREFIX, BOND_R0_PREFIX)):
+                raise ValueError(f"Unexpected parameter {p} for BondConfiguration")
+        if len(self.params) == 0 or len(self.params) % 2 != 0:
+            raise ValueError("BondConfiguration requires pairs of k and r0 parameters")
+
+
+class AngleConfiguration(MartiniEnergyConfiguration):
+    """``angle_k_NAME`` / ``angle_theta0_NAME`` pairs, theta0 in radians (m2/angle.py:19-32)."""
+
+    def __post_init__(self) -> None:
+        for p in self.params:
+            if not p.startswith((ANGLE_K_PREFIX, ANGLE_THETA0_PREFIX)):
+                raise ValueError(f"Unexpected parameter {p} for AngleConfiguration")
+        if len(self.params) == 0 or len(self.params) % 2 != 0:
+            raise ValueError("AngleConfiguration requires pairs of k and theta0 parameters")
+
+
+class _MartiniOp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, box, system, column):
+        e, g = system.energy(pos.detach(), box, grads=pos.requires_grad)
+        ctx.single = pos.dim() == 2
+        if pos.requires_grad:
+            ctx.save_for_backward(g)
+        return e[..., column]
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (g,) = ctx.saved_tensors
+        scale = g_out.to(g.dtype)
+        return g * (scale if ctx.single else scale[:, None, None]), None, None, None
+
+
+class MartiniEnergyFunction:
+    """Base of the MARTINI terms (mythos/energy/martini/base.py:98-132).  A term evaluates ONLY its own
+    contribution: the other two are given neutral parameters in the shared kernel launch."""
+
+    column = 0
+    angle_kind = 0
+
+    def __init__(self, *, params: MartiniEnergyConfiguration, atom_types, atom_names, residue_names, angles,
+                 bonded_neighbors, unbonded_neighbors=None, transform_fn=None, dtype=torch.float64):
+        if unbonded_neighbors is not None:
+            raise ValueError("MartiniEnergyFunction does not support user-input unbonded_neighbors.")
+        self.params = params
+        self.atom_types, self.atom_names, self.residue_names = tuple(atom_types), tuple(atom_names), tuple(residue_names)
+        self.angles = np.asarray(angles, dtype=np.int32).reshape(-1, 3)
+        self.bonded_neighbors = np.asarray(bonded_neighbors, dtype=np.int32).reshape(-1, 2)
+        self.transform_fn = transform_fn
+        self.dtype = dtype
+        self._system = None
+
+    @classmethod
+    def from_topology(cls, topology: MartiniTopology, **kwargs) -> "MartiniEnergyFunction":
+        return cls(atom_types=topology.atom_types, atom_names=topology.atom_names, residue_names=topology.residue_names,
+                   angles=topology.angles, bonded_neighbors=topology.bonded_neighbors, **kwargs)
+
+    @property
+    def bond_names(self) -> tuple:
+        return tuple(f"{self.residue_names[b[0]]}_{self.atom_names[b[0]]}_{self.atom_names[b[1]]}" for b in self.bonded_neighbors)
+
+    @property
+    def angle_names(self) -> tuple:
+        return tuple(
+            f"{self.residue_names[a[0]]}_{self.atom_names[a[0]]}_{self.atom_names[a[1]]}_{self.atom_names[a[2]]}" for a in self.angles
+        )
+
+    # -- parameter plumbing (reference EnergyFunction protocol) ---------------------------------------
+    def with_params(self, *repl_dicts: dict, **repl_kwargs: Any) -> "MartiniEnergyFunction":
+        new = self.params
+        for d in repl_dicts:
+            new = new | d
+        new = new | repl_kwargs
+        out = object.__new__(type(self))
+        out.__dict__.update(self.__dict__)
+        out.params = new.init_params()
+        out._system = None
+        return out
+
+    def with_props(self, **kwargs) -> "MartiniEnergyFunction":
+        out = object.__new__(type(self))
+        out.__dict__.update(self.__dict__)
+        out.__dict__.update(kwargs)
+        out._system = None
+        return out
+
+    def opt_params(self) -> dict:
+        return self.params.opt_params
+
+    def params_dict(self, **_) -> dict:
+        return dict(self.params.params)
+
+    # -- kernel inputs -----------------------------------------------------------------------------------
+    def _tables(self):
+        """(types, sigma, eps, bond_k, bond_r0, angle_k, angle_t0): neutral values unless overridden."""
+        n = len(self.atom_types)
+        nb, na = len(self.bonded_neighbors), len(self.angles)
+        return (np.zeros(n, np.int32), np.ones((1, 1)), np.zeros((1, 1)), np.zeros(nb), np.ones(nb), np.zeros(na), np.zeros(na))
+
+    def _get_system(self, device):
+        from mythos_amd.hip_system import MartiniSystem
+
+        if self._system is None or self._system.device != device:
+            t, sg, ep, bk, br, ak, at = self._tables()
+            self._system = MartiniSystem(t, sg, ep, self.bonded_neighbors, bk, br, self.angles, ak, at,
+                                         angle_kind=self.angle_kind, dtype=self.dtype, device=device)
+        return self._system
+
+    def compute_energy(self, trajectory) -> torch.Tensor:
+        if self.transform_fn is not None:
+            trajectory = self.transform_fn(trajectory)
+        pos = trajectory.center
+        if not isinstance(pos, torch.Tensor) or pos.device.type != "cuda":
+            raise ValueError("trajectory.center must be a CUDA/HIP tensor (no CPU fallback)")
+        if trajectory.box_size is None:
+            raise ValueError("MARTINI energy functions need trajectory.box_size")
+        system = self._get_system(pos.device)
+        return _MartiniOp.apply(pos.to(self.dtype), trajectory.box_size, system, self.column)
+
+    __call__ = compute_energy
+
+    def map(self, body_sequence) -> torch.Tensor:
+        """Per-frame energies (n_states,): one launch over all frames (reference: lax.map, m2/lj.py:110-127)."""
+        return self.compute_energy(body_sequence)
+
+
+class LJ(MartiniEnergyFunction):
+    """Shifted-cut-off Lennard-Jones over all non-bonded pairs (m2/lj.py:92-157)."""
+
+    column = 0
+
+    def _tables(self):
+        t, _, _, bk, br, ak, at = super()._tables()
+        idx = {name: i for i, name in enumerate(self.params.bead_types)}
+        types = np.array([idx[a] for a in self.atom_types], dtype=np.int32)
+        return types, self.params.sigmas, self.params.epsilons, bk, br, ak, at
+
+
+class Bond(MartiniEnergyFunction):
+    """Harmonic bonds 1/2 k (r - r0)^2 (m2/bond.py:44-71)."""
+
+    column = 1
+
+    def _tables(self):
+        t, sg, ep, _, _, ak, at = super()._tables()
+        k = np.array([float(self.params[BOND_K_PREFIX + n]) for n in self.bond_names])
+        r0 = np.array([float(self.params[BOND_R0_PREFIX + n]) for n in self.bond_names])
+        return t, sg, ep, k, r0, ak, at
+
+
+class Angle(MartiniEnergyFunction):
+    """G96 cosine angles 1/2 k (cos theta - cos theta0)^2, MARTINI 2 (m2/angle.py:97-129)."""
+
+    column = 2
+    use_G96 = True  # noqa: N815 - reference spelling
+    angle_kind = 0
+
+    def _tables(self):
+        t, sg, ep, bk, br, _, _ = super()._tables()
+        k = np.array([float(self.params[ANGLE_K_PREFIX + n]) for n in self.angle_names])
+        t0 = np.array([float(self.params[ANGLE_THETA0_PREFIX + n]) for n in self.angle_names])
+        return t, sg, ep, bk, br, k, t0
+
+
+class Angle3(Angle):
+    """Harmonic angles 1/2 k (theta - theta0)^2, MARTINI 3 (m3/angle.py:8-11)."""
+
+    use_G96 = False  # noqa: N815
+    angle_kind = 1
+
+
+__all__ = [
+    "Angle", "Angle3", "AngleConfiguration", "Bond", "BondConfiguration", "LJ", "LJConfiguration",
+    "MartiniEnergyConfiguration", "MartiniEnergyFunction", "MartiniTopology",
+]

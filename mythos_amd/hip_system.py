@@ -233,3 +233,68 @@ class LangevinIntegrator:
             "last_kernel_ms",
         )
         return {"kernel_ms": k.value, "loop_ms_per_launch": loop.value, "launches": n.value, "samples": ns.value}
+
+
+class MartiniSystem:
+    """One MARTINI system on one GPU (mythos_martini_t): LJ type tables, bonds, angles."""
+
+    N_TERMS = 3  # lj, bond, angle
+
+    def __init__(self, types, sigma, eps, bonds, bond_k, bond_r0, angles, angle_k, angle_t0, angle_kind=0, r_cut=1.1,
+                 dtype=torch.float32, device=None):
+        lib = _lib.load()
+        if _lib.device_count() == 0 or not torch.cuda.is_available():
+            raise _lib.MythosHipError("no HIP device visible: the mythos_amd HIP path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dtype = dtype
+        types = np.ascontiguousarray(types, dtype=np.int32)
+        self.n = int(types.shape[0])
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
+        n_types = int(sigma.shape[0])
+        bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
+        angles = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, 3)
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        bond_k, bond_r0, angle_k, angle_t0 = f(bond_k), f(bond_r0), f(angle_k), f(angle_t0)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)  # noqa: E731
+        self._h = lib.mythos_martini_create(
+            self.n, types.ctypes.data_as(_lib.c_int_p), n_types, dp(sigma), dp(eps), int(bonds.shape[0]),
+            bonds.ctypes.data_as(_lib.c_int_p), dp(bond_k), dp(bond_r0), int(angles.shape[0]),
+            angles.ctypes.data_as(_lib.c_int_p), dp(angle_k), dp(angle_t0), int(angle_kind), float(r_cut),
+            _dtype_code(dtype), self.device.index or 0,
+        )
+        if not self._h:
+            raise _lib.MythosHipError(f"mythos_martini_create: {_lib.last_error()}")
+        self._lib = lib
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_martini_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def energy(self, pos: torch.Tensor, box: torch.Tensor, grads: bool = False):
+        """pos (F, N, 3) or (N, 3); box (F, 3) or (3,) -> (e_terms (F, 3) float64, dU/dpos or None)."""
+        single = pos.dim() == 2
+        if single:
+            pos, box = pos[None], torch.as_tensor(box).reshape(1, 3)
+        if pos.device != self.device or pos.dtype != self.dtype or tuple(pos.shape[1:]) != (self.n, 3):
+            raise ValueError(f"pos must be a {self.dtype} tensor of shape (F, {self.n}, 3) on {self.device}")
+        pos = pos.contiguous()
+        box = torch.as_tensor(box, dtype=self.dtype, device=self.device).reshape(-1, 3)
+        if box.shape[0] == 1 and pos.shape[0] > 1:
+            box = box.expand(pos.shape[0], 3)
+        box = box.contiguous()
+        nf = pos.shape[0]
+        e = torch.empty((nf, 3), dtype=torch.float64, device=self.device)
+        g = torch.empty_like(pos) if grads else None
+        _lib.check(
+            self._lib.mythos_martini_energy(self._h, _lib.ptr(pos), _lib.ptr(box), nf, _lib.ptr(e), _lib.ptr(g), _stream(self.device)),
+            "martini_energy",
+        )
+        return (e[0], g[0] if grads else None) if single else (e, g)
