@@ -106,7 +106,7 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
     s->h_partners[2 * j + 0] = i;  // j plays nn_j
   }
   bool ok = hipMalloc((void**)&s->d_meta, n * sizeof(int)) == hipSuccess &&
-            hipMalloc((void**)&s->d_row_len, (size_t)3 * n * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_row_len, (size_t)4 * n * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
             hipMemcpy(s->d_meta, meta.data(), n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(s->d_row_len + n, s->h_partners.data(), (size_t)2 * n * sizeof(int), hipMemcpyHostToDevice) ==

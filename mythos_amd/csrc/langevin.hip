@@ -22,6 +22,7 @@
 // DESIGN.md; the working set of a 12 kbp duplex (~3 MB) is L2 / Infinity-Cache resident.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 #include "oxdna_gather.h"
@@ -52,8 +53,7 @@ __device__ __forceinline__ void box_muller(uint32_t u0, uint32_t u1, float& z0, 
   const float a = (float(u0) + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
   const float b = float(u1) * 2.3283064365386963e-10f;
   const float r = sqrtf(-2.0f * __logf(a));
-  float s, c;
-  __sincosf(6.283185307179586f * b, &s, &c);
+  const float s = __sinf(6.283185307179586f * b), c = __cosf(6.283185307179586f * b);
   z0 = r * c;
   z1 = r * s;
 }
@@ -94,7 +94,10 @@ __device__ __forceinline__ void free_rotor(R* q, R* L, R h, const R* inv_I) {
   const R phi = h * L[K] * inv_I[K];
   R s, c;
   if constexpr (sizeof(R) == 4) {
-    __sincosf(R(0.5) * phi, &s, &c);
+    // native v_sin / v_cos: |phi| is a few 1e-2, the precise sincosf (argument reduction, private
+    // out-pointers) costs an order of magnitude more instructions for digits fp32 MD cannot use
+    s = __sinf(R(0.5) * phi);
+    c = __cosf(R(0.5) * phi);
   } else {
     sincos(R(0.5) * phi, &s, &c);
   }
@@ -125,10 +128,11 @@ __device__ __forceinline__ void free_rotor(R* q, R* L, R h, const R* inv_I) {
 }
 
 template <typename R>
-__device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const LangevinConst<R>& K) {
+__device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const LangevinConst<R>& K, bool rotate = true) {
   x[0] += h * p[0] * K.inv_mass;
   x[1] += h * p[1] * K.inv_mass;
   x[2] += h * p[2] * K.inv_mass;
+  if (!rotate) return;
   free_rotor<2>(q, L, R(0.5) * h, K.inv_inertia);
   free_rotor<1>(q, L, R(0.5) * h, K.inv_inertia);
   free_rotor<0>(q, L, h, K.inv_inertia);
@@ -163,7 +167,17 @@ __device__ __forceinline__ V3<R> xyz(const typename Vec4T<R>::type& v) {
   return V3<R>{v.x, v.y, v.z};
 }
 
-// radial f3 on a site pair given d and r^2: returns energy, accumulates dV/dd into g
+// radial f3 from r^2: returns the energy and, in coef, tw * V'(r) / r (0 outside the support)
+template <typename R>
+__device__ __forceinline__ R f3_coef(R eps, R tw, const F3P<R>& fp, R r2, R& coef) {
+  coef = R(0);
+  if (r2 >= fp.rc * fp.rc) return R(0);
+  const R r = m_sqrt(r2);
+  const FD<R> v = f3_eval(r, eps, fp);
+  coef = tw * v.d / r;
+  return v.f;
+}
+
 template <typename R>
 __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R r2, V3<R>& g) {
   if (r2 >= fp.rc * fp.rc) return R(0);
@@ -172,6 +186,15 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
   axpy(g, tw * v.d / r, d);
   return v.f;
 }
+
+// Diagnostic stamps (ablate bit 7): lane 0 of every wavefront records s_memtime at the phase boundaries
+// into the (otherwise unused) energy scratch; no output value depends on them.
+#define MD_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    if ((ablate & 128) && (threadIdx.x & 63) == 0)                                                     \
+      reinterpret_cast<unsigned long long*>(e_part)[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
+          __builtin_readcyclecounter();                                                                \
+  } while (0)
 
 // One MD step (see file header).  kick_close: multiple of dt*F that closes the previous step
 // (0 for the first kernel of a run, 1/2 otherwise); do_step = 0 for the closing-only kernel.
@@ -186,11 +209,11 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 //           lane; the list of flagged slots lives in LDS;
 //   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
 template <typename R, int MODEL, bool SAVE>
-__global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
-    const OxParams<R> P, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
+__global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
+    const OxParams<R> Pk, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
-    const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride, R kick_close, int do_step,
-    uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
+    const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
+    R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
     R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate) {
   using V4 = typename Vec4T<R>::type;
   constexpr int G = kMdG, PPB = kMdPPB;
@@ -202,6 +225,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   __shared__ R self_lds[PPB][13];
   __shared__ R res[PPB][kSlots][RW];
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
+  const OxParams<R>& P = Pk;  // SGPR-resident; an LDS copy was measured 2.4x slower in the angular pass
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
   const int i = blockIdx.x * PPB + grp;
@@ -233,14 +257,17 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   if (threadIdx.x == 0) max_cnt = 0;
   const int* __restrict__ row = rows + (size_t)ii * row_stride;
   const int len = (valid && !(ablate & 1)) ? row_len[ii] : 0;
+  const int close_end = min(len, row_close[ii]);  // [2, close_end): any term may act; [close_end, len): backbone only
 
   R e[T_COUNT];
 #pragma unroll
   for (int k = 0; k < T_COUNT; ++k) e[k] = R(0);
   V3<R> gbk{R(0), R(0), R(0)}, gba{R(0), R(0), R(0)};  // sum of dV/dd acting on self's backbone / base site
 
+  MD_STAMP(0);
   // ---- phase 1: radial pass over the unbonded slots
-  const F3P<R> f_bb = f3_params(P, NEXC_BACKBONE_RSTAR), f_base = f3_params(P, NEXC_BASE_RSTAR);
+  const F3P<R> f_bb = f3_params<R>(P, NEXC_BACKBONE_RSTAR), f_base = f3_params<R>(P, NEXC_BASE_RSTAR);
+  const F3P<R> f_bkba = f3_params<R>(P, NEXC_BACK_BASE_RSTAR), f_babk = f3_params<R>(P, NEXC_BASE_BACK_RSTAR);
   const R eps_n = P[NEXC_EPS];
   const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
   const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
@@ -250,32 +277,32 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
   // Software pipeline: the lane's row entries are fetched kEnt at a time, and the neighbour
   // state (centre, backbone offset) of entry k+1 is requested before entry k is evaluated, so the
   // L2 / Infinity-Cache round trips overlap the arithmetic instead of serialising with it.
-  constexpr int kEnt = 6;
-  for (int base = ROW_BONDED_SLOTS; base < len; base += kEnt * G) {
-    int ent[kEnt];
-#pragma unroll
-    for (int k = 0; k < kEnt; ++k) {
-      const int s = base + k * G + lane;
-      ent[k] = (s < len) ? row[s] : -1;
-    }
+  // (rolled: keeping the body once in the instruction stream matters more than unrolling - the whole
+  // kernel has to stay inside the instruction cache that two CUs share)
+  {
+    int e_cur = -1, e_nxt = -1;
     V4 n0{}, n3{};
-    if (ent[0] >= 0) {
-      const int j = ent[0] & ROW_INDEX_MASK;
-      n0 = in.p0[j];
-      n3 = in.p3[j];
+    {
+      const int s = ROW_BONDED_SLOTS + lane;
+      e_cur = (s < close_end) ? row[s] : -1;
+      e_nxt = (s + G < close_end) ? row[s + G] : -1;
+      if (e_cur >= 0) {
+        const int j = e_cur & ROW_INDEX_MASK;
+        n0 = in.p0[j];
+        n3 = in.p3[j];
+      }
     }
-#pragma unroll
-    for (int k = 0; k < kEnt; ++k) {
-      if (base + k * G >= len) break;  // uniform per group
-      const int s = base + k * G + lane;
-      const int entry = ent[k];
+#pragma unroll 1
+    for (int s0 = ROW_BONDED_SLOTS; s0 < close_end; s0 += G) {
+      const int s = s0 + lane;
+      const int entry = e_cur;
       const V4 o0 = n0, o3 = n3;
-      if (k + 1 < kEnt) {
-        if (ent[k + 1] >= 0) {
-          const int jn = ent[k + 1] & ROW_INDEX_MASK;
-          n0 = in.p0[jn];
-          n3 = in.p3[jn];
-        }
+      e_cur = e_nxt;
+      e_nxt = (s + 2 * G < close_end) ? row[s + 2 * G] : -1;
+      if (e_cur >= 0) {
+        const int jn = e_cur & ROW_INDEX_MASK;
+        n0 = in.p0[jn];
+        n3 = in.p3[jn];
       }
       bool flag = false;
       if (entry >= 0) {
@@ -312,16 +339,20 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
         if (close) {
           const V3<R> a1o = xyz<R>(o1);
           R en = R(0);
-          // self backbone - other base ("back_p - base_q" if self is p) ; self base - other backbone
+          // self backbone - other base and self base - other backbone: which of the two is the reference's
+          // "back_p - base_q" / "base_p - back_q" depends on the role; the squared distances are routed by
+          // role so both parameter blocks stay scalar operands
           {
-            V3<R> d = dco - offb_s;
-            axpy(d, g_ba, a1o);
-            en += f3_radial(eps_n, tw_n, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR), d, dot(d, d), gbk);
-          }
-          {
-            V3<R> d = dco + offb_o;
-            axpy(d, -g_ba, self.a1);
-            en += f3_radial(eps_n, tw_n, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR), d, dot(d, d), gba);
+            V3<R> dA = dco - offb_s;
+            axpy(dA, g_ba, a1o);
+            V3<R> dB = dco + offb_o;
+            axpy(dB, -g_ba, self.a1);
+            const R ra2 = dot(dA, dA), rb2 = dot(dB, dB);
+            R c1, c2;
+            en += f3_coef(eps_n, tw_n, f_bkba, role_p ? ra2 : rb2, c1);
+            en += f3_coef(eps_n, tw_n, f_babk, role_p ? rb2 : ra2, c2);
+            axpy(gbk, role_p ? c1 : c2, dA);
+            axpy(gba, role_p ? c2 : c1, dB);
           }
           const V3<R> da = a1o - self.a1;
           {
@@ -349,16 +380,68 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
       n_items += __popc(gm);
     }
   }
+  // far segment: only the backbone-backbone terms (excluded volume + Debye-Hueckel) can act
+  {
+    int e_cur = -1, e_nxt = -1;
+    V4 n0{}, n3{};
+    {
+      const int s = close_end + lane;
+      e_cur = (s < len) ? row[s] : -1;
+      e_nxt = (s + G < len) ? row[s + G] : -1;
+      if (e_cur >= 0) {
+        const int j = e_cur & ROW_INDEX_MASK;
+        n0 = in.p0[j];
+        n3 = in.p3[j];
+      }
+    }
+#pragma unroll 1
+    for (int s0 = close_end; s0 < len; s0 += G) {
+      const int s = s0 + lane;
+      const int entry = e_cur;
+      const V4 o0 = n0, o3 = n3;
+      e_cur = e_nxt;
+      e_nxt = (s + 2 * G < len) ? row[s + 2 * G] : -1;
+      if (e_cur >= 0) {
+        const int jn = e_cur & ROW_INDEX_MASK;
+        n0 = in.p0[jn];
+        n3 = in.p3[jn];
+      }
+      if (entry >= 0) {
+        const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
+        const V3<R> d = dco + xyz<R>(o3) - offb_s;
+        const R r2 = dot(d, d);
+        if (r2 < cut.rbb2) {
+          const R r = m_sqrt(r2);
+          const FD<R> v = f3_eval(r, eps_n, f_bb);
+          R dVdr = tw_n * v.d;
+          if constexpr (MODEL == 2) {
+            const FD<R> dh = debye_eval(r, P);
+            R mult = R(1);
+            if (half_ends) {
+              const int mo = (int)o0.w;
+              mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
+            }
+            dVdr += tw_dh * mult * dh.d;
+            if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
+          }
+          if constexpr (SAVE) e[T_NEXC] += R(0.5) * v.f;
+          axpy(gbk, dVdr / r, d);
+        }
+      }
+    }
+  }
   if (n_items > kMdMaxItems) {
     if (lane == 0) atomicOr(flags, 4);
     n_items = kMdMaxItems;
   }
+  MD_STAMP(1);
   __syncthreads();  // max_cnt = 0 and self_lds are visible
   if (lane == 0) {
     item_cnt[grp] = valid ? n_items : 0;
     atomicMax(&max_cnt, valid ? n_items : 0);
   }
   __syncthreads();
+  MD_STAMP(2);
 
   // ---- phase 2: angular pass, work items spread over the whole workgroup so that every wavefront
   //      runs ONE code path: wave 0 takes the 2 x 32 bonded neighbours (FENE, bonded excluded volume,
@@ -369,7 +452,8 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     constexpr int kPerSweep = (kMdBlock - 64) / PPB;  // 6
     const bool bonded_wave = threadIdx.x < 64;
     const int n_sweeps = (max_cnt + kPerSweep - 1) / kPerSweep;
-    for (int sweep = 0; sweep < ((ablate & 2) ? 0 : (bonded_wave ? 1 : n_sweeps)); ++sweep) {
+    const int my_sweeps = bonded_wave ? ((ablate & 16) ? 0 : 1) : ((ablate & 8) ? 0 : n_sweeps);
+    for (int sweep = 0; sweep < ((ablate & 2) ? 0 : my_sweeps); ++sweep) {
       int p, idx;
       if (bonded_wave) {
         p = threadIdx.x >> 1;
@@ -426,7 +510,9 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
       }
     }
   }
+  MD_STAMP(3);
   __syncthreads();
+  MD_STAMP(4);
 
   // ---- fold: each group gathers its owner's result rows (one per lane), adds the radial-pass
   //      site gradients, and reduces over its 8 lanes in a fixed order
@@ -462,10 +548,11 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     group_reduce_v3<G>(sg.g3);
   }
 
+  MD_STAMP(5);
   // ---- thermostat noise for this (nucleotide, step): the two Philox blocks and the three
   //      Box-Muller pairs are produced by lanes 0..2 of the group side by side, then handed to lane 0
   R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
-  if (do_step && !(ablate & 4)) {
+  if (do_step && !(ablate & (4 | 32))) {
     uint32_t c[4] = {(uint32_t)ii, uint32_t(step), uint32_t(step >> 32), (uint32_t)(lane & 1)};
     philox4x32(c, uint32_t(seed), uint32_t(seed >> 32));
     const bool hi = (lane == 2);
@@ -479,6 +566,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     z[5] = __shfl(zb, 1, G);
   }
 
+  MD_STAMP(6);
   double ke_t = 0.0, ke_r = 0.0;
   if (lane == 0 && valid) {
     const V3<R> F = -sg.dc;
@@ -519,14 +607,14 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
       L[0] += K.half_dt * tb[0];
       L[1] += K.half_dt * tb[1];
       L[2] += K.half_dt * tb[2];
-      drift(x, qs, p, L, K.half_dt, K);
+      drift(x, qs, p, L, K.half_dt, K, !(ablate & 64));
       p[0] = K.c1_t * p[0] + K.c2_t * z[0];
       p[1] = K.c1_t * p[1] + K.c2_t * z[1];
       p[2] = K.c1_t * p[2] + K.c2_t * z[2];
       L[0] = K.c1_r * L[0] + K.c2_r[0] * z[3];
       L[1] = K.c1_r * L[1] + K.c2_r[1] * z[4];
       L[2] = K.c1_r * L[2] + K.c2_r[2] * z[5];
-      drift(x, qs, p, L, K.half_dt, K);
+      drift(x, qs, p, L, K.half_dt, K, !(ablate & 64));
       // keep the quaternion on the unit sphere (fp32 round-off)
       const R inv = m_rsqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
       qs[0] *= inv;
@@ -549,6 +637,7 @@ __global__ __launch_bounds__(kMdBlock, 2) void md_step_kernel(
     out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
     mom[i] = V4{p[0], p[1], p[2], R(0)};
     ang[i] = V4{L[0], L[1], L[2], R(0)};
+    MD_STAMP(7);
   }
   if constexpr (SAVE) {
     if (lane == 0) {
@@ -690,15 +779,9 @@ static LangevinConst<R> make_const(const mythos_sim* s) {
 template <typename R>
 static MdCut<R> make_cut(const mythos_system* sys) {
   const OxParams<double>& P = sys->pd;
-  const double off_back = std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model == 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
-  const double off_base = std::fabs(P[GEO_BASE]), off_stack = std::fabs(P[GEO_STACK]);
   double rbb = P[NEXC_BACKBONE_RC];
   if (sys->model == 2) rbb = std::max(rbb, (double)P[DH_RCUT]);
-  double rcom = std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]) + off_back + off_base;
-  rcom = std::max(rcom, P[NEXC_BASE_RC] + 2 * off_base);
-  rcom = std::max(rcom, std::max((double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH]) + 2 * off_base);
-  rcom = std::max(rcom, P[CXST_RCHIGH] + 2 * off_stack);
-  rcom *= 1.0 + 1e-6;
+  const double rcom = oxdna_close_range(sys);
   MdCut<R> c;
   c.rbb2 = R(rbb * rbb);
   c.rcom2 = R(rcom * rcom);
@@ -760,13 +843,13 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->row_stride, kick_close,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sb[samples++], st));
@@ -793,6 +876,16 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   }
   sim->last_kernel_ms = samples ? acc / samples : 0.0;
   sim->last_samples = samples;
+  if (ablate & 128) {  // diagnostic: dump the cycle stamps of the last launch
+    if (const char* path = getenv("MYTHOS_MD_STAMPS")) {
+      std::vector<unsigned long long> h((size_t)blocks * 32);
+      MYTHOS_HIP_TRY(hipMemcpy(h.data(), sim->d_epart, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(path, "wb")) {
+        fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
+        fclose(f);
+      }
+    }
+  }
   sim->step += n_steps;
   if (flags & 2) {
     set_error("mythos_langevin_run: NaN in the state (time step too large or overlapping start configuration)");
@@ -845,7 +938,7 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
     for (int a = 0; a < 5; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
        hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
-       hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * kTraceWidth * sizeof(double)) == hipSuccess &&
+       hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 32 * sizeof(double)) == hipSuccess &&
        hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
   for (int k = 0; ok && k < mythos_sim::kMaxSamples; ++k)
     ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -51,7 +53,7 @@ struct mythos_system {
 
   // neighbour rows (device)
   int* d_rows = nullptr;     // [n][row_stride]
-  int* d_row_len = nullptr;  // [n] number of used slots (>= 2)
+  int* d_row_len = nullptr;  // [n] used slots (>= 2) | [2n] bonded partners | [n] end of the "close" segment
   int row_stride = 0;
   size_t rows_cap = 0;  // allocated ints in d_rows
   bool nbrs_set = false;
@@ -95,6 +97,22 @@ template <>
 inline const OxParams<float>& params_of<float>(const mythos_system* s) { return s->pf; }
 template <>
 inline const OxParams<double>& params_of<double>(const mythos_system* s) { return s->pd; }
+
+// Largest centre-centre distance at which anything other than the backbone-backbone terms (excluded
+// volume between base / backbone sites, H-bond, cross- and coaxial stacking) can act.  Rows keep the
+// neighbours inside this range (+ skin) in a leading "close" segment so the MD kernel's radial pass
+// runs its heavy and its Debye-only code on homogeneous wavefronts.
+inline double oxdna_close_range(const mythos_system* sys) {
+  const OxParams<double>& P = sys->pd;
+  const double off_back =
+      std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model == 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
+  const double off_base = std::fabs(P[GEO_BASE]), off_stack = std::fabs(P[GEO_STACK]);
+  double rcom = std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]) + off_back + off_base;
+  rcom = std::max(rcom, P[NEXC_BASE_RC] + 2 * off_base);
+  rcom = std::max(rcom, std::max((double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH]) + 2 * off_base);
+  rcom = std::max(rcom, P[CXST_RCHIGH] + 2 * off_stack);
+  return rcom * (1.0 + 1e-6);
+}
 
 // oxdna_kernels.hip
 int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,

@@ -52,6 +52,8 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
   if (int rc = rows_reserve(sys, stride)) return rc;
   MYTHOS_HIP_TRY(hipMemcpy(sys->d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
   MYTHOS_HIP_TRY(hipMemcpy(sys->d_row_len, len.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  // a user-supplied pair list carries no distance classes: every entry is in the "close" segment
+  MYTHOS_HIP_TRY(hipMemcpy(sys->d_row_len + 3 * (size_t)n, len.data(), n * sizeof(int), hipMemcpyHostToDevice));
   sys->nbrs_set = true;
   return 0;
 }
@@ -63,10 +65,11 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
 // ------------------------------------------------------------------------------------------------
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R* __restrict__ pos,
-                                                                   const BoxT<R> box, R rc2,
+                                                                   const BoxT<R> box, R rc2, R rcl2,
                                                                    const int* __restrict__ partners_rows_in,
                                                                    int* __restrict__ rows, int* __restrict__ row_len,
-                                                                   int row_stride, int* __restrict__ overflow) {
+                                                                   int* __restrict__ row_close, int row_stride,
+                                                                   int* __restrict__ overflow) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
   if (wave >= n) return;
@@ -75,21 +78,25 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
   int* row = rows + (size_t)i * row_stride;
   const int b0 = partners_rows_in[2 * i], b1 = partners_rows_in[2 * i + 1];
-  int cnt = ROW_BONDED_SLOTS;
-  for (int j0 = 0; j0 < n; j0 += 64) {
-    const int j = j0 + lane;
-    bool hit = false;
-    if (j < n && j != i && j != b0 && j != b1) {
-      V3<R> d{pos[S * j] - ci.x, pos[S * j + 1] - ci.y, pos[S * j + 2] - ci.z};
-      d = min_image(d, box);
-      hit = dot(d, d) < rc2;
+  int cnt = ROW_BONDED_SLOTS, n_close = 0;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: "close" segment (r2 < rcl2), pass 1: the rest of the list
+    for (int j0 = 0; j0 < n; j0 += 64) {
+      const int j = j0 + lane;
+      bool hit = false;
+      if (j < n && j != i && j != b0 && j != b1) {
+        V3<R> d{pos[S * j] - ci.x, pos[S * j + 1] - ci.y, pos[S * j + 2] - ci.z};
+        d = min_image(d, box);
+        const R r2 = dot(d, d);
+        hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2);
+      }
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        if (slot < row_stride) row[slot] = (j < i) ? (j | ROW_ROLE_Q) : j;
+      }
+      cnt += __popcll(m);
     }
-    const unsigned long long m = __ballot(hit);
-    if (hit) {
-      const int slot = cnt + __popcll(m & ((1ull << lane) - 1ull));
-      if (slot < row_stride) row[slot] = (j < i) ? (j | ROW_ROLE_Q) : j;
-    }
-    cnt += __popcll(m);
+    if (pass == 0) n_close = cnt;
   }
   if (lane == 0) {
     row[0] = b0;
@@ -99,6 +106,7 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
       cnt = row_stride;
     }
     row_len[i] = cnt;
+    row_close[i] = min(n_close, cnt);
   }
 }
 
@@ -153,29 +161,68 @@ __global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGr
   atomicAdd(&cnt[h], 1);
 }
 
-// exclusive scan of cnt[0..m) into start[0..m], one workgroup; cnt is cleared for reuse as a cursor
-__global__ __launch_bounds__(1024) void cell_scan_kernel(int m, int* __restrict__ cnt, int* __restrict__ start) {
-  __shared__ int part[1024];
-  const int t = threadIdx.x;
-  const int per = (m + 1023) / 1024;
-  const int lo = t * per, hi = min(m, lo + per);
-  int s = 0;
-  for (int k = lo; k < hi; ++k) s += cnt[k];
-  part[t] = s;
+// exclusive scan of cnt[0..m) into start[0..m] in two coalesced passes; cnt is cleared for reuse as a
+// cursor.  Pass 1: each 1024-thread workgroup scans 4096 counters (int4 per lane, wave shuffles + one LDS
+// hop) and publishes its total.  Pass 2 adds the totals of the preceding workgroups.
+constexpr int kScanBlock = 1024;
+constexpr int kScanPerBlock = 4 * kScanBlock;
+
+__global__ __launch_bounds__(kScanBlock) void cell_scan_local_kernel(int m, int* __restrict__ cnt,
+                                                                      int* __restrict__ start,
+                                                                      int* __restrict__ block_sum) {
+  __shared__ int wave_tot[kScanBlock / 64];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int base = (blockIdx.x * kScanBlock + t) * 4;
+  int4 v = make_int4(0, 0, 0, 0);
+  if (base + 3 < m) {
+    v = *reinterpret_cast<const int4*>(cnt + base);
+    *reinterpret_cast<int4*>(cnt + base) = make_int4(0, 0, 0, 0);
+  } else {
+    int* pv = &v.x;
+    for (int k = 0; k < 4; ++k)
+      if (base + k < m) {
+        pv[k] = cnt[base + k];
+        cnt[base + k] = 0;
+      }
+  }
+  const int s = v.x + v.y + v.z + v.w;
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wave_tot[w] = inc;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (t >= o) ? part[t - o] : 0;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
+  if (t == 0) {
+    int run = 0;
+    for (int k = 0; k < kScanBlock / 64; ++k) {
+      const int x = wave_tot[k];
+      wave_tot[k] = run;
+      run += x;
+    }
+    block_sum[blockIdx.x] = run;
   }
-  int run = part[t] - s;
-  for (int k = lo; k < hi; ++k) {
-    start[k] = run;
-    run += cnt[k];
-    cnt[k] = 0;
+  __syncthreads();
+  const int pre = wave_tot[w] + inc - s;
+  const int o4[4] = {pre, pre + v.x, pre + v.x + v.y, pre + v.x + v.y + v.z};
+  for (int k = 0; k < 4; ++k)
+    if (base + k < m) start[base + k] = o4[k];
+}
+
+__global__ void cell_scan_fix_kernel(int m, int n_blocks, const int* __restrict__ block_sum, int* __restrict__ start) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h > m) return;
+  const int b = (h < m ? h : m - 1) / kScanPerBlock;
+  int off = 0;
+  for (int k = 0; k < b; ++k) off += block_sum[k];
+  if (h < m) {
+    start[h] += off;
+  } else {
+    int tot = 0;
+    for (int k = 0; k < n_blocks; ++k) tot += block_sum[k];
+    start[m] = tot;
   }
-  if (t == 1023) start[m] = part[1023];
 }
 
 __global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, const int* __restrict__ start,
@@ -205,12 +252,12 @@ __global__ void cell_sort_kernel(int m, const int* __restrict__ start, int* __re
 // are concatenated by a wave prefix sum and swept 64 at a time with ballot compaction
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* __restrict__ pos, const BoxT<R> box,
-                                                                const CellGrid<R> g, R rc2,
+                                                                const CellGrid<R> g, R rc2, R rcl2,
                                                                 const int* __restrict__ partners,
                                                                 const int* __restrict__ start,
                                                                 const int* __restrict__ bucket, int* __restrict__ rows,
-                                                                int* __restrict__ row_len, int row_stride,
-                                                                int* __restrict__ overflow) {
+                                                                int* __restrict__ row_len, int* __restrict__ row_close,
+                                                                int row_stride, int* __restrict__ overflow) {
   __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
@@ -244,7 +291,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   const int total = __shfl(inc, 26, 64);
   int* row = rows + (size_t)i * row_stride;
   const int b0 = partners[2 * i], b1 = partners[2 * i + 1];
-  int out = ROW_BONDED_SLOTS;
+  int out = ROW_BONDED_SLOTS, n_close = 0;
+  for (int pass = 0; pass < 2; ++pass) {  // pass 0: "close" segment, pass 1: the rest
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
     bool hit = false;
@@ -263,7 +311,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
         if (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]) {
           V3<R> d{xj - ci.x, yj - ci.y, zj - ci.z};
           d = min_image(d, box);
-          hit = dot(d, d) < rc2;
+          const R r2 = dot(d, d);
+          hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2);
         }
       }
     }
@@ -274,6 +323,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     }
     out += __popcll(m);
   }
+  if (pass == 0) n_close = out;
+  }
   if (lane == 0) {
     row[0] = b0;
     row[1] = b1;
@@ -282,6 +333,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
       out = row_stride;
     }
     row_len[i] = out;
+    row_close[i] = min(n_close, out);
   }
 }
 
@@ -292,8 +344,11 @@ static int next_pow2(int v) {
 }
 
 template <typename R>
-static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, hipStream_t st) {
+static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, double skin, hipStream_t st) {
   const int n = sys->n;
+  // classification radius of the leading "close" segment (everything is close until parameters exist)
+  const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
+  int* d_close = sys->d_row_len + 3 * (size_t)n;
   CellGrid<R> g;
   bool ok = true;
   for (int k = 0; k < 3; ++k) {
@@ -315,15 +370,15 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   if (!ok || n < 512) {  // tiny systems / boxes under three cells: the all-pairs sweep is exact and cheap
     if (vec4)
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, true>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), d_partners, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
     else
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, false>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), d_partners, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
     return 0;
   }
   const int H = next_pow2(2 * n);
   g.hmask = H - 1;
-  const size_t need = (size_t)2 * H + 2 + (size_t)2 * n;  // cnt[H] start[H+1] slot_of[n] bucket[n]
+  const size_t need = (size_t)2 * H + 4 + (size_t)2 * n + 1024;  // cnt[H] start[H+1] pad slot_of[n] bucket[n] block_sum
   if (need > sys->cell_cap) {
     if (sys->d_cell) (void)hipFree(sys->d_cell);
     sys->d_cell = nullptr;
@@ -333,24 +388,29 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   }
   int* cnt = sys->d_cell;
   int* start = cnt + H;
-  int* slot_of = start + H + 1;
+  int* slot_of = start + H + 4;  // keeps the int4 accesses on cnt aligned
   int* bucket = slot_of + n;
+  int* block_sum = bucket + n;
   MYTHOS_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)H * sizeof(int), st));
   const int tb = (n + 255) / 256;
   if (vec4)
     hipLaunchKernelGGL((cell_count_kernel<R, true>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
   else
     hipLaunchKernelGGL((cell_count_kernel<R, false>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
-  hipLaunchKernelGGL(cell_scan_kernel, dim3(1), dim3(1024), 0, st, H, cnt, start);
+  const int nsb = (H + kScanPerBlock - 1) / kScanPerBlock;
+  hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nsb), dim3(kScanBlock), 0, st, H, cnt, start, block_sum);
+  hipLaunchKernelGGL(cell_scan_fix_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, st, H, nsb, block_sum, start);
   hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, slot_of, start, cnt, bucket);
   hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, start, bucket);
   const int wb = (n + 3) / 4;
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       d_partners, start, bucket, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+                       R(rcl * rcl), d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       sys->d_overflow);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       d_partners, start, bucket, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_overflow);
+                       R(rcl * rcl), d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       sys->d_overflow);
   return 0;
 }
 
@@ -362,9 +422,9 @@ int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec
   MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, sizeof(int), stream));
   int rc;
   if (sys->dtype == MYTHOS_F32)
-    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, stream);
+    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, stream);
   else
-    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, stream);
+    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, skin, stream);
   if (rc) return rc;
   MYTHOS_HIP_TRY(hipGetLastError());
   sys->nbrs_set = true;

@@ -85,8 +85,8 @@ __device__ __forceinline__ R group_sum(R v) {
 // Walk row i with the G lanes of a group.  On return every lane holds its PARTIAL sums;
 // call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
 // parameter partials, inside the sink) carry weight 1/2.
-template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader>
-__device__ __forceinline__ void gather_row(const OxParams<R>& P, const Loader& ld, const BoxT<R>& box,
+template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader, class PT>
+__device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
                                            PG& pg) {

@@ -27,7 +27,7 @@ struct LdsPG {
 
 template <typename R, int MODEL, int MODE, int G>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
 __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy_kernel(
-    const OxParams<R> P, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
+    const OxParams<R> Pk, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
     double* __restrict__ pg_part) {
@@ -35,6 +35,9 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
   __shared__ double pg_lds[MODE == 2 ? OXP_COUNT : 1];
+  __shared__ R p_lds[OXP_COUNT];
+  stage_params(Pk, p_lds, threadIdx.x, kBlock);
+  const LdsParams<R> P{p_lds};
 
   const int frame = blockIdx.y;
   const int grp = threadIdx.x / G;
@@ -44,8 +47,8 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy
 
   if constexpr (MODE == 2) {
     for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) pg_lds[k] = 0.0;
-    __syncthreads();
   }
+  __syncthreads();
 
   R e[T_COUNT];
 #pragma unroll

@@ -20,11 +20,31 @@ enum OxParamIndex : int {
   OXP_COUNT
 };
 
+// The flat parameter vector as it travels in the kernel-argument segment.
 template <typename R>
 struct OxParams {
+  static constexpr bool indexed = false;  // compile-time indices only (kernel-argument segment)
   R v[OXP_COUNT];
   __host__ __device__ __forceinline__ R operator[](int i) const { return v[i]; }
 };
+
+// What the device code indexes: a copy of the vector staged in LDS by every workgroup.  Reading it with
+// a compile-time index is one broadcast ds_read (all lanes, same address); a lane-varying index - the
+// role-dependent choice between two parameter blocks, or the 4x4 sequence-weight tables - is an ordinary
+// LDS gather.  Keeping the ~270 scalars in the kernel-argument segment instead costs a scalar-cache
+// round trip (s_load + s_waitcnt) per parameter block at every use, because they cannot all stay in
+// the 100 or so SGPRs a wave owns; that was the dominant stall of the angular terms.
+template <typename R>
+struct LdsParams {
+  static constexpr bool indexed = true;
+  const R* p;
+  __device__ __forceinline__ R operator[](int i) const { return p[i]; }
+};
+
+template <typename R>
+__device__ __forceinline__ void stage_params(const OxParams<R>& P, R* lds, int tid, int nthreads) {
+  for (int k = tid; k < OXP_COUNT; k += nthreads) lds[k] = P.v[k];
+}
 
 // ------------------------------------------------------------------ tiny vector algebra
 template <typename R>
@@ -108,8 +128,8 @@ __device__ __forceinline__ FD<R> acos_clamped(R c) {
 
 // ------------------------------------------------------------------ f1 (base_functions.py:13-37), eps = 1
 // parameter block layout: RLOW,RHIGH,RCLOW,RCHIGH,A,R0,RC,BLOW,BHIGH,SHIFT
-template <typename R>
-__device__ __forceinline__ FD<R> f1_eval(R r, const OxParams<R>& P, int b) {
+template <typename R, class PT>
+__device__ __forceinline__ FD<R> f1_eval(R r, const PT& P, int b) {
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3];
   FD<R> o{R(0), R(0)};
   if (rlow < r && r < rhigh) {
@@ -128,8 +148,8 @@ __device__ __forceinline__ FD<R> f1_eval(R r, const OxParams<R>& P, int b) {
   }
   return o;
 }
-template <typename R, class PG>
-__device__ __forceinline__ void f1_pgrad(R r, const OxParams<R>& P, int b, R scale, PG& pg) {
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void f1_pgrad(R r, const PT& P, int b, R scale, PG& pg) {
   if constexpr (!PG::on) return;
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3];
   if (rlow < r && r < rhigh) {
@@ -151,8 +171,8 @@ __device__ __forceinline__ void f1_pgrad(R r, const OxParams<R>& P, int b, R sca
 
 // ------------------------------------------------------------------ f2 (base_functions.py:40-63)
 // layout: RLOW,RHIGH,RCLOW,RCHIGH,K,R0,RC,BLOW,BHIGH,SHIFT ; SHIFT = (rc-r0)^2/2
-template <typename R>
-__device__ __forceinline__ FD<R> f2_eval(R r, const OxParams<R>& P, int b) {
+template <typename R, class PT>
+__device__ __forceinline__ FD<R> f2_eval(R r, const PT& P, int b) {
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3], k = P[b + 4];
   FD<R> o{R(0), R(0)};
   if (rlow < r && r < rhigh) {
@@ -170,8 +190,8 @@ __device__ __forceinline__ FD<R> f2_eval(R r, const OxParams<R>& P, int b) {
   }
   return o;
 }
-template <typename R, class PG>
-__device__ __forceinline__ void f2_pgrad(R r, const OxParams<R>& P, int b, R scale, PG& pg) {
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void f2_pgrad(R r, const PT& P, int b, R scale, PG& pg) {
   if constexpr (!PG::on) return;
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3], k = P[b + 4];
   if (rlow < r && r < rhigh) {
@@ -199,13 +219,16 @@ struct F3P {
   R rstar, sigma, b, rc;
   int base;  // index of RSTAR in the flat vector (for parameter partials)
 };
-template <typename R>
-__device__ __forceinline__ F3P<R> f3_params(const OxParams<R>& P, int b) {
+template <typename R, class PT>
+__device__ __forceinline__ F3P<R> f3_params(const PT& P, int b) {
   return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], b};
 }
 // role-dependent choice between two blocks (compile-time indices -> one v_cndmask per value)
-template <typename R>
-__device__ __forceinline__ F3P<R> f3_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+// role-dependent choice between two blocks: an indexed read for the LDS copy, one v_cndmask per value
+// for the kernel-argument copy (a lane-varying index into kernel arguments would spill the whole block)
+template <typename R, class PT>
+__device__ __forceinline__ F3P<R> f3_params_sel(const PT& P, bool first, int ba, int bb) {
+  if constexpr (PT::indexed) return f3_params<R>(P, first ? ba : bb);
   return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
           first ? P[ba + 3] : P[bb + 3], first ? ba : bb};
 }
@@ -252,12 +275,13 @@ struct F4P {
   R t0, ts, tc, a, b;
   int base;
 };
-template <typename R>
-__device__ __forceinline__ F4P<R> f4_params(const OxParams<R>& P, int b) {
+template <typename R, class PT>
+__device__ __forceinline__ F4P<R> f4_params(const PT& P, int b) {
   return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], P[b + 4], b};
 }
-template <typename R>
-__device__ __forceinline__ F4P<R> f4_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+template <typename R, class PT>
+__device__ __forceinline__ F4P<R> f4_params_sel(const PT& P, bool first, int ba, int bb) {
+  if constexpr (PT::indexed) return f4_params<R>(P, first ? ba : bb);
   return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
           first ? P[ba + 3] : P[bb + 3], first ? P[ba + 4] : P[bb + 4], first ? ba : bb};
 }
@@ -306,8 +330,16 @@ struct F5P {
   R xs, xc, a, b;
   int base;
 };
-template <typename R>
-__device__ __forceinline__ F5P<R> f5_params_sel(const OxParams<R>& P, bool first, int ba, int bb) {
+template <typename R, class PT>
+__device__ __forceinline__ F5P<R> f5_params(const PT& P, int b) {
+  return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], b};
+}
+template <typename R, class PT>
+__device__ __forceinline__ F5P<R> f5_params_sel(const PT& P, bool first, int ba, int bb) {
+  if constexpr (PT::indexed) {
+    const int b = first ? ba : bb;
+    return {P[b + 0], P[b + 1], P[b + 2], P[b + 3], b};
+  }
   return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
           first ? P[ba + 3] : P[bb + 3], first ? ba : bb};
 }
@@ -341,8 +373,8 @@ __device__ __forceinline__ void f5_pgrad(R x, const F5P<R>& p, R scale, PG& pg) 
 
 // ------------------------------------------------------------------ f6 (dna2/base_functions.py:13-17)
 // layout: A,B
-template <typename R>
-__device__ __forceinline__ FD<R> f6_eval(R th, const OxParams<R>& P, int b) {
+template <typename R, class PT>
+__device__ __forceinline__ FD<R> f6_eval(R th, const PT& P, int b) {
   FD<R> o{R(0), R(0)};
   if (th >= P[b + 1]) {
     const R t = th - P[b + 1];
@@ -351,8 +383,8 @@ __device__ __forceinline__ FD<R> f6_eval(R th, const OxParams<R>& P, int b) {
   }
   return o;
 }
-template <typename R, class PG>
-__device__ __forceinline__ void f6_pgrad(R th, const OxParams<R>& P, int b, R scale, PG& pg) {
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void f6_pgrad(R th, const PT& P, int b, R scale, PG& pg) {
   if constexpr (!PG::on) return;
   if (th >= P[b + 1]) {
     const R t = th - P[b + 1];
@@ -362,8 +394,8 @@ __device__ __forceinline__ void f6_pgrad(R th, const OxParams<R>& P, int b, R sc
 }
 
 // ------------------------------------------------------------------ smoothed FENE (interactions.py:16-41)
-template <typename R>
-__device__ __forceinline__ FD<R> fene_eval(R r, const OxParams<R>& P) {
+template <typename R, class PT>
+__device__ __forceinline__ FD<R> fene_eval(R r, const PT& P) {
   const R eps = P[FENE_EPS], x = r - P[FENE_R0], delta = P[FENE_DELTA];
   const R diff = m_sqrt(x * x + R(1e-10));
   FD<R> o;
@@ -378,8 +410,8 @@ __device__ __forceinline__ FD<R> fene_eval(R r, const OxParams<R>& P) {
   }
   return o;
 }
-template <typename R, class PG>
-__device__ __forceinline__ void fene_pgrad(R r, const OxParams<R>& P, R dVdr, R scale, PG& pg) {
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void fene_pgrad(R r, const PT& P, R dVdr, R scale, PG& pg) {
   if constexpr (!PG::on) return;
   const R eps = P[FENE_EPS], x = r - P[FENE_R0], delta = P[FENE_DELTA];
   const R diff = m_sqrt(x * x + R(1e-10));
@@ -398,8 +430,8 @@ __device__ __forceinline__ void fene_pgrad(R r, const OxParams<R>& P, R dVdr, R 
 }
 
 // ------------------------------------------------------------------ Debye-Hueckel (dna2/interactions.py:15-28)
-template <typename R>
-__device__ __forceinline__ FD<R> debye_eval(R r, const OxParams<R>& P) {
+template <typename R, class PT>
+__device__ __forceinline__ FD<R> debye_eval(R r, const PT& P) {
   FD<R> o{R(0), R(0)};
   if (r < P[DH_RCUT]) {
     if (r < P[DH_RHIGH]) {
@@ -414,8 +446,8 @@ __device__ __forceinline__ FD<R> debye_eval(R r, const OxParams<R>& P) {
   }
   return o;
 }
-template <typename R, class PG>
-__device__ __forceinline__ void debye_pgrad(R r, const OxParams<R>& P, R mult, PG& pg) {
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void debye_pgrad(R r, const PT& P, R mult, PG& pg) {
   if constexpr (!PG::on) return;
   if (r < P[DH_RCUT]) {
     if (r < P[DH_RHIGH]) {

@@ -50,14 +50,19 @@ __device__ __forceinline__ void quat_axes(R q0, R q1, R q2, R q3, V3<R>& a1, V3<
   a3 = {R(2) * (q1 * q3 + q0 * q2), R(2) * (q2 * q3 - q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3};
 }
 
-// 4x4 sequence-weight lookup as a select chain over scalar registers: a dynamic index into the
-// by-value parameter block would force the whole block into scratch memory.
-template <typename R>
-__device__ __forceinline__ R weight_lookup(const OxParams<R>& P, int base, int k) {
-  R w = P[base];
+// 4x4 sequence-weight lookup: an indexed read of an LDS-staged vector, or a select chain over scalar
+// registers for the kernel-argument copy (a lane-varying index into kernel arguments would force the
+// whole block into scratch memory)
+template <typename R = void, class PT>
+__device__ __forceinline__ auto weight_lookup(const PT& P, int base, int k) {
+  if constexpr (PT::indexed) {
+    return P[base + k];
+  } else {
+    auto w = P[base];
 #pragma unroll
-  for (int t = 1; t < 16; ++t) w = (k == t) ? P[base + t] : w;
-  return w;
+    for (int t = 1; t < 16; ++t) w = (k == t) ? P[base + t] : w;
+    return w;
+  }
 }
 
 template <typename R>
@@ -91,8 +96,8 @@ __device__ __forceinline__ void acc_dir(V3<R>& gd, R coef, R sg, R c, V3<R> u, V
 }
 
 // one radial f3 site pair: energy, self gradient, parameter partials
-template <typename R, bool GRAD, class PG>
-__device__ __forceinline__ R f3_site_pair(const OxParams<R>& P, int ie, const F3P<R>& fp, V3<R> d, R als, R bes,
+template <typename R, bool GRAD, class PG, class PT>
+__device__ __forceinline__ R f3_site_pair(const PT& P, int ie, const F3P<R>& fp, V3<R> d, R als, R bes,
                                           R tw, SelfGrad<R>& sg, PG& pg) {
   const R r = m_sqrt(dot(d, d));
   const FD<R> v = f3_eval(r, P[ie], fp);
@@ -105,8 +110,8 @@ __device__ __forceinline__ R f3_site_pair(const OxParams<R>& P, int ie, const F3
 // ------------------------------------------------------------------------------------------------
 // bonded pair: FENE + bonded excluded volume + stacking.   role_p: self is nn_i of the bond.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MODEL, bool GRAD, class PG>
-__device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+template <typename R, int MODEL, bool GRAD, class PG, class PT>
+__device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                             bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
@@ -123,12 +128,12 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
   }
   // ---- bonded excluded volume: base-base, back_p-base_q, base_p-back_q
   {
-    R eb = f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params(P, BEXC_BASE_RSTAR),
+    R eb = f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params<R>(P, BEXC_BASE_RSTAR),
                                      site_disp(dco, s, o, g_ba, R(0), g_ba, R(0)), g_ba, R(0), P[TW_BEXC], sg, pg);
     // self backbone - other base: "back_p - base_q" if self is p, else "base_p - back_q"
-    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
+    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel<R>(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
                                     site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_BEXC], sg, pg);
-    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel(P, role_p, BEXC_BASE_BACK_RSTAR, BEXC_BACK_BASE_RSTAR),
+    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel<R>(P, role_p, BEXC_BASE_BACK_RSTAR, BEXC_BACK_BASE_RSTAR),
                                     site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_BEXC], sg, pg);
     e[T_BEXC] += wgt * eb;
   }
@@ -152,9 +157,9 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
     ts.d = -ts.d;
     to.f = R(kPi) - to.f;
     to.d = -to.d;
-    const F4P<R> p4 = f4_params(P, STCK_TH4_T0);
-    const F4P<R> ps = f4_params_sel(P, role_p, STCK_TH6_T0, STCK_TH5_T0);
-    const F4P<R> po = f4_params_sel(P, role_p, STCK_TH5_T0, STCK_TH6_T0);
+    const F4P<R> p4 = f4_params<R>(P, STCK_TH4_T0);
+    const F4P<R> ps = f4_params_sel<R>(P, role_p, STCK_TH6_T0, STCK_TH5_T0);
+    const F4P<R> po = f4_params_sel<R>(P, role_p, STCK_TH5_T0, STCK_TH6_T0);
     const FD<R> A4 = f4_eval(t4.f, p4);
     if (A4.f == R(0)) return;
     const FD<R> As = f4_eval(ts.f, ps);
@@ -166,8 +171,8 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
     const V3<R> nb = irb * db;
     const R xs = sgm * dot(s.a2, nb);  // -cos(phi1) if p, -cos(phi2) if q
     const R xo = sgm * dot(o.a2, nb);
-    const F5P<R> qs = f5_params_sel(P, role_p, STCK_PHI1_XS, STCK_PHI2_XS);
-    const F5P<R> qo = f5_params_sel(P, role_p, STCK_PHI2_XS, STCK_PHI1_XS);
+    const F5P<R> qs = f5_params_sel<R>(P, role_p, STCK_PHI1_XS, STCK_PHI2_XS);
+    const F5P<R> qo = f5_params_sel<R>(P, role_p, STCK_PHI2_XS, STCK_PHI1_XS);
     const FD<R> Bs = f5_eval(xs, qs);
     if (Bs.f == R(0)) return;
     const FD<R> Bo = f5_eval(xo, qo);
@@ -211,12 +216,12 @@ __device__ __forceinline__ void bonded_pair(const OxParams<R>& P, const Nuc<R>& 
 
 // radial supports of the angular unbonded terms: H-bond / cross-stacking act on the base-base
 // distance, coaxial stacking on the stack-stack distance
-template <typename R>
-__device__ __forceinline__ bool hb_crst_support(const OxParams<R>& P, R r) {
+template <typename R, class PT>
+__device__ __forceinline__ bool hb_crst_support(const PT& P, R r) {
   return (P[HYDR_RCLOW] < r && r < P[HYDR_RCHIGH]) || (P[CRST_RCLOW] < r && r < P[CRST_RCHIGH]);
 }
-template <typename R>
-__device__ __forceinline__ bool cxst_support(const OxParams<R>& P, R r) {
+template <typename R, class PT>
+__device__ __forceinline__ bool cxst_support(const PT& P, R r) {
   return P[CXST_RCLOW] < r && r < P[CXST_RCHIGH];
 }
 
@@ -225,8 +230,8 @@ __device__ __forceinline__ bool cxst_support(const OxParams<R>& P, R r) {
 // angular terms (H-bond, cross-stacking, coaxial stacking) can be non-zero for this pair.
 // role_p: self is op_i of the ordered pair.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MODEL, bool GRAD, class PG>
-__device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+template <typename R, int MODEL, bool GRAD, class PG, class PT>
+__device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
@@ -235,7 +240,7 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
   {
     const V3<R> d = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
     const R r = m_sqrt(dot(d, d));
-    const F3P<R> fp = f3_params(P, NEXC_BACKBONE_RSTAR);
+    const F3P<R> fp = f3_params<R>(P, NEXC_BACKBONE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     R dVdr = P[TW_NEXC] * v.d;
@@ -253,9 +258,9 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
   }
   // ---- self backbone - other base ("back_p - base_q" if self is p) and self base - other backbone
   {
-    R en = f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
+    R en = f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
                                      site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_NEXC], sg, pg);
-    en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
+    en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
                                     site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_NEXC], sg, pg);
     e[T_NEXC] += wgt * en;
   }
@@ -264,7 +269,7 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
   {
     const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
     const R r = m_sqrt(dot(d, d));
-    const F3P<R> fp = f3_params(P, NEXC_BASE_RSTAR);
+    const F3P<R> fp = f3_params<R>(P, NEXC_BASE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
@@ -287,8 +292,8 @@ __device__ __forceinline__ bool unbonded_radial(const OxParams<R>& P, const Nuc<
 //      In self/other form the cosines are  a1s.n, -a1o.n, a3s.n, -a3o.n  for either role; the role
 //      decides which angle (and parameter block) each of them is.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MODEL, bool GRAD, class PG>
-__device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+template <typename R, int MODEL, bool GRAD, class PG, class PT>
+__device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                  bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
@@ -326,11 +331,11 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
       }
       R k1 = R(0), k4 = R(0), ks1 = R(0), ko1 = R(0), ks3 = R(0), ko3 = R(0), krad = R(0);
       if (hb_on) {
-        const F4P<R> p1 = f4_params(P, HYDR_TH1_T0), p4 = f4_params(P, HYDR_TH4_T0);
-        const F4P<R> ps1 = f4_params_sel(P, role_p, HYDR_TH3_T0, HYDR_TH2_T0);
-        const F4P<R> po1 = f4_params_sel(P, role_p, HYDR_TH2_T0, HYDR_TH3_T0);
-        const F4P<R> ps3 = f4_params_sel(P, role_p, HYDR_TH8_T0, HYDR_TH7_T0);
-        const F4P<R> po3 = f4_params_sel(P, role_p, HYDR_TH7_T0, HYDR_TH8_T0);
+        const F4P<R> p1 = f4_params<R>(P, HYDR_TH1_T0), p4 = f4_params<R>(P, HYDR_TH4_T0);
+        const F4P<R> ps1 = f4_params_sel<R>(P, role_p, HYDR_TH3_T0, HYDR_TH2_T0);
+        const F4P<R> po1 = f4_params_sel<R>(P, role_p, HYDR_TH2_T0, HYDR_TH3_T0);
+        const F4P<R> ps3 = f4_params_sel<R>(P, role_p, HYDR_TH8_T0, HYDR_TH7_T0);
+        const F4P<R> po3 = f4_params_sel<R>(P, role_p, HYDR_TH7_T0, HYDR_TH8_T0);
         const FD<R> A1 = f4_eval(t1.f, p1), A4 = f4_eval(t4.f, p4);
         const FD<R> As1 = f4_eval(ts1.f, ps1), Ao1 = f4_eval(to1.f, po1);
         const FD<R> As3 = f4_eval(ts3.f, ps3), Ao3 = f4_eval(to3.f, po3);
@@ -365,15 +370,15 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
         }
       }
       if (cr_on) {
-        const F4P<R> p1 = f4_params(P, CRST_TH1_T0);
-        const F4P<R> ps1 = f4_params_sel(P, role_p, CRST_TH3_T0, CRST_TH2_T0);
-        const F4P<R> po1 = f4_params_sel(P, role_p, CRST_TH2_T0, CRST_TH3_T0);
+        const F4P<R> p1 = f4_params<R>(P, CRST_TH1_T0);
+        const F4P<R> ps1 = f4_params_sel<R>(P, role_p, CRST_TH3_T0, CRST_TH2_T0);
+        const F4P<R> po1 = f4_params_sel<R>(P, role_p, CRST_TH2_T0, CRST_TH3_T0);
         const FD<R> A1 = f4_eval(t1.f, p1), As1 = f4_eval(ts1.f, ps1), Ao1 = f4_eval(to1.f, po1);
         const R a123 = A1.f * As1.f * Ao1.f;
         if (a123 != R(0)) {
-          const F4P<R> p4 = f4_params(P, CRST_TH4_T0);
-          const F4P<R> ps3 = f4_params_sel(P, role_p, CRST_TH8_T0, CRST_TH7_T0);
-          const F4P<R> po3 = f4_params_sel(P, role_p, CRST_TH7_T0, CRST_TH8_T0);
+          const F4P<R> p4 = f4_params<R>(P, CRST_TH4_T0);
+          const F4P<R> ps3 = f4_params_sel<R>(P, role_p, CRST_TH8_T0, CRST_TH7_T0);
+          const F4P<R> po3 = f4_params_sel<R>(P, role_p, CRST_TH7_T0, CRST_TH8_T0);
           const FD<R> A4a = f4_eval(t4.f, p4), A4b = f4_eval(R(kPi) - t4.f, p4);
           const FD<R> Sa = f4_eval(ts3.f, ps3), Sb = f4_eval(R(kPi) - ts3.f, ps3);
           const FD<R> Oa = f4_eval(to3.f, po3), Ob = f4_eval(R(kPi) - to3.f, po3);
@@ -441,9 +446,9 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
     const R cs = dot(s.a3, n);   // theta5 if p, theta6 if q
     const R co = -dot(o.a3, n);  // theta6 if p, theta5 if q
     const FD<R> t4 = acos_clamped(c4), t1 = acos_clamped(c1), ts = acos_clamped(cs), to = acos_clamped(co);
-    const F4P<R> p4 = f4_params(P, CXST_TH4_T0), p1 = f4_params(P, CXST_TH1_T0);
-    const F4P<R> ps = f4_params_sel(P, role_p, CXST_TH5_T0, CXST_TH6_T0);
-    const F4P<R> po = f4_params_sel(P, role_p, CXST_TH6_T0, CXST_TH5_T0);
+    const F4P<R> p4 = f4_params<R>(P, CXST_TH4_T0), p1 = f4_params<R>(P, CXST_TH1_T0);
+    const F4P<R> ps = f4_params_sel<R>(P, role_p, CXST_TH5_T0, CXST_TH6_T0);
+    const F4P<R> po = f4_params_sel<R>(P, role_p, CXST_TH6_T0, CXST_TH5_T0);
     const FD<R> A4 = f4_eval(t4.f, p4);
     if (A4.f == R(0)) return;
     const FD<R> Sa = f4_eval(ts.f, ps), Sb = f4_eval(R(kPi) - ts.f, ps);
@@ -477,8 +482,8 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
       nb = irb * db;
       xs = dot(n, cross(nb, s.a1));
       xo = dot(n, cross(nb, o.a1));
-      qs = f5_params_sel(P, role_p, CXST_PHI4_XS, CXST_PHI3_XS);
-      qo = f5_params_sel(P, role_p, CXST_PHI3_XS, CXST_PHI4_XS);
+      qs = f5_params_sel<R>(P, role_p, CXST_PHI4_XS, CXST_PHI3_XS);
+      qo = f5_params_sel<R>(P, role_p, CXST_PHI3_XS, CXST_PHI4_XS);
       Bs = f5_eval(xs, qs);
       Bo = f5_eval(xo, qo);
       phi = Bs.f * Bo.f;
@@ -537,8 +542,8 @@ __device__ __forceinline__ void unbonded_angular(const OxParams<R>& P, const Nuc
 }
 
 // whole unbonded pair (energy API path)
-template <typename R, int MODEL, bool GRAD, class PG>
-__device__ __forceinline__ void unbonded_pair(const OxParams<R>& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+template <typename R, int MODEL, bool GRAD, class PG, class PT>
+__device__ __forceinline__ void unbonded_pair(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                               bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   if (unbonded_radial<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg))
     unbonded_angular<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg);
