@@ -129,6 +129,8 @@ void mythos_oxdna_destroy(mythos_system_t* s) {
   if (s->d_overflow) (void)hipFree(s->d_overflow);
   if (s->d_cell) (void)hipFree(s->d_cell);
   if (s->d_ref_pos) (void)hipFree(s->d_ref_pos);
+  if (s->d_pf) (void)hipFree(s->d_pf);
+  if (s->d_pd) (void)hipFree(s->d_pd);
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->d_pgpart) (void)hipFree(s->d_pgpart);
   delete s;
@@ -147,6 +149,14 @@ int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params
     s->pd.v[k] = flat[k];
     s->pf.v[k] = (float)flat[k];
   }
+  // device copies for the MD kernel; a blocking copy after a device-wide sync, so no kernel in flight
+  // sees a half-written vector
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  if (!s->d_pf) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pf, OXP_COUNT * sizeof(float)));
+  if (!s->d_pd) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pd, OXP_COUNT * sizeof(double)));
+  MYTHOS_HIP_TRY(hipDeviceSynchronize());
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_pf, s->pf.v, OXP_COUNT * sizeof(float), hipMemcpyHostToDevice));
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd.v, OXP_COUNT * sizeof(double), hipMemcpyHostToDevice));
   s->params_set = true;
   return MYTHOS_OK;
 }

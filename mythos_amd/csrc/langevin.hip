@@ -187,13 +187,14 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
   return v.f;
 }
 
-// Diagnostic stamps (ablate bit 7): lane 0 of every wavefront records s_memtime at the phase boundaries
+// Diagnostic stamps (ablate bit 7): lane 0 of every wavefront records s_memtime (bit 8: the 100 MHz
+// s_memrealtime instead) at the phase boundaries
 // into the (otherwise unused) energy scratch; no output value depends on them.
 #define MD_STAMP(k)                                                                                   \
   do {                                                                                                \
     if ((ablate & 128) && (threadIdx.x & 63) == 0)                                                     \
-      reinterpret_cast<unsigned long long*>(e_part)[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
-          __builtin_readcyclecounter();                                                                \
+      reinterpret_cast<unsigned long long*>(e_part)[(((step & 1) * gridDim.x + (size_t)blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
+          (ablate & 256) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();           \
   } while (0)
 
 // One MD step (see file header).  kick_close: multiple of dt*F that closes the previous step
@@ -210,7 +211,7 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 //   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
 template <typename R, int MODEL, bool SAVE>
 __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
-    const OxParams<R> Pk, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
+    const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
     R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
@@ -219,13 +220,15 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   constexpr int G = kMdG, PPB = kMdPPB;
   constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
   constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
-  __shared__ unsigned short items[PPB][kMdMaxItems];
-  __shared__ int item_cnt[PPB];
-  __shared__ int max_cnt;
+  // three work lists per nucleotide (flagged row slots): 0 = H-bond, 1 = cross-stacking, 2 = coaxial
+  __shared__ unsigned short items[3][PPB][kMdMaxItems];
+  __shared__ int item_cnt[3][PPB];
+  __shared__ int item_pre[3][PPB + 1];
   __shared__ R self_lds[PPB][13];
+  __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
   __shared__ R res[PPB][kSlots][RW];
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
-  const OxParams<R>& P = Pk;  // SGPR-resident; an LDS copy was measured 2.4x slower in the angular pass
+  const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
   const int i = blockIdx.x * PPB + grp;
@@ -254,7 +257,6 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
       sl[6] = s2.x, sl[7] = s2.y, sl[8] = s2.z, sl[9] = s0.w;
     }
   }
-  if (threadIdx.x == 0) max_cnt = 0;
   const int* __restrict__ row = rows + (size_t)ii * row_stride;
   const int len = (valid && !(ablate & 1)) ? row_len[ii] : 0;
   const int close_end = min(len, row_close[ii]);  // [2, close_end): any term may act; [close_end, len): backbone only
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   const R eps_n = P[NEXC_EPS];
   const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
   const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
-  int n_items = 0;
+  int n_items[3] = {0, 0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
   // Software pipeline: the lane's row entries are fetched kEnt at a time, and the neighbour
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
         n0 = in.p0[jn];
         n3 = in.p3[jn];
       }
-      bool flag = false;
+      bool flag[3] = {false, false, false};
       if (entry >= 0) {
         const int j = entry & ROW_INDEX_MASK;
         const bool role_p = (entry & ROW_ROLE_Q) == 0;
@@ -360,24 +362,32 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
             axpy(d, g_ba, da);
             const R r2 = dot(d, d);
             en += f3_radial(eps_n, tw_n, f_base, d, r2, gba);
-            flag = hb_crst_support(P, m_sqrt(r2));
+            const R rb = m_sqrt(r2);
+            flag[1] = P[CRST_RCLOW] < rb && rb < P[CRST_RCHIGH];
+            if (P[HYDR_RCLOW] < rb && rb < P[HYDR_RCHIGH]) {  // H-bond only for pairs with a non-zero weight
+              const int so = (int)o0.w & 3;
+              flag[0] = weight_lookup(P, HYDR_EPS_00, role_p ? (self.seq * 4 + so) : (so * 4 + self.seq)) != R(0);
+            }
           }
           {
             V3<R> d = dco;
             axpy(d, g_st, da);
-            flag = flag || cxst_support(P, m_sqrt(dot(d, d)));
+            flag[2] = cxst_support(P, m_sqrt(dot(d, d)));
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
         }
       }
-      // append the flagged slots of this group to its LDS list, in slot order
-      const unsigned long long bal = __ballot(flag);
-      const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
-      if (flag) {
-        const int pos = n_items + __popc(gm & ((1u << lane) - 1u));
-        if (pos < kMdMaxItems) items[grp][pos] = (unsigned short)s;
+      // append the flagged slots of this group to its three LDS lists, in slot order
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned long long bal = __ballot(flag[t]);
+        const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
+        if (flag[t]) {
+          const int pos = n_items[t] + __popc(gm & ((1u << lane) - 1u));
+          if (pos < kMdMaxItems) items[t][grp][pos] = (unsigned short)s;
+        }
+        n_items[t] += __popc(gm);
       }
-      n_items += __popc(gm);
     }
   }
   // far segment: only the backbone-backbone terms (excluded volume + Debye-Hueckel) can act
@@ -430,15 +440,35 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
       }
     }
   }
-  if (n_items > kMdMaxItems) {
+  if (n_items[0] + n_items[1] + n_items[2] > kMdMaxItems) {  // result rows of one nucleotide exhausted
     if (lane == 0) atomicOr(flags, 4);
-    n_items = kMdMaxItems;
+    n_items[0] = n_items[1] = n_items[2] = 0;
+  }
+  // The radial sums are folded over the group now and parked in LDS: nothing computed so far stays in
+  // registers across the angular pass (whose pair functions need the whole register budget).
+  group_reduce_v3<G>(gbk);
+  group_reduce_v3<G>(gba);
+  if (lane == 0) {
+    R* rl = rad_lds[grp];
+    rl[0] = gbk.x, rl[1] = gbk.y, rl[2] = gbk.z, rl[3] = gba.x, rl[4] = gba.y, rl[5] = gba.z;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) item_cnt[t][grp] = valid ? n_items[t] : 0;
   }
   MD_STAMP(1);
-  __syncthreads();  // max_cnt = 0 and self_lds are visible
-  if (lane == 0) {
-    item_cnt[grp] = valid ? n_items : 0;
-    atomicMax(&max_cnt, valid ? n_items : 0);
+  __syncthreads();  // self_lds, rad_lds and item_cnt are visible
+  // exclusive prefix of the 32 per-nucleotide counts of each list (waves 0..2 take one list each), so every
+  // list is dense over the workgroup
+  if (threadIdx.x < 192) {
+    const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int c = (l < PPB) ? item_cnt[t][l] : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < PPB; o <<= 1) {
+      const int u = __shfl_up(inc, o, 64);
+      if (l >= o) inc += u;
+    }
+    if (l < PPB) item_pre[t][l + 1] = inc;
+    if (l == 0) item_pre[t][0] = 0;
   }
   __syncthreads();
   MD_STAMP(2);
@@ -449,24 +479,36 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   //      (H-bond, cross-stacking, coaxial stacking).  Results go to res[owner][slot] in LDS.
   {
     NoPG pg;
-    constexpr int kPerSweep = (kMdBlock - 64) / PPB;  // 6
-    const bool bonded_wave = threadIdx.x < 64;
-    const int n_sweeps = (max_cnt + kPerSweep - 1) / kPerSweep;
+    const int wave = threadIdx.x >> 6;  // 0: bonded, 1: H-bond list, 2: cross-stacking list, 3: coaxial list
+    const bool bonded_wave = wave == 0;
+    const int lst = bonded_wave ? 0 : wave - 1;
+    const int n_total = item_pre[lst][PPB];
+    const int n_sweeps = (n_total + 63) / 64;
     const int my_sweeps = bonded_wave ? ((ablate & 16) ? 0 : 1) : ((ablate & 8) ? 0 : n_sweeps);
     for (int sweep = 0; sweep < ((ablate & 2) ? 0 : my_sweeps); ++sweep) {
-      int p, idx;
+      int p, idx, sl;
+      bool active;
       if (bonded_wave) {
         p = threadIdx.x >> 1;
         idx = threadIdx.x & 1;
+        sl = idx;
+        active = true;
       } else {
-        const int u = threadIdx.x - 64;
-        p = u / kPerSweep;
-        idx = ROW_BONDED_SLOTS + sweep * kPerSweep + (u - p * kPerSweep);
+        const int q = sweep * 64 + (threadIdx.x & 63);
+        active = q < n_total;
+        int lo = 0, hi = PPB;  // owner: largest p with item_pre[lst][p] <= q
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (item_pre[lst][mid] <= q) lo = mid; else hi = mid;
+        }
+        p = lo;
+        const int k = q - item_pre[lst][lo];
+        sl = active ? (int)items[lst][p][k] : 0;
+        // result row: bonded 0..1, then the nucleotide's H-bond, cross-stacking and coaxial items
+        idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0) + (lst >= 2 ? item_cnt[1][p] : 0);
       }
       const int ip = blockIdx.x * PPB + p;
-      const bool active = ip < n && idx < ROW_BONDED_SLOTS + item_cnt[p];
-      if (!active) continue;
-      const int sl = bonded_wave ? idx : (int)items[p][idx - ROW_BONDED_SLOTS];
+      if (!active || ip >= n) continue;
       const int entry = rows[(size_t)ip * row_stride + sl];
       R* out_r = res[p][idx];
       SelfGrad<R> g;
@@ -495,10 +537,18 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
         o.seq = mo & 3;
         o.is_end = (mo >> 2) & 1;
         const V3<R> dco = min_image(o.c - me.c, box);
-        if (bonded_wave)
-          bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
-        else
-          unbonded_angular<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+#ifndef MD_DBG_SKIP
+#define MD_DBG_SKIP 0
+#endif
+        if (wave == 0) {
+          if (!(MD_DBG_SKIP & 1)) bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        } else if (wave == 1) {
+          if (!(MD_DBG_SKIP & 2)) unbonded_angular<R, MODEL, true, NoPG, 1>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        } else if (wave == 2) {
+          if (!(MD_DBG_SKIP & 4)) unbonded_angular<R, MODEL, true, NoPG, 2>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        } else {
+          if (!(MD_DBG_SKIP & 8)) unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        }
       }
       out_r[0] = g.dc.x, out_r[1] = g.dc.y, out_r[2] = g.dc.z;
       out_r[3] = g.g1.x, out_r[4] = g.g1.y, out_r[5] = g.g1.z;
@@ -519,7 +569,7 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
   if (valid) {
-    const int total = ROW_BONDED_SLOTS + n_items;
+    const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp] + item_cnt[2][grp];
     for (int t = lane; t < total; t += G) {
       const R* rr = res[grp][t];
       sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
@@ -532,12 +582,13 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
       }
     }
   }
-  {
-    const V3<R> gsum = gbk + gba;
-    sg.dc = sg.dc - gsum;
-    axpy(sg.g1, -g_k1, gbk);
-    axpy(sg.g1, -g_ba, gba);
-    axpy(sg.g2, -g_k2, gbk);
+  if (lane == 0) {  // radial-pass sums (already folded over the group)
+    const R* rl = rad_lds[grp];
+    const V3<R> rbk{rl[0], rl[1], rl[2]}, rba{rl[3], rl[4], rl[5]};
+    sg.dc = sg.dc - (rbk + rba);
+    axpy(sg.g1, -P[GEO_BACK_A1], rbk);
+    axpy(sg.g1, -P[GEO_BASE], rba);
+    if constexpr (MODEL == 2) axpy(sg.g2, -P[GEO_BACK_A2], rbk);
   }
   if constexpr (SAVE) {
     group_reduce<G, R, true>(e, sg);
@@ -569,6 +620,16 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   MD_STAMP(6);
   double ke_t = 0.0, ke_r = 0.0;
   if (lane == 0 && valid) {
+    Nuc<R> self;  // reloaded from LDS (shadows the copy of the radial pass on purpose)
+    {
+      const R* ms = self_lds[grp];
+      self.c = V3<R>{ms[0], ms[1], ms[2]};
+      self.a1 = V3<R>{ms[3], ms[4], ms[5]};
+      self.a3 = V3<R>{ms[6], ms[7], ms[8]};
+      self.a2 = cross(self.a3, self.a1);
+    }
+    const R g_k1 = P[GEO_BACK_A1];
+    const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
     const V3<R> F = -sg.dc;
     const V3<R> tl = axes_grad_to_torque(self, sg);
     const R tb[3] = {dot(self.a1, tl), dot(self.a2, tl), dot(self.a3, tl)};
@@ -804,6 +865,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   const int blocks = (n + kMdPPB - 1) / kMdPPB;
   const int tb = (n + 255) / 256;
   const OxParams<R>& P = params_of<R>(sys);
+  const R* Pdev = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
   const LangevinConst<R> K = make_const<R>(sim);
   const MdCut<R> cut = make_cut<R>(sys);
@@ -842,13 +904,13 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, P, box, K, cut, n,
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
@@ -878,7 +940,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   sim->last_samples = samples;
   if (ablate & 128) {  // diagnostic: dump the cycle stamps of the last launch
     if (const char* path = getenv("MYTHOS_MD_STAMPS")) {
-      std::vector<unsigned long long> h((size_t)blocks * 32);
+      std::vector<unsigned long long> h((size_t)blocks * 64);  // two launches: even step | odd step
       MYTHOS_HIP_TRY(hipMemcpy(h.data(), sim->d_epart, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       if (FILE* f = fopen(path, "wb")) {
         fwrite(h.data(), sizeof(unsigned long long), h.size(), f);
@@ -938,7 +1000,7 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
     for (int a = 0; a < 5; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
        hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
-       hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 32 * sizeof(double)) == hipSuccess &&
+       hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 64 * sizeof(double)) == hipSuccess &&
        hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
   for (int k = 0; ok && k < mythos_sim::kMaxSamples; ++k)
     ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;

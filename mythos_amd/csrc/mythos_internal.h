@@ -70,6 +70,8 @@ struct mythos_system {
   bool params_set = false;
   mythos::OxParams<float> pf;
   mythos::OxParams<double> pd;
+  float* d_pf = nullptr;   // the same vectors in device memory (read by the MD kernel as scalar loads)
+  double* d_pd = nullptr;
 
   // energy-pass scratch
   double* d_epart = nullptr;  // [frames_chunk][blocks][8]
@@ -97,6 +99,12 @@ template <>
 inline const OxParams<float>& params_of<float>(const mythos_system* s) { return s->pf; }
 template <>
 inline const OxParams<double>& params_of<double>(const mythos_system* s) { return s->pd; }
+template <typename R>
+const R* device_params_of(const mythos_system* s);
+template <>
+inline const float* device_params_of<float>(const mythos_system* s) { return s->d_pf; }
+template <>
+inline const double* device_params_of<double>(const mythos_system* s) { return s->d_pd; }
 
 // Largest centre-centre distance at which anything other than the backbone-backbone terms (excluded
 // volume between base / backbone sites, H-bond, cross- and coaxial stacking) can act.  Rows keep the

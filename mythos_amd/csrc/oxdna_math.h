@@ -41,6 +41,19 @@ struct LdsParams {
   __device__ __forceinline__ R operator[](int i) const { return p[i]; }
 };
 
+// The vector in device memory, read through the constant address space: every access with a
+// compile-time index is one s_load at the point of use (scalar cache), so no parameter has to stay live
+// in a register between uses.  (Passed by value in the kernel-argument segment, the compiler loads all
+// used entries in the entry block and then spills them - SGPR -> VGPR -> scratch - in a large kernel.)
+template <typename R>
+struct ConstParams {
+  static constexpr bool indexed = false;
+  typedef const R __attribute__((address_space(4))) * cptr;
+  cptr p;
+  __device__ __forceinline__ explicit ConstParams(const R* g) : p((cptr)g) {}
+  __device__ __forceinline__ R operator[](int i) const { return p[i]; }
+};
+
 template <typename R>
 __device__ __forceinline__ void stage_params(const OxParams<R>& P, R* lds, int tid, int nthreads) {
   for (int k = tid; k < OXP_COUNT; k += nthreads) lds[k] = P.v[k];

@@ -292,22 +292,26 @@ __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, co
 //      In self/other form the cosines are  a1s.n, -a1o.n, a3s.n, -a3o.n  for either role; the role
 //      decides which angle (and parameter block) each of them is.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MODEL, bool GRAD, class PG, class PT>
+// TERMS selects which terms are compiled in: 1 = H-bond, 2 = cross-stacking, 4 = coaxial stacking.  The MD
+// kernel instantiates the three separately so that each wavefront of its angular pass runs one term on a
+// homogeneous work list; the energy path uses all three (7).
+template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT>
 __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                  bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  (void)g_st;
   (void)g_k1;
   (void)g_k2;
-  {
+  if constexpr ((TERMS & 3) != 0) {
     const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
     const R r = m_sqrt(dot(d, d));
     V3<R> gd{R(0), R(0), R(0)};
     bool any = false;
     const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
     const R whb = weight_lookup(P, HYDR_EPS_00, wk);
-    const FD<R> F1 = (whb != R(0) || PG::on) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
-    const FD<R> F2 = f2_eval(r, P, CRST_RLOW);
+    const FD<R> F1 = ((TERMS & 1) && (whb != R(0) || PG::on)) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
+    const FD<R> F2 = (TERMS & 2) ? f2_eval(r, P, CRST_RLOW) : FD<R>{R(0), R(0)};
     const bool hb_on = (F1.f != R(0) || F1.d != R(0));
     const bool cr_on = (F2.f != R(0) || F2.d != R(0));
     if (hb_on || cr_on) {
@@ -434,7 +438,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
   }
   // ---- coaxial stacking on the stacking sites.  Reference: dr = stack_q - stack_p,
   //      theta5 = acos(a3p.n), theta6 = acos(-a3q.n); self/other cosines a3s.n and -a3o.n.
-  {
+  if constexpr ((TERMS & 4) != 0) {
     const V3<R> d = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
     const R r = m_sqrt(dot(d, d));
     const FD<R> F2 = f2_eval(r, P, CXST_RLOW);
