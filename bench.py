@@ -12,8 +12,13 @@ bracketed by barrier + synchronize; value = N_gpus * K / max-over-ranks time.  F
 replicas' observables (energy trace) are all-gathered over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line with the fields of the driver contract plus
-  roofline      HBM roofline of the step kernel (algorithmic bytes / HIP-event kernel time)
-  cpu_baseline  the CPU oracle (torch fp64 restatement, all host cores) timed on a bounded sample
+  roofline      HBM roofline of the step kernel: algorithmic bytes per launch (2 x 14 state
+                words + 13 B topology + 4 B per neighbour entry, per nucleotide) / the kernel's mean duration,
+                measured with HIP events on the launch stream inside the timed region.  ``traffic`` is the
+                PMC-measured HBM-side byte count per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)
+                of the SAME command, read from profiles/traffic.json when that file matches the workload.
+  cpu_baseline  the CPU oracle (torch fp64 restatement over the same Verlet list, all host cores) timed on a
+                bounded sample of the same system (N=1, rank 0 only)
 """
 
 from __future__ import annotations
@@ -63,12 +68,38 @@ def algorithmic_bytes_per_step(n: int, nbar: float, word: int) -> float:
     return n * (2 * 14 * word + 13 + 4.0 * nbar)
 
 
-def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray) -> dict:
-    """Time the CPU oracle (torch fp64, vectorised over the same Verlet pair list) on the host."""
+def measured_traffic(args, n: int):
+    """HBM-side bytes per md_step_kernel launch from the committed PMC passes of this command
+    (profiles/traffic.json, written by scripts/collect_traffic.py), or None if it is for another workload."""
+    f = ROOT / "profiles" / "traffic.json"
+    if not f.exists():
+        return None
+    t = json.loads(f.read_text())
+    if t.get("n_nucleotides") != n or t.get("dtype") != args.dtype:
+        return None
+    return t["hbm_bytes_per_launch"]
+
+
+def host_cores() -> int:
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box hands
+    a 1-GPU job a share of a much larger host; oversubscribing it makes the baseline meaningless)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("MYTHOS_BENCH_CPU_CORES", "16"))))
+
+
+def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray, budget_s: float = 20.0) -> dict:
+    """Time the CPU oracle (torch fp64, vectorised over the same Verlet pair list) on the host: up to
+    ``n_steps`` steps, stopping early once ``budget_s`` seconds are spent."""
     from oracle.langevin_oracle import LangevinOracle
     from tests import helpers as H
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
     P = H.oracle_params(2, half_charged_ends=True)
     tt = (
         torch.as_tensor(top.seq, dtype=torch.long),
@@ -80,7 +111,12 @@ def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray) -> dict:
     o = LangevinOracle(2, P, tt, None, sim["dt"], kT, kT / sim["diff_coef"], kT / sim["rot_diff_coef"], seed=0)
     x, q = c0.copy(), q0.copy()
     p, L = np.zeros_like(x), np.zeros_like(x)
-    o.run(x, q, p, L, 1)  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    o.run(x, q, p, L, 1)  # warm-up (thread pools, allocator); two force evaluations
+    est = 0.5 * (time.perf_counter() - t0)
+    n_steps = int(max(1, min(n_steps, budget_s / max(est, 1e-9))))
+    print(f"[bench] cpu baseline: {n_steps} steps, about {est * n_steps:.0f} s on {torch.get_num_threads()} threads",
+          file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     o.run(x, q, p, L, n_steps)
     dt = time.perf_counter() - t0
@@ -165,7 +201,7 @@ def main():
         kms = timing["kernel_ms"]
         achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         out = {
-            "metric": "MD steps/sec per GPU, oxDNA2 12 kbp duplex",
+            "metric": "MD steps/sec (and ns/day) per GPU, oxDNA2 12 kbp duplex",
             "value": steps_per_s,
             "unit": "steps/s",
             "n_gpus": world,
@@ -190,7 +226,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args, n),
                 "kernel": "md_step_kernel",
                 "kernel_ms": kms,
                 "loop_ms_per_launch": timing["loop_ms_per_launch"],
@@ -199,7 +235,7 @@ def main():
         }
         cpu_steps = args.cpu_steps
         if cpu_steps < 0:
-            cpu_steps = 3 if n > 8000 else 20
+            cpu_steps = 60 if n > 8000 else 400  # capped at about 20 s of host work
         if cpu_steps > 0 and world == 1:
             from mythos_amd.simulators.neighbors import verlet_pairs_numpy
 

@@ -193,7 +193,7 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 #define MD_STAMP(k)                                                                                   \
   do {                                                                                                \
     if ((ablate & 128) && (threadIdx.x & 63) == 0)                                                     \
-      reinterpret_cast<unsigned long long*>(e_part)[(((step & 1) * gridDim.x + (size_t)blockIdx.x) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
+      reinterpret_cast<unsigned long long*>(e_part)[(((step & 1) * n_blocks + (size_t)bid) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
           (ablate & 256) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();           \
   } while (0)
 
@@ -210,7 +210,7 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 //           lane; the list of flagged slots lives in LDS;
 //   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
 template <typename R, int MODEL, bool SAVE>
-__global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
+__global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
@@ -231,7 +231,13 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
-  const int i = blockIdx.x * PPB + grp;
+  // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, so workgroup b
+  // takes chunk (b % 8) * ceil(n_blocks / 8) + b / 8 - every XCD then owns one contiguous eighth of the
+  // nucleotide index range and neighbouring chunks (same strand, adjacent cells) share its L2.
+  const int n_blocks = (n + PPB - 1) / PPB;
+  const int bid = (int)(blockIdx.x & 7) * ((n_blocks + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (bid >= n_blocks) return;  // grid is padded to a multiple of 8; whole workgroup leaves together
+  const int i = bid * PPB + grp;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;  // out-of-range groups shadow the last nucleotide and discard
 
@@ -479,7 +485,9 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
   //      (H-bond, cross-stacking, coaxial stacking).  Results go to res[owner][slot] in LDS.
   {
     NoPG pg;
-    const int wave = threadIdx.x >> 6;  // 0: bonded, 1: H-bond list, 2: cross-stacking list, 3: coaxial list
+    // role of this wavefront: 0 bonded, 1 H-bond list, 2 cross-stacking list, 3 coaxial list; rotated with
+    // the workgroup index so the heavy and the light roles spread over the four SIMDs of a CU
+    const int wave = ((threadIdx.x >> 6) + bid) & 3;
     const bool bonded_wave = wave == 0;
     const int lst = bonded_wave ? 0 : wave - 1;
     const int n_total = item_pre[lst][PPB];
@@ -489,7 +497,7 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
       int p, idx, sl;
       bool active;
       if (bonded_wave) {
-        p = threadIdx.x >> 1;
+        p = (threadIdx.x & 63) >> 1;
         idx = threadIdx.x & 1;
         sl = idx;
         active = true;
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
         // result row: bonded 0..1, then the nucleotide's H-bond, cross-stacking and coaxial items
         idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0) + (lst >= 2 ? item_cnt[1][p] : 0);
       }
-      const int ip = blockIdx.x * PPB + p;
+      const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
       const int entry = rows[(size_t)ip * row_stride + sl];
       R* out_r = res[p][idx];
@@ -599,34 +607,42 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
     group_reduce_v3<G>(sg.g3);
   }
 
-  MD_STAMP(5);
-  // ---- thermostat noise for this (nucleotide, step): the two Philox blocks and the three
-  //      Box-Muller pairs are produced by lanes 0..2 of the group side by side, then handed to lane 0
-  R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
-  if (do_step && !(ablate & (4 | 32))) {
-    uint32_t c[4] = {(uint32_t)ii, uint32_t(step), uint32_t(step >> 32), (uint32_t)(lane & 1)};
-    philox4x32(c, uint32_t(seed), uint32_t(seed >> 32));
-    const bool hi = (lane == 2);
-    R za, zb;
-    box_muller(hi ? c[2] : c[0], hi ? c[3] : c[1], za, zb);
-    z[0] = za;
-    z[1] = zb;
-    z[2] = __shfl(za, 2, G);
-    z[3] = __shfl(zb, 2, G);
-    z[4] = __shfl(za, 1, G);
-    z[5] = __shfl(zb, 1, G);
+  // the folded gradient of every nucleotide goes back to LDS (row 0 of its own result block, which only
+  // this group has read) so that ONE wavefront integrates all 32 nucleotides of the workgroup, one per
+  // lane: the integrator is ~0.6 k instructions per lane whatever the lane count, and run by lane 0 of
+  // every group it occupied all four SIMDs at 1/8 lane use
+  if (lane == 0) {
+    R* fr = res[grp][0];
+    fr[0] = sg.dc.x, fr[1] = sg.dc.y, fr[2] = sg.dc.z;
+    fr[3] = sg.g1.x, fr[4] = sg.g1.y, fr[5] = sg.g1.z;
+    fr[6] = sg.g2.x, fr[7] = sg.g2.y, fr[8] = sg.g2.z;
+    fr[9] = sg.g3.x, fr[10] = sg.g3.y, fr[11] = sg.g3.z;
   }
-
+  MD_STAMP(5);
+  __syncthreads();
   MD_STAMP(6);
   double ke_t = 0.0, ke_r = 0.0;
-  if (lane == 0 && valid) {
-    Nuc<R> self;  // reloaded from LDS (shadows the copy of the radial pass on purpose)
+  const int int_wave = (bid >> 2) & 3;  // rotates over the SIMDs from workgroup to workgroup
+  const int il = threadIdx.x & 63;      // nucleotide of this lane in the integrating wave
+  const int i_int = bid * PPB + il;
+  if ((int)(threadIdx.x >> 6) == int_wave && il < PPB && i_int < n) {
+    const int i = i_int;
+    // ---- thermostat noise for this (nucleotide, step): two Philox blocks, three Box-Muller pairs
+    R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+    if (do_step && !(ablate & (4 | 32))) normals6(seed, (uint32_t)i, step, 0u, z);
+    Nuc<R> self;
+    SelfGrad<R> sg;
     {
-      const R* ms = self_lds[grp];
+      const R* ms = self_lds[il];
       self.c = V3<R>{ms[0], ms[1], ms[2]};
       self.a1 = V3<R>{ms[3], ms[4], ms[5]};
       self.a3 = V3<R>{ms[6], ms[7], ms[8]};
       self.a2 = cross(self.a3, self.a1);
+      const R* fr = res[il][0];
+      sg.dc = V3<R>{fr[0], fr[1], fr[2]};
+      sg.g1 = V3<R>{fr[3], fr[4], fr[5]};
+      sg.g2 = V3<R>{fr[6], fr[7], fr[8]};
+      sg.g3 = V3<R>{fr[9], fr[10], fr[11]};
     }
     const R g_k1 = P[GEO_BACK_A1];
     const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
@@ -690,28 +706,29 @@ __global__ __launch_bounds__(kMdBlock, 3) void md_step_kernel(
       if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
       quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
     }
-    const V4 s0 = in.p0[i];
-    out.p0[i] = V4{x[0], x[1], x[2], s0.w};
+    out.p0[i] = V4{x[0], x[1], x[2], self_lds[il][9]};
     out.p1[i] = V4{n1.x, n1.y, n1.z, R(0)};
     out.p2[i] = V4{n3.x, n3.y, n3.z, R(0)};
     out.p3[i] = V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)};
     out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
     mom[i] = V4{p[0], p[1], p[2], R(0)};
     ang[i] = V4{L[0], L[1], L[2], R(0)};
-    MD_STAMP(7);
   }
+  MD_STAMP(7);
   if constexpr (SAVE) {
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < T_COUNT; ++k) e_lds[grp][k] = valid ? double(e[k]) : 0.0;
-      e_lds[grp][T_COUNT] = ke_t;
-      e_lds[grp][T_COUNT + 1] = ke_r;
+    }
+    if ((int)(threadIdx.x >> 6) == int_wave && il < PPB) {
+      e_lds[il][T_COUNT] = ke_t;
+      e_lds[il][T_COUNT + 1] = ke_r;
     }
     __syncthreads();
     if (threadIdx.x < kTraceWidth) {
       double s = 0.0;
       for (int g = 0; g < PPB; ++g) s += e_lds[g][threadIdx.x];
-      e_part[(size_t)blockIdx.x * kTraceWidth + threadIdx.x] = s;
+      e_part[(size_t)bid * kTraceWidth + threadIdx.x] = s;
     }
   }
 }
@@ -863,6 +880,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   mythos_system* sys = sim->sys;
   const int n = sys->n;
   const int blocks = (n + kMdPPB - 1) / kMdPPB;
+  const int grid = 8 * ((blocks + 7) / 8);  // padded for the kernel's XCD-aware workgroup order
   const int tb = (n + 255) / 256;
   const OxParams<R>& P = params_of<R>(sys);
   const R* Pdev = device_params_of<R>(sys);
@@ -904,13 +922,13 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
     if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(blocks), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(blocks), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
+      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
