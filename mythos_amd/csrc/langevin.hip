@@ -160,6 +160,9 @@ template <typename R>
 struct MdCut {
   R rbb2;    // backbone-backbone: max(Debye r_cut, excluded-volume r_c)^2
   R rcom2;   // centre-centre distance below which the base / stack site terms can act
+  // squared supports of the angular terms' radial factors (base-base for H-bond and cross-stacking,
+  // stack-stack for coaxial stacking): the radial pass flags a neighbour without taking a square root
+  R hb_lo2, hb_hi2, cr_lo2, cr_hi2, cx_lo2, cx_hi2;
 };
 
 template <typename R>
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
   // kernel has to stay inside the instruction cache that two CUs share)
   {
     int e_cur = -1, e_nxt = -1;
-    V4 n0{}, n3{};
+    V4 n0{}, n3{}, n1{};
     {
       const int s = ROW_BONDED_SLOTS + lane;
       e_cur = (s < close_end) ? row[s] : -1;
@@ -298,29 +301,28 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
         const int j = e_cur & ROW_INDEX_MASK;
         n0 = in.p0[j];
         n3 = in.p3[j];
+        n1 = in.p1[j];
       }
     }
 #pragma unroll 1
     for (int s0 = ROW_BONDED_SLOTS; s0 < close_end; s0 += G) {
       const int s = s0 + lane;
       const int entry = e_cur;
-      const V4 o0 = n0, o3 = n3;
+      const V4 o0 = n0, o3 = n3, o1 = n1;
       e_cur = e_nxt;
       e_nxt = (s + 2 * G < close_end) ? row[s + 2 * G] : -1;
-      if (e_cur >= 0) {
+      if (e_cur >= 0) {  // the close segment reads a1 as well: nearly all of its entries need it
         const int jn = e_cur & ROW_INDEX_MASK;
         n0 = in.p0[jn];
         n3 = in.p3[jn];
+        n1 = in.p1[jn];
       }
       bool flag[3] = {false, false, false};
       if (entry >= 0) {
-        const int j = entry & ROW_INDEX_MASK;
         const bool role_p = (entry & ROW_ROLE_Q) == 0;
         const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
         const V3<R> offb_o = xyz<R>(o3);
         const bool close = dot(dco, dco) < cut.rcom2;
-        V4 o1{};
-        if (close) o1 = in.p1[j];  // requested before the backbone arithmetic below
         // backbone - backbone: excluded volume + Debye-Hueckel
         {
           const V3<R> d = dco + offb_o - offb_s;
@@ -368,9 +370,8 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
             axpy(d, g_ba, da);
             const R r2 = dot(d, d);
             en += f3_radial(eps_n, tw_n, f_base, d, r2, gba);
-            const R rb = m_sqrt(r2);
-            flag[1] = P[CRST_RCLOW] < rb && rb < P[CRST_RCHIGH];
-            if (P[HYDR_RCLOW] < rb && rb < P[HYDR_RCHIGH]) {  // H-bond only for pairs with a non-zero weight
+            flag[1] = cut.cr_lo2 < r2 && r2 < cut.cr_hi2;
+            if (cut.hb_lo2 < r2 && r2 < cut.hb_hi2) {  // H-bond only for pairs with a non-zero weight
               const int so = (int)o0.w & 3;
               flag[0] = weight_lookup(P, HYDR_EPS_00, role_p ? (self.seq * 4 + so) : (so * 4 + self.seq)) != R(0);
             }
@@ -378,7 +379,8 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
           {
             V3<R> d = dco;
             axpy(d, g_st, da);
-            flag[2] = cxst_support(P, m_sqrt(dot(d, d)));
+            const R r2 = dot(d, d);
+            flag[2] = cut.cx_lo2 < r2 && r2 < cut.cx_hi2;
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
         }
@@ -863,6 +865,10 @@ static MdCut<R> make_cut(const mythos_system* sys) {
   MdCut<R> c;
   c.rbb2 = R(rbb * rbb);
   c.rcom2 = R(rcom * rcom);
+  auto sq = [](double v) { return R(v * v); };
+  c.hb_lo2 = sq(P[HYDR_RCLOW]), c.hb_hi2 = sq(P[HYDR_RCHIGH]);
+  c.cr_lo2 = sq(P[CRST_RCLOW]), c.cr_hi2 = sq(P[CRST_RCHIGH]);
+  c.cx_lo2 = sq(P[CXST_RCLOW]), c.cx_hi2 = sq(P[CXST_RCHIGH]);
   return c;
 }
 
