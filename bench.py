@@ -198,6 +198,8 @@ def main():
     if rank == 0:
         steps_per_s = world * args.steps / elapsed
         alg = algorithmic_bytes_per_step(n, nbar, word)
+        # mean duration of the step kernel from HIP events attached to sampled dispatches on the launch
+        # stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
         kms = timing["kernel_ms"]
         achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         out = {

@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "oxdna_gather.h"
 
 namespace mythos {
@@ -229,7 +231,11 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
   __shared__ int item_pre[3][PPB + 1];
   __shared__ R self_lds[PPB][13];
   __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
-  __shared__ R res[PPB][kSlots][RW];
+  // result rows, [nucleotide][slot][RW] with the nucleotide stride padded to an odd word count: the 32
+  // nucleotides' rows then start in 32 different banks (20 x 13 = 260 words would alias p and p + 8)
+  constexpr int kResStride = (kSlots * RW) | 1;
+  __shared__ R res_flat[PPB * kResStride];
+  auto res_row = [&](int pp, int slot) -> R* { return res_flat + pp * kResStride + slot * RW; };
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
   const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
@@ -244,8 +250,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;  // out-of-range groups shadow the last nucleotide and discard
 
-  const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK];
 
   // ---- owner state (also parked in LDS for the block-wide angular pass)
   Nuc<R> self;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
       const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
       const int entry = rows[(size_t)ip * row_stride + sl];
-      R* out_r = res[p][idx];
+      R* out_r = res_row(p, idx);
       SelfGrad<R> g;
       g.dc = g.g1 = g.g2 = g.g3 = V3<R>{R(0), R(0), R(0)};
       R ee[T_COUNT];
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
   if (valid) {
     const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp] + item_cnt[2][grp];
     for (int t = lane; t < total; t += G) {
-      const R* rr = res[grp][t];
+      const R* rr = res_row(grp, t);
       sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
       sg.g1 = sg.g1 + V3<R>{rr[3], rr[4], rr[5]};
       sg.g2 = sg.g2 + V3<R>{rr[6], rr[7], rr[8]};
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
   // lane: the integrator is ~0.6 k instructions per lane whatever the lane count, and run by lane 0 of
   // every group it occupied all four SIMDs at 1/8 lane use
   if (lane == 0) {
-    R* fr = res[grp][0];
+    R* fr = res_row(grp, 0);
     fr[0] = sg.dc.x, fr[1] = sg.dc.y, fr[2] = sg.dc.z;
     fr[3] = sg.g1.x, fr[4] = sg.g1.y, fr[5] = sg.g1.z;
     fr[6] = sg.g2.x, fr[7] = sg.g2.y, fr[8] = sg.g2.z;
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
       self.a1 = V3<R>{ms[3], ms[4], ms[5]};
       self.a3 = V3<R>{ms[6], ms[7], ms[8]};
       self.a2 = cross(self.a3, self.a1);
-      const R* fr = res[il][0];
+      const R* fr = res_row(il, 0);
       sg.dc = V3<R>{fr[0], fr[1], fr[2]};
       sg.g1 = V3<R>{fr[3], fr[4], fr[5]};
       sg.g2 = V3<R>{fr[6], fr[7], fr[8]};
@@ -926,19 +931,25 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     R* tq = (save && traj_quat) ? traj_quat + (size_t)sidx * n * 4 : nullptr;
     const V4* ref = (const V4*)sys->d_ref_pos;
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
-    if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sa[samples], st));
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
+    } else if (sampled) {
+      // the event pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
+      // kernel trace reports), not the time between two markers in the queue
+      hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
+                            sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
+                            sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close, do_step,
+                            sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
+      ++samples;
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
-    if (sampled) MYTHOS_HIP_TRY(hipEventRecord(sim->sb[samples++], st));
     ++launches;
     cur ^= 1;
   }
