@@ -214,8 +214,15 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 //           flagged ones (H-bond, cross-stacking, coaxial stacking) are evaluated densely, one per
 //           lane; the list of flagged slots lives in LDS;
 //   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
+// workgroups per CU the register allocator is asked to make room for: what the LDS footprint of the
+// variant allows (fp32 stepping 40 KB; the trace and fp64 variants carry wider result rows)
+template <typename R, bool SAVE>
+constexpr int md_blocks_per_cu() {
+  return sizeof(R) == 4 ? (SAVE ? 2 : 4) : (SAVE ? 1 : 2);
+}
+
 template <typename R, int MODEL, bool SAVE>
-__global__ __launch_bounds__(kMdBlock, 4) void md_step_kernel(
+__global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_step_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
