@@ -59,6 +59,9 @@ def parse_args():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="CPU-baseline sample size in steps (-1: auto, 0: skip)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
+                         "between ranks); the printed line is then marked as a rehearsal, not a measurement")
     return ap.parse_args()
 
 
@@ -140,13 +143,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        from mythos_amd import distributed as md
+
+        md.init("gloo" if args.rehearse_on_one_gpu else "nccl")  # "nccl" is RCCL on ROCm
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     word = 4 if args.dtype == "f32" else 8
@@ -179,14 +185,17 @@ def main():
     _, _, et = integ.run(c, q, p, L, args.steps, save_every=args.save_every)
     gathered = None
     if dist is not None:
+        # per-replica observables (energy trace, or one row of zeros without --save-every), replica id =
+        # rank: one all-gather over RCCL / xGMI - the only collective, the MD data path has none
         obs = et if et is not None else torch.zeros((1, 10), dtype=torch.float64, device=dev)
-        gathered = [torch.empty_like(obs) for _ in range(world)]
-        dist.all_gather(gathered, obs)  # RCCL over xGMI: per-replica observables
+        obs = obs.reshape(1, -1)
+        gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs)
+        assert gathered.shape[0] == world
     torch.cuda.synchronize(dev)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -219,6 +228,7 @@ def main():
                 "workload": f"oxDNA2 {args.bp} bp ideal B-duplex ({n} nt), Debye-Hueckel salt 0.5, half-charged ends, "
                 f"Langevin dt {sim['dt']}, kT {kT:.6f}, free space, 1 replica per GPU",
                 "replicas": world,
+                **({"rehearsal": "all ranks on cuda:0 over gloo - not a measurement"} if args.rehearse_on_one_gpu else {}),
                 "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": nbar, "max_row": mx},
                 "ns_per_day": steps_per_s / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
             },
