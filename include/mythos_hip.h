@@ -165,6 +165,18 @@ void mythos_martini_destroy(mythos_martini_t* m);
 int mythos_martini_energy(mythos_martini_t* m, const void* pos, const void* box, int n_frames, double* e_terms,
                           void* dU_dpos, mythos_stream_t stream);
 
+/* Parameter gradients per frame (the reference: jax.grad of the same energy functions with respect to the
+ * configuration values, mythos/energy/martini/m2/lj.py:137-157, bond.py:60-71, angle.py:113-129).
+ * All outputs are dev double and optional (NULL = skip), except that d_sigma and d_eps come as a pair:
+ *   d_sigma, d_eps   [n_frames][n_types][n_types]  dU_lj/dsigma[a][b], dU_lj/deps[a][b] for the ORDERED type
+ *                    pair (owner, partner), each unordered bead pair contributing half to either order: the
+ *                    derivative with respect to a symmetric entry is out[a][b] + out[b][a]
+ *   d_bond_k/_r0     [n_frames][n_bonds]     d_angle_k/_t0  [n_frames][n_angles]   (one value per bond / angle;
+ *                    the host sums the bonds that share a named parameter) */
+int mythos_martini_param_grads(mythos_martini_t* m, const void* pos, const void* box, int n_frames, double* d_sigma,
+                               double* d_eps, double* d_bond_k, double* d_bond_r0, double* d_angle_k,
+                               double* d_angle_t0, mythos_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,6 +70,7 @@ def load() -> C.CDLL:
         ),
         "mythos_martini_destroy": (None, [V]),
         "mythos_martini_energy": (C.c_int, [V, V, V, C.c_int, V, V, V]),
+        "mythos_martini_param_grads": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V, V, V]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch: fail loudly
@@ -103,6 +104,7 @@ DECLARED_SYMBOLS = (
     "mythos_martini_create",
     "mythos_martini_destroy",
     "mythos_martini_energy",
+    "mythos_martini_param_grads",
 )
 
 

@@ -222,6 +222,148 @@ __global__ __launch_bounds__(256) void martini_bonded_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Parameter gradients (the reference obtains them by jax.grad through the same functions).
+// LJ: dU/dsigma[a][b] and dU/deps[a][b] per frame for the ORDERED type pair (type of the owner, type of the
+// partner); every pair is visited from both ends with weight 1/2, so the derivative with respect to a
+// symmetric table entry is out[a][b] + out[b][a] - which is what differentiating through the host's
+// symmetric table construction yields.  Workgroup tables in LDS (fp64 atomics), then one fp64 atomic per
+// touched entry into the frame's table.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ __launch_bounds__(kLjBlock) void martini_lj_pgrad_kernel(
+    int n, const R* __restrict__ pos, const R* __restrict__ box, const int* __restrict__ types,
+    const R* __restrict__ sigma, const R* __restrict__ eps, const int* __restrict__ excl, MartiniConst<R> K,
+    int n_tiles, double* __restrict__ d_sigma, double* __restrict__ d_eps) {
+  extern __shared__ unsigned char smem_raw[];
+  double* s_ds = reinterpret_cast<double*>(smem_raw);
+  double* s_de = s_ds + K.n_types * K.n_types;
+  R* s_sig = reinterpret_cast<R*>(s_de + K.n_types * K.n_types);
+  R* s_eps = s_sig + K.n_types * K.n_types;
+  R* s_x = s_eps + K.n_types * K.n_types;
+  R* s_y = s_x + kLjBlock;
+  R* s_z = s_y + kLjBlock;
+  int* s_t = reinterpret_cast<int*>(s_z + kLjBlock);
+
+  const int frame = blockIdx.z;
+  const int js = blockIdx.y, n_js = gridDim.y;
+  const int i = blockIdx.x * kLjBlock + threadIdx.x;
+  const R* __restrict__ p = pos + (size_t)frame * n * 3;
+  const R lx = box[frame * 3], ly = box[frame * 3 + 1], lz = box[frame * 3 + 2];
+  const R ilx = R(1) / lx, ily = R(1) / ly, ilz = R(1) / lz;
+  const int tt = K.n_types * K.n_types;
+  const R irc2 = R(1) / K.rc2;
+  for (int k = threadIdx.x; k < tt; k += kLjBlock) {
+    s_sig[k] = sigma[k];
+    s_eps[k] = eps[k];
+    s_ds[k] = 0.0;
+    s_de[k] = 0.0;
+  }
+  R xi = 0, yi = 0, zi = 0;
+  int ti = 0;
+  int ex[kMaxExcl];
+#pragma unroll
+  for (int k = 0; k < kMaxExcl; ++k) ex[k] = -1;
+  if (i < n) {
+    xi = p[3 * i], yi = p[3 * i + 1], zi = p[3 * i + 2];
+    ti = types[i] * K.n_types;
+#pragma unroll
+    for (int k = 0; k < kMaxExcl; ++k) ex[k] = excl[(size_t)i * kMaxExcl + k];
+  }
+  for (int tile = js; tile < n_tiles; tile += n_js) {
+    __syncthreads();
+    const int j0 = tile * kLjBlock, jl = j0 + threadIdx.x;
+    if (jl < n) {
+      s_x[threadIdx.x] = p[3 * jl], s_y[threadIdx.x] = p[3 * jl + 1], s_z[threadIdx.x] = p[3 * jl + 2];
+      s_t[threadIdx.x] = types[jl];
+    }
+    __syncthreads();
+    const int cnt = min(kLjBlock, n - j0);
+    if (i < n) {
+      for (int k = 0; k < cnt; ++k) {
+        const R dx = wrap(xi - s_x[k], lx, ilx), dy = wrap(yi - s_y[k], ly, ily), dz = wrap(zi - s_z[k], lz, ilz);
+        const R r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 < K.rc2) {
+          const int j = j0 + k;
+          bool skip = (j == i);
+#pragma unroll
+          for (int q = 0; q < kMaxExcl; ++q) skip = skip || (ex[q] == j);
+          if (!skip) {
+            const int tp = ti + s_t[k];
+            const R sg = s_sig[tp], ep = s_eps[tp];
+            const R ir2 = R(1) / r2;
+            const R s2 = sg * sg * ir2, s6 = s2 * s2 * s2, s12 = s6 * s6;
+            const R c2 = sg * sg * irc2, c6 = c2 * c2 * c2, c12 = c6 * c6;
+            // V = 4 eps [(s12 - s6) - (c12 - c6)];  dV/dsigma = 4 eps [12 s12 - 6 s6 - 12 c12 + 6 c6] / sigma
+            atomicAdd(&s_de[tp], 0.5 * double(R(4) * ((s12 - s6) - (c12 - c6))));
+            atomicAdd(&s_ds[tp], 0.5 * double(R(4) * ep * (R(12) * (s12 - c12) - R(6) * (s6 - c6)) / sg));
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < tt; k += kLjBlock) {
+    if (s_ds[k] != 0.0) atomicAdd(&d_sigma[(size_t)frame * tt + k], s_ds[k]);
+    if (s_de[k] != 0.0) atomicAdd(&d_eps[(size_t)frame * tt + k], s_de[k]);
+  }
+}
+
+// one thread per bond / per angle: dE/dk and dE/dr0 (dE/dtheta0), E as in martini_bonded_kernel
+template <typename R>
+__global__ void martini_bonded_pgrad_kernel(int n, const R* __restrict__ pos, const R* __restrict__ box, int n_bonds,
+                                            const int* __restrict__ bonds, const R* __restrict__ bond_k,
+                                            const R* __restrict__ bond_r0, int n_angles,
+                                            const int* __restrict__ angles, const R* __restrict__ angle_k,
+                                            const R* __restrict__ angle_t0, int angle_kind,
+                                            double* __restrict__ d_bk, double* __restrict__ d_br,
+                                            double* __restrict__ d_ak, double* __restrict__ d_at) {
+  const int frame = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const R* __restrict__ p = pos + (size_t)frame * n * 3;
+  const R l[3] = {box[frame * 3], box[frame * 3 + 1], box[frame * 3 + 2]};
+  const R il[3] = {R(1) / l[0], R(1) / l[1], R(1) / l[2]};
+  if (t < n_bonds) {
+    const int i = bonds[2 * t], o = bonds[2 * t + 1];
+    R r2 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const R d = wrap(p[3 * i + k] - p[3 * o + k], l[k], il[k]);
+      r2 += d * d;
+    }
+    const double x = double(m_sqrt(r2)) - double(bond_r0[t]);
+    if (d_bk) d_bk[(size_t)frame * n_bonds + t] = 0.5 * x * x;
+    if (d_br) d_br[(size_t)frame * n_bonds + t] = -double(bond_k[t]) * x;
+  }
+  if (t < n_angles) {
+    const int bi = angles[3 * t], bj = angles[3 * t + 1], bk = angles[3 * t + 2];
+    R u[3], v[3], u2 = 0, v2 = 0, uv = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u[k] = wrap(p[3 * bi + k] - p[3 * bj + k], l[k], il[k]);
+      v[k] = wrap(p[3 * bk + k] - p[3 * bj + k], l[k], il[k]);
+      u2 += u[k] * u[k], v2 += v[k] * v[k], uv += u[k] * v[k];
+    }
+    const R iu = R(1) / m_sqrt(u2), iv = R(1) / m_sqrt(v2);
+    const R c = uv * iu * iv;
+    const double k0 = double(angle_k[t]), t0 = double(angle_t0[t]);
+    double dk, dt0;
+    if (angle_kind == 0) {
+      const double x = double(c) - cos(t0);
+      dk = 0.5 * x * x;
+      dt0 = k0 * x * sin(t0);  // d/dtheta0 of 1/2 k (cos theta - cos theta0)^2
+    } else {
+      R cr[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+      const R sn = m_sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]) * iu * iv;
+      const double x = atan2(double(sn), double(c)) - t0;
+      dk = 0.5 * x * x;
+      dt0 = -k0 * x;
+    }
+    if (d_ak) d_ak[(size_t)frame * n_angles + t] = dk;
+    if (d_at) d_at[(size_t)frame * n_angles + t] = dt0;
+  }
+}
+
 template <typename R>
 __global__ void martini_reduce_kernel(int n, int n_slots, const R* __restrict__ f_part, R* __restrict__ dU,
                                       const double* __restrict__ e_part, int n_e, const double* __restrict__ eb_part,
@@ -326,6 +468,49 @@ static int martini_energy_typed(mythos_martini* m, const R* pos, const R* box, i
   return 0;
 }
 
+template <typename R>
+static int martini_pgrad_typed(mythos_martini* m, const R* pos, const R* box, int n_frames, double* d_sigma,
+                               double* d_eps, double* d_bk, double* d_br, double* d_ak, double* d_at, hipStream_t st) {
+  const int n = m->n;
+  const int nbx = (n + kLjBlock - 1) / kLjBlock;
+  const size_t tt = (size_t)m->n_types * m->n_types;
+  MartiniConst<R> K{R(m->r_cut * m->r_cut), m->n_types, m->angle_kind};
+  if (d_sigma || d_eps) {
+    // both tables are produced together; a caller that wants one still passes scratch for the other
+    if (!d_sigma || !d_eps) {
+      set_error("mythos_martini_param_grads: d_sigma and d_eps come as a pair");
+      return MYTHOS_ERR_INVALID_ARGUMENT;
+    }
+    MYTHOS_HIP_TRY(hipMemsetAsync(d_sigma, 0, (size_t)n_frames * tt * sizeof(double), st));
+    MYTHOS_HIP_TRY(hipMemsetAsync(d_eps, 0, (size_t)n_frames * tt * sizeof(double), st));
+    const size_t lds = 2 * tt * sizeof(double) + 2 * tt * sizeof(R) + 3 * kLjBlock * sizeof(R) + kLjBlock * sizeof(int);
+    MYTHOS_HIP_TRY(hipFuncSetAttribute((const void*)martini_lj_pgrad_kernel<R>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int n_js = std::min(nbx, std::max(1, 768 / std::max(1, nbx)));
+    for (int f0 = 0; f0 < n_frames; f0 += 4096) {
+      const int nf = std::min(n_frames - f0, 4096);
+      hipLaunchKernelGGL(martini_lj_pgrad_kernel<R>, dim3(nbx, nf > 16 ? std::max(1, n_js / 4) : n_js, nf),
+                         dim3(kLjBlock), lds, st, n, pos + (size_t)f0 * n * 3, box + (size_t)f0 * 3, m->d_types,
+                         (const R*)m->d_sigma, (const R*)m->d_eps, m->d_excl, K, nbx, d_sigma + (size_t)f0 * tt,
+                         d_eps + (size_t)f0 * tt);
+    }
+  }
+  if (d_bk || d_br || d_ak || d_at) {
+    const int cnt = std::max(m->n_bonds, m->n_angles);
+    for (int f0 = 0; cnt > 0 && f0 < n_frames; f0 += 4096) {
+      const int nf = std::min(n_frames - f0, 4096);
+      auto off = [&](double* ptr, int per) { return ptr ? ptr + (size_t)f0 * per : nullptr; };
+      hipLaunchKernelGGL(martini_bonded_pgrad_kernel<R>, dim3((cnt + 255) / 256, nf), dim3(256), 0, st, n,
+                         pos + (size_t)f0 * n * 3, box + (size_t)f0 * 3, m->n_bonds, m->d_bonds,
+                         (const R*)m->d_bond_k, (const R*)m->d_bond_r0, m->n_angles, m->d_angles,
+                         (const R*)m->d_angle_k, (const R*)m->d_angle_t0, m->angle_kind, off(d_bk, m->n_bonds),
+                         off(d_br, m->n_bonds), off(d_ak, m->n_angles), off(d_at, m->n_angles));
+    }
+  }
+  MYTHOS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // namespace mythos
 
 extern "C" {
@@ -422,6 +607,22 @@ int mythos_martini_energy(mythos_martini_t* m, const void* pos, const void* box,
                                        (hipStream_t)stream);
   return martini_energy_typed<double>(m, (const double*)pos, (const double*)box, n_frames, e_terms, (double*)dU_dpos,
                                       (hipStream_t)stream);
+}
+
+int mythos_martini_param_grads(mythos_martini_t* m, const void* pos, const void* box, int n_frames, double* d_sigma,
+                               double* d_eps, double* d_bond_k, double* d_bond_r0, double* d_angle_k,
+                               double* d_angle_t0, mythos_stream_t stream) {
+  if (!m || !pos || !box || n_frames < 0) {
+    set_error("mythos_martini_param_grads: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (n_frames == 0) return MYTHOS_OK;
+  MYTHOS_HIP_TRY(hipSetDevice(m->device));
+  if (m->dtype == MYTHOS_F32)
+    return martini_pgrad_typed<float>(m, (const float*)pos, (const float*)box, n_frames, d_sigma, d_eps, d_bond_k,
+                                      d_bond_r0, d_angle_k, d_angle_t0, (hipStream_t)stream);
+  return martini_pgrad_typed<double>(m, (const double*)pos, (const double*)box, n_frames, d_sigma, d_eps, d_bond_k,
+                                     d_bond_r0, d_angle_k, d_angle_t0, (hipStream_t)stream);
 }
 
 }  // extern "C"

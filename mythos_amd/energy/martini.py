@@ -6,8 +6,11 @@ of mythos_amd/csrc/martini.hip.
     lj = LJ.from_topology(topology=top, params=LJConfiguration(**lj_params))
     energies = lj.map(trajectory)            # trajectory.center (S, M, 3) nm, trajectory.box_size (S, 3)
 
-Energies are differentiable with respect to the positions through ``torch.autograd`` (the kernel
-returns dU/dpos); parameter gradients of the MARTINI terms are not wired yet ("next").
+Energies are differentiable through ``torch.autograd`` with respect to the positions (the kernel
+returns dU/dpos) and with respect to every configuration value given as a torch tensor that requires
+grad - the analogue of ``jax.grad`` over ``with_params`` in the reference: the kernel returns
+dU/dsigma, dU/deps per type pair and dU/dk, dU/dr0 (dU/dtheta0) per bond (angle), and autograd carries
+them through the table construction (symmetric type tables, named bonds, couplings).
 """
 
 from __future__ import annotations
@@ -84,14 +87,19 @@ class LJConfiguration(MartiniEnergyConfiguration):
             bead_types.update(p.split("_")[2:4])
         self.bead_types = tuple(sorted(bead_types))
 
-        def get(prefix, a, b):
+        self.sigmas = self.table("sigma").detach().numpy()
+        self.epsilons = self.table("epsilon").detach().numpy()
+
+    def table(self, prefix: str) -> torch.Tensor:
+        """(T, T) float64 table of ``lj_<prefix>_A_B`` values; differentiable where a value is a tensor."""
+
+        def get(a, b):
             v = self.params.get(f"lj_{prefix}_{a}_{b}", self.params.get(f"lj_{prefix}_{b}_{a}"))
             if v is None:
                 raise ValueError(f"Missing LJ {prefix} parameter for pair {a}_{b} ({b}_{a})")
-            return float(v)
+            return _as_scalar(v)
 
-        self.sigmas = np.array([[get("sigma", i, j) for j in self.bead_types] for i in self.bead_types])
-        self.epsilons = np.array([[get("epsilon", i, j) for j in self.bead_types] for i in self.bead_types])
+        return torch.stack([torch.stack([get(i, j) for j in self.bead_types]) for i in self.bead_types])
 
 
 class BondConfiguration(MartiniEnergyConfiguration):
@@ -116,20 +124,55 @@ class AngleConfiguration(MartiniEnergyConfiguration):
             raise ValueError("AngleConfiguration requires pairs of k and theta0 parameters")
 
 
+def _as_scalar(v) -> torch.Tensor:
+    """A configuration value as a 0-dim float64 CPU tensor (keeps the autograd graph of a tensor value)."""
+    if isinstance(v, torch.Tensor):
+        return v.to(device="cpu", dtype=torch.float64).reshape(())
+    return torch.tensor(float(v), dtype=torch.float64)
+
+
+def _num(v) -> float:
+    return float(v.detach()) if isinstance(v, torch.Tensor) else float(v)
+
+
+_THETA_KEYS = ("sigma", "eps", "bond_k", "bond_r0", "angle_k", "angle_t0")
+
+
 class _MartiniOp(torch.autograd.Function):
+    """column of the kernel's [lj, bond, angle] energies; ``theta`` = the six parameter arrays (CPU float64),
+    only used to route gradients: the system already holds their values."""
+
     @staticmethod
-    def forward(ctx, pos, box, system, column):
-        e, g = system.energy(pos.detach(), box, grads=pos.requires_grad)
+    def forward(ctx, pos, box, system, column, *theta):
+        want_pos = pos.requires_grad
+        e, g = system.energy(pos.detach(), box, grads=want_pos)
         ctx.single = pos.dim() == 2
-        if pos.requires_grad:
-            ctx.save_for_backward(g)
+        ctx.want_pos = want_pos
+        need = [t is not None and t.requires_grad for t in theta]
+        ctx.need = need
+        pg = None
+        if any(need):
+            pg = system.param_grads(pos.detach(), box, lj=need[0] or need[1], bonds=need[2] or need[3],
+                                    angles=need[4] or need[5])
+        ctx.pg = pg
+        ctx.save_for_backward(*([g] if want_pos else []))
         return e[..., column]
 
     @staticmethod
     def backward(ctx, g_out):
-        (g,) = ctx.saved_tensors
-        scale = g_out.to(g.dtype)
-        return g * (scale if ctx.single else scale[:, None, None]), None, None, None
+        gpos = None
+        if ctx.want_pos:
+            (g,) = ctx.saved_tensors
+            scale = g_out.to(g.dtype)
+            gpos = g * (scale if ctx.single else scale[:, None, None])
+        gtheta = [None] * 6
+        if ctx.pg is not None:
+            w = g_out.reshape(-1).to(torch.float64)  # one weight per frame
+            for k, key in enumerate(_THETA_KEYS):
+                if ctx.need[k]:
+                    pgk = ctx.pg[key]
+                    gtheta[k] = (w.reshape(-1, *([1] * (pgk.dim() - 1))) * pgk).sum(0).cpu()
+        return (gpos, None, None, None, *gtheta)
 
 
 class MartiniEnergyFunction:
@@ -198,11 +241,18 @@ class MartiniEnergyFunction:
         nb, na = len(self.bonded_neighbors), len(self.angles)
         return (np.zeros(n, np.int32), np.ones((1, 1)), np.zeros((1, 1)), np.zeros(nb), np.ones(nb), np.zeros(na), np.zeros(na))
 
+    def _theta(self) -> tuple:
+        """The six parameter arrays as CPU float64 tensors, in ``_THETA_KEYS`` order; the ones this term owns
+        are built from ``self.params`` so gradients flow back to tensor-valued configuration entries."""
+        _, sg, ep, bk, br, ak, at = self._tables()
+        return tuple(torch.as_tensor(np.asarray(a, dtype=np.float64)) for a in (sg, ep, bk, br, ak, at))
+
     def _get_system(self, device):
         from mythos_amd.hip_system import MartiniSystem
 
         if self._system is None or self._system.device != device:
-            t, sg, ep, bk, br, ak, at = self._tables()
+            t = self._tables()[0]
+            sg, ep, bk, br, ak, at = (x.detach().numpy() for x in self._theta())
             self._system = MartiniSystem(t, sg, ep, self.bonded_neighbors, bk, br, self.angles, ak, at,
                                          angle_kind=self.angle_kind, dtype=self.dtype, device=device)
         return self._system
@@ -216,7 +266,7 @@ class MartiniEnergyFunction:
         if trajectory.box_size is None:
             raise ValueError("MARTINI energy functions need trajectory.box_size")
         system = self._get_system(pos.device)
-        return _MartiniOp.apply(pos.to(self.dtype), trajectory.box_size, system, self.column)
+        return _MartiniOp.apply(pos.to(self.dtype), trajectory.box_size, system, self.column, *self._theta())
 
     __call__ = compute_energy
 
@@ -236,6 +286,10 @@ class LJ(MartiniEnergyFunction):
         types = np.array([idx[a] for a in self.atom_types], dtype=np.int32)
         return types, self.params.sigmas, self.params.epsilons, bk, br, ak, at
 
+    def _theta(self):
+        base = super()._theta()
+        return (self.params.table("sigma"), self.params.table("epsilon"), *base[2:])
+
 
 class Bond(MartiniEnergyFunction):
     """Harmonic bonds 1/2 k (r - r0)^2 (m2/bond.py:44-71)."""
@@ -244,9 +298,15 @@ class Bond(MartiniEnergyFunction):
 
     def _tables(self):
         t, sg, ep, _, _, ak, at = super()._tables()
-        k = np.array([float(self.params[BOND_K_PREFIX + n]) for n in self.bond_names])
-        r0 = np.array([float(self.params[BOND_R0_PREFIX + n]) for n in self.bond_names])
+        k = np.array([_num(self.params[BOND_K_PREFIX + n]) for n in self.bond_names])
+        r0 = np.array([_num(self.params[BOND_R0_PREFIX + n]) for n in self.bond_names])
         return t, sg, ep, k, r0, ak, at
+
+    def _theta(self):
+        base = super()._theta()
+        k = torch.stack([_as_scalar(self.params[BOND_K_PREFIX + n]) for n in self.bond_names])
+        r0 = torch.stack([_as_scalar(self.params[BOND_R0_PREFIX + n]) for n in self.bond_names])
+        return (*base[:2], k, r0, *base[4:])
 
 
 class Angle(MartiniEnergyFunction):
@@ -258,9 +318,15 @@ class Angle(MartiniEnergyFunction):
 
     def _tables(self):
         t, sg, ep, bk, br, _, _ = super()._tables()
-        k = np.array([float(self.params[ANGLE_K_PREFIX + n]) for n in self.angle_names])
-        t0 = np.array([float(self.params[ANGLE_THETA0_PREFIX + n]) for n in self.angle_names])
+        k = np.array([_num(self.params[ANGLE_K_PREFIX + n]) for n in self.angle_names])
+        t0 = np.array([_num(self.params[ANGLE_THETA0_PREFIX + n]) for n in self.angle_names])
         return t, sg, ep, bk, br, k, t0
+
+    def _theta(self):
+        base = super()._theta()
+        k = torch.stack([_as_scalar(self.params[ANGLE_K_PREFIX + n]) for n in self.angle_names])
+        t0 = torch.stack([_as_scalar(self.params[ANGLE_THETA0_PREFIX + n]) for n in self.angle_names])
+        return (*base[:4], k, t0)
 
 
 class Angle3(Angle):

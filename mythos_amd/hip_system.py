@@ -254,6 +254,7 @@ class MartiniSystem:
         n_types = int(sigma.shape[0])
         bonds = np.ascontiguousarray(bonds, dtype=np.int32).reshape(-1, 2)
         angles = np.ascontiguousarray(angles, dtype=np.int32).reshape(-1, 3)
+        self.n_types, self.n_bonds, self.n_angles = n_types, int(bonds.shape[0]), int(angles.shape[0])
         f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
         bond_k, bond_r0, angle_k, angle_t0 = f(bond_k), f(bond_r0), f(angle_k), f(angle_t0)
         dp = lambda a: a.ctypes.data_as(_lib.c_double_p)  # noqa: E731
@@ -298,3 +299,32 @@ class MartiniSystem:
             "martini_energy",
         )
         return (e[0], g[0] if grads else None) if single else (e, g)
+
+    def param_grads(self, pos: torch.Tensor, box: torch.Tensor, lj: bool = True, bonds: bool = True, angles: bool = True):
+        """Per-frame parameter gradients (float64, on the device): dict with ``sigma``/``eps`` (F, T, T) for the
+        ordered type pair, ``bond_k``/``bond_r0`` (F, n_bonds), ``angle_k``/``angle_t0`` (F, n_angles)."""
+        if pos.dim() == 2:
+            pos, box = pos[None], torch.as_tensor(box).reshape(1, 3)
+        if pos.device != self.device or pos.dtype != self.dtype or tuple(pos.shape[1:]) != (self.n, 3):
+            raise ValueError(f"pos must be a {self.dtype} tensor of shape (F, {self.n}, 3) on {self.device}")
+        pos = pos.contiguous()
+        box = torch.as_tensor(box, dtype=self.dtype, device=self.device).reshape(-1, 3)
+        if box.shape[0] == 1 and pos.shape[0] > 1:
+            box = box.expand(pos.shape[0], 3)
+        box = box.contiguous()
+        nf = pos.shape[0]
+
+        def buf(on, *shape):
+            return torch.zeros((nf, *shape), dtype=torch.float64, device=self.device) if on else None
+
+        out = {"sigma": buf(lj, self.n_types, self.n_types), "eps": buf(lj, self.n_types, self.n_types),
+               "bond_k": buf(bonds, self.n_bonds), "bond_r0": buf(bonds, self.n_bonds),
+               "angle_k": buf(angles, self.n_angles), "angle_t0": buf(angles, self.n_angles)}
+        _lib.check(
+            self._lib.mythos_martini_param_grads(
+                self._h, _lib.ptr(pos), _lib.ptr(box), nf, _lib.ptr(out["sigma"]), _lib.ptr(out["eps"]),
+                _lib.ptr(out["bond_k"]), _lib.ptr(out["bond_r0"]), _lib.ptr(out["angle_k"]), _lib.ptr(out["angle_t0"]),
+                _stream(self.device)),
+            "martini_param_grads",
+        )
+        return out
