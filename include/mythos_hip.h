@@ -32,6 +32,7 @@ extern "C" {
 typedef struct mythos_system mythos_system_t;   /* one oxDNA system: topology + parameters + neighbours */
 typedef struct mythos_sim mythos_sim_t;         /* Langevin integrator state bound to a system */
 typedef struct mythos_martini mythos_martini_t; /* one MARTINI system */
+typedef struct mythos_martini_sim mythos_martini_sim_t; /* Langevin integrator state bound to a MARTINI system */
 typedef void* mythos_stream_t;                  /* hipStream_t */
 
 enum mythos_status {
@@ -176,6 +177,26 @@ int mythos_martini_energy(mythos_martini_t* m, const void* pos, const void* box,
 int mythos_martini_param_grads(mythos_martini_t* m, const void* pos, const void* box, int n_frames, double* d_sigma,
                                double* d_eps, double* d_bond_k, double* d_bond_r0, double* d_angle_k,
                                double* d_angle_t0, mythos_stream_t stream);
+
+/* ---- MARTINI Langevin MD ----------------------------------------------------------------------
+ * BASELINE configs[2].  The reference runs MARTINI dynamics in GROMACS as an external process
+ * (mythos/simulators/gromacs/) and has no integrator of its own for it; this is the device-resident
+ * integrator for the same force field (LJ over a Verlet list rebuilt on the device, bonds, angles) with the
+ * BAOAB Langevin splitting of mythos_langevin_run for point particles.  Units: nm, ps, amu, kJ/mol.
+ *   gamma    friction rate 1/ps (GROMACS sd integrator: 1 / tau_t);  mass host double[n] or NULL (72 amu)
+ *   pos, vel dev real[n][3], updated in place;  box host double[3] (orthorhombic, fixed during the run)
+ *   traj_pos dev real[n_steps/save_every][n][3] or NULL;  e_trace dev double[.][4] = lj, bond, angle, kinetic
+ * Errors as mythos_langevin_run (OVERFLOW: row capacity or skin violated, NUMERIC: NaN). */
+mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, double dt, double kT, double gamma,
+                                                     const double* mass, uint64_t seed);
+void mythos_martini_langevin_destroy(mythos_martini_sim_t* sim);
+int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* sim, double skin, int rebuild_every);
+int mythos_martini_langevin_init_velocities(mythos_martini_sim_t* sim, void* vel, mythos_stream_t stream);
+int mythos_martini_langevin_run(mythos_martini_sim_t* sim, void* pos, void* vel, const double* box, int n_steps,
+                                int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream);
+int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* sim, double* kernel_ms,
+                                           double* loop_ms_per_launch, int* launches, int* samples);
+int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* sim, int* max_row, double* mean_row);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,736 @@
+// Langevin MD of a MARTINI system: one fused kernel per time step (BASELINE configs[2]).
+//
+// The reference has no MARTINI integrator of its own - it drives GROMACS as an external process
+// (mythos/simulators/gromacs/) and only re-evaluates energies (mythos/energy/martini/m2/*.py).  This file
+// is the device-resident counterpart for the same force field: shifted-cut-off Lennard-Jones over a Verlet
+// list, harmonic bonds, G96 / harmonic angles, and the BAOAB Langevin splitting used for oxDNA
+// (langevin.hip) specialised to point particles:
+//   B  v += h F / m      A  x += h v      O  v = c1 v + sqrt(kT (1 - c1^2) / m) xi,  c1 = exp(-gamma dt)
+// Units are GROMACS': nm, ps, amu, kJ/mol (1 kJ/mol = 1 amu nm^2 / ps^2), kT = 0.0083144626 T.
+//
+// Work decomposition (as md_step_kernel): 8 lanes per bead, 32 beads per 256-thread workgroup; the lanes stride
+// over the bead's neighbour row (partners inside r_c + skin, bonded partners already excluded), then over the
+// bead's bonds and angles; DPP fold; one wavefront integrates the workgroup's 32 beads.  The kernel that
+// evaluates F(x_k) closes step k-1 and opens step k; frames ping-pong.  No atomics in the force path.
+// Roofline: as for oxDNA the state is cache resident; algorithmic bytes per bead per step =
+// 2 x (pos 3 + vel 3) words + 4 B type + 4 B x nbar.
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include <hip/hip_ext.h>
+
+#include "cell_list.h"
+#include "martini_internal.h"
+#include "philox.h"
+#include "wave_ops.h"
+
+namespace mythos {
+
+constexpr int kMmBlock = 256;
+constexpr int kMmG = 8;
+constexpr int kMmPPB = kMmBlock / kMmG;
+constexpr int kMmTrace = 4;  // lj, bond, angle, kinetic
+
+template <typename R>
+struct Real4;
+template <>
+struct Real4<float> {
+  using type = float4;
+};
+template <>
+struct Real4<double> {
+  using type = double4;
+};
+
+template <typename R>
+struct MmConst {
+  R lx, ly, lz, ilx, ily, ilz;
+  R rc2;
+  R dt, half_dt, c1, kT;
+  R skin_half_sq;  // (skin/2)^2, <= 0 disables the displacement check
+  int n_types, angle_kind;
+};
+
+template <typename R, bool SAVE>
+__global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
+    int n, const MmConst<R> K, const typename Real4<R>::type* __restrict__ in, typename Real4<R>::type* __restrict__ out,
+    typename Real4<R>::type* __restrict__ vel, const int* __restrict__ rows, const int* __restrict__ row_len,
+    int row_stride, const R* __restrict__ sigma, const R* __restrict__ eps, const int* __restrict__ bead_bonds,
+    const int* __restrict__ bead_angles, const int* __restrict__ bonds, const R* __restrict__ bond_k,
+    const R* __restrict__ bond_r0, const int* __restrict__ angles, const R* __restrict__ angle_k,
+    const R* __restrict__ angle_t0, R kick_close, int do_step, uint64_t seed, uint64_t step,
+    const typename Real4<R>::type* __restrict__ ref_pos, int* __restrict__ flags, R* __restrict__ traj,
+    double* __restrict__ e_part) {
+  using V4 = typename Real4<R>::type;
+  constexpr int G = kMmG, PPB = kMmPPB;
+  extern __shared__ unsigned char smem_raw[];
+  R* s_sig2 = reinterpret_cast<R*>(smem_raw);
+  R* s_eps = s_sig2 + K.n_types * K.n_types;
+  __shared__ R s_f[PPB][4];
+  __shared__ double s_e[SAVE ? PPB : 1][kMmTrace];
+
+  const int n_blocks = (n + PPB - 1) / PPB;
+  const int bid = (int)(blockIdx.x & 7) * ((n_blocks + 7) >> 3) + (int)(blockIdx.x >> 3);  // XCD-aware order
+  if (bid >= n_blocks) return;
+  const int grp = threadIdx.x / G, lane = threadIdx.x % G;
+  const int i = bid * PPB + grp;
+  const bool valid = i < n;
+  const int ii = valid ? i : n - 1;
+
+  const int tt = K.n_types * K.n_types;
+  for (int k = threadIdx.x; k < tt; k += kMmBlock) {
+    const R sg = sigma[k];
+    s_sig2[k] = sg * sg;
+    s_eps[k] = eps[k];
+  }
+  const V4 me = in[ii];
+  const int type_i = (int)me.w * K.n_types;  // the bead type travels as an integer-valued real in .w
+  const int* __restrict__ row = rows + (size_t)ii * row_stride;
+  const int len = valid ? row_len[ii] : 0;
+  __syncthreads();
+
+  R gx = 0, gy = 0, gz = 0;  // dU/dx_i
+  R e_lj = 0, e_b = 0, e_a = 0;
+  const R irc2 = R(1) / K.rc2;
+  // ---- Lennard-Jones over the row, neighbour state prefetched one iteration ahead
+  {
+    int j_cur = (lane < len) ? row[lane] : -1;
+    int j_nxt = (lane + G < len) ? row[lane + G] : -1;
+    V4 nb{};
+    if (j_cur >= 0) nb = in[j_cur];
+#pragma unroll 1
+    for (int s0 = 0; s0 < len; s0 += G) {
+      const int j = j_cur;
+      const V4 o = nb;
+      j_cur = j_nxt;
+      j_nxt = (s0 + lane + 2 * G < len) ? row[s0 + lane + 2 * G] : -1;
+      if (j_cur >= 0) nb = in[j_cur];
+      if (j >= 0) {
+        const R dx = wrap(me.x - o.x, K.lx, K.ilx), dy = wrap(me.y - o.y, K.ly, K.ily), dz = wrap(me.z - o.z, K.lz, K.ilz);
+        const R r2 = dx * dx + dy * dy + dz * dz;
+        if (r2 < K.rc2) {
+          const int tp = type_i + (int)o.w;
+          const R ir2 = R(1) / r2;
+          const R s2 = s_sig2[tp] * ir2, s6 = s2 * s2 * s2, s12 = s6 * s6;
+          const R ep = s_eps[tp];
+          const R g = R(-24) * ep * (R(2) * s12 - s6) * ir2;  // (dV/dr) / r
+          gx += g * dx, gy += g * dy, gz += g * dz;
+          if constexpr (SAVE) {
+            const R c2 = s_sig2[tp] * irc2, c6 = c2 * c2 * c2;
+            e_lj += R(0.5) * R(4) * ep * ((s12 - s6) - (c6 * c6 - c6));
+          }
+        }
+      }
+    }
+  }
+  // ---- bonds and angles of this bead (incidence lists, one entry per lane)
+  if (valid) {
+    for (int s = lane; s < kMaxBeadBonds; s += G) {
+      const int ent = bead_bonds[(size_t)i * kMaxBeadBonds + s];
+      if (ent < 0) continue;
+      const int b = ent >> 1, side = ent & 1;
+      const V4 o = in[bonds[2 * b + (1 - side)]];
+      const R dx = wrap(me.x - o.x, K.lx, K.ilx), dy = wrap(me.y - o.y, K.ly, K.ily), dz = wrap(me.z - o.z, K.lz, K.ilz);
+      const R r = m_sqrt(dx * dx + dy * dy + dz * dz), x = r - bond_r0[b];
+      const R c = bond_k[b] * x / r;
+      gx += c * dx, gy += c * dy, gz += c * dz;
+      if constexpr (SAVE)
+        if (side == 0) e_b += R(0.5) * bond_k[b] * x * x;
+    }
+    for (int s = lane; s < kMaxBeadAngles; s += G) {
+      const int ent = bead_angles[(size_t)i * kMaxBeadAngles + s];
+      if (ent < 0) continue;
+      const int a = ent >> 2, role = ent & 3;  // 0: first bead, 1: centre, 2: last bead
+      const V4 pi = in[angles[3 * a]], pj = in[angles[3 * a + 1]], pk = in[angles[3 * a + 2]];
+      const R u[3] = {wrap(pi.x - pj.x, K.lx, K.ilx), wrap(pi.y - pj.y, K.ly, K.ily), wrap(pi.z - pj.z, K.lz, K.ilz)};
+      const R v[3] = {wrap(pk.x - pj.x, K.lx, K.ilx), wrap(pk.y - pj.y, K.ly, K.ily), wrap(pk.z - pj.z, K.lz, K.ilz)};
+      const R u2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+      const R uv = u[0] * v[0] + u[1] * v[1] + u[2] * v[2];
+      const R iu = R(1) / m_sqrt(u2), iv = R(1) / m_sqrt(v2);
+      const R c = uv * iu * iv;
+      R dEdc, en;
+      if (K.angle_kind == 0) {
+        R c0;
+        if constexpr (sizeof(R) == 4) c0 = cosf(angle_t0[a]); else c0 = cos(angle_t0[a]);
+        const R x = c - c0;
+        dEdc = angle_k[a] * x;
+        en = R(0.5) * angle_k[a] * x * x;
+      } else {
+        const R cr[3] = {u[1] * v[2] - u[2] * v[1], u[2] * v[0] - u[0] * v[2], u[0] * v[1] - u[1] * v[0]};
+        const R sn = m_sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]) * iu * iv;
+        R th;
+        if constexpr (sizeof(R) == 4) th = atan2f(sn, c); else th = atan2(sn, c);
+        const R x = th - angle_t0[a];
+        dEdc = (sn > R(1e-6)) ? -angle_k[a] * x / sn : angle_k[a];
+        en = R(0.5) * angle_k[a] * x * x;
+      }
+      if constexpr (SAVE)
+        if (role == 0) e_a += en;
+      R gk[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const R du = (v[k] * iv - c * u[k] * iu) * iu, dv = (u[k] * iu - c * v[k] * iv) * iv;
+        gk[k] = (role == 0) ? du : ((role == 2) ? dv : -(du + dv));
+      }
+      gx += dEdc * gk[0], gy += dEdc * gk[1], gz += dEdc * gk[2];
+    }
+  }
+  gx = group_sum<G>(gx);
+  gy = group_sum<G>(gy);
+  gz = group_sum<G>(gz);
+  if constexpr (SAVE) {
+    e_lj = group_sum<G>(e_lj);
+    e_b = group_sum<G>(e_b);
+    e_a = group_sum<G>(e_a);
+  }
+  if (lane == 0) {
+    s_f[grp][0] = gx, s_f[grp][1] = gy, s_f[grp][2] = gz;
+    if constexpr (SAVE) {
+      s_e[grp][0] = valid ? double(e_lj) : 0.0;
+      s_e[grp][1] = valid ? double(e_b) : 0.0;
+      s_e[grp][2] = valid ? double(e_a) : 0.0;
+      s_e[grp][3] = 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- one wavefront integrates the 32 beads of the workgroup, one per lane
+  const int int_wave = (bid >> 2) & 3;
+  const int il = threadIdx.x & 63;
+  const int ib = bid * PPB + il;
+  if ((int)(threadIdx.x >> 6) == int_wave && il < PPB && ib < n) {
+    const V4 x0 = in[ib];
+    V4 vv = vel[ib];
+    const R im = vv.w;  // inverse mass
+    const R F[3] = {-s_f[il][0], -s_f[il][1], -s_f[il][2]};
+    R x[3] = {x0.x, x0.y, x0.z}, v[3] = {vv.x, vv.y, vv.z};
+    const R kc = kick_close * K.dt * im;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += kc * F[k];
+    if constexpr (SAVE) {
+      s_e[il][3] = 0.5 * (double(v[0]) * v[0] + double(v[1]) * v[1] + double(v[2]) * v[2]) / double(im);
+      if (traj) traj[3 * (size_t)ib] = x[0], traj[3 * (size_t)ib + 1] = x[1], traj[3 * (size_t)ib + 2] = x[2];
+    }
+    if (do_step) {
+      R z[6];
+      normals6(seed, (uint32_t)ib, step, 0u, z);
+      const R hk = K.half_dt * im;
+      const R c2 = m_sqrt(K.kT * im * (R(1) - K.c1 * K.c1));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        v[k] += hk * F[k];
+        x[k] += K.half_dt * v[k];
+        v[k] = K.c1 * v[k] + c2 * z[k];
+        x[k] += K.half_dt * v[k];
+      }
+      if (K.skin_half_sq > R(0)) {
+        const V4 r0 = ref_pos[ib];
+        const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
+        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags, 1);
+      }
+      if (!(x[0] == x[0]) || !(v[0] == v[0])) atomicOr(flags, 2);
+    }
+    out[ib] = V4{x[0], x[1], x[2], x0.w};
+    vel[ib] = V4{v[0], v[1], v[2], im};
+  }
+  if constexpr (SAVE) {
+    __syncthreads();
+    if (threadIdx.x < kMmTrace) {
+      double s = 0.0;
+      for (int g = 0; g < PPB; ++g) s += s_e[g][threadIdx.x];
+      e_part[(size_t)bid * kMmTrace + threadIdx.x] = s;
+    }
+  }
+}
+
+__global__ void mm_reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k >= kMmTrace || !out) return;
+  double s = 0.0;
+  for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * kMmTrace + k];
+  out[k] = s;
+}
+
+template <typename R>
+__global__ void mm_pack_kernel(int n, const R* __restrict__ pos, const R* __restrict__ v, const int* __restrict__ types,
+                               const R* __restrict__ inv_mass, typename Real4<R>::type* __restrict__ frame,
+                               typename Real4<R>::type* __restrict__ vel) {
+  using V4 = typename Real4<R>::type;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  frame[i] = V4{pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], R(types[i])};
+  vel[i] = V4{v[3 * i], v[3 * i + 1], v[3 * i + 2], inv_mass[i]};
+}
+
+template <typename R>
+__global__ void mm_unpack_kernel(int n, const typename Real4<R>::type* __restrict__ frame,
+                                 const typename Real4<R>::type* __restrict__ vel, R* __restrict__ pos, R* __restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  pos[3 * i] = frame[i].x, pos[3 * i + 1] = frame[i].y, pos[3 * i + 2] = frame[i].z;
+  v[3 * i] = vel[i].x, v[3 * i + 1] = vel[i].y, v[3 * i + 2] = vel[i].z;
+}
+
+// Maxwell-Boltzmann velocities with the centre-of-mass momentum removed (single workgroup, runs once)
+template <typename R>
+__global__ void mm_init_velocities_kernel(int n, R kT, const R* __restrict__ inv_mass, uint64_t seed, R* __restrict__ v) {
+  __shared__ double sum[4][256];
+  double s0 = 0, s1 = 0, s2 = 0, sm = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    R z[6];
+    normals6(seed, (uint32_t)i, 0xFFFFFFFFFFFFFFFFull, 7u, z);
+    const R sd = m_sqrt(kT * inv_mass[i]);
+    v[3 * i] = sd * z[0], v[3 * i + 1] = sd * z[1], v[3 * i + 2] = sd * z[2];
+    const double m = 1.0 / double(inv_mass[i]);
+    s0 += m * v[3 * i], s1 += m * v[3 * i + 1], s2 += m * v[3 * i + 2], sm += m;
+  }
+  sum[0][threadIdx.x] = s0, sum[1][threadIdx.x] = s1, sum[2][threadIdx.x] = s2, sum[3][threadIdx.x] = sm;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) sum[k][threadIdx.x] += sum[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  const R c0 = R(sum[0][0] / sum[3][0]), c1 = R(sum[1][0] / sum[3][0]), c2 = R(sum[2][0] / sum[3][0]);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) v[3 * i] -= c0, v[3 * i + 1] -= c1, v[3 * i + 2] -= c2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Verlet rows for point particles in a periodic orthorhombic box.  One wavefront per bead; candidates come
+// from the 27 surrounding cells of the hashed cell list (cell_list.h) or, for boxes under three cells per edge
+// and tiny systems, from a sweep over all beads.  Directly bonded partners are left out (the reference masks
+// them, mythos/energy/martini/m2/lj.py:137-157).  Rows are in ascending (cell, index) order: reproducible.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ bool mm_excluded(const int* __restrict__ ex, int j) {
+  bool hit = false;
+#pragma unroll
+  for (int q = 0; q < kMaxExcl; ++q) hit = hit || (ex[q] == j);
+  return hit;
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
+    int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, const CellGrid<R> g, R rl2,
+    const int* __restrict__ excl, const int* __restrict__ start, const int* __restrict__ bucket, int* __restrict__ rows,
+    int* __restrict__ row_len, int row_stride, int* __restrict__ overflow) {
+  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= n) return;
+  const auto pi = pos[i];
+  int cx, cy, cz;
+  cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
+  int cnt = 0;
+  if (lane < 27) {
+    int c[3] = {cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[k] = (c[k] + g.nc[k]) % g.nc[k];
+    const int h = cell_hash(c[0], c[1], c[2], g.hmask);
+    const int st = start[h];
+    cnt = start[h + 1] - st;
+    s_st[w][lane] = st;
+    s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
+  }
+  int inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 32; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane < 27) s_pre[w][lane + 1] = inc;
+  if (lane == 0) s_pre[w][0] = 0;
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = __shfl(inc, 26, 64);
+  int ex[kMaxExcl];
+#pragma unroll
+  for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
+  int* row = rows + (size_t)i * row_stride;
+  int out = 0;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int t = t0 + lane;
+    bool hit = false;
+    int j = -1;
+    if (t < total) {
+      int lo = 0, hi = 27;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_pre[w][mid] <= t) lo = mid; else hi = mid;
+      }
+      j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
+      if (j != i && !mm_excluded<R>(ex, j)) {
+        const auto pj = pos[j];
+        int jx, jy, jz;
+        cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
+        // a bucket may mix cells that collide in the hash, and with fewer than 3 distinct cells along an edge
+        // the same cell would be visited twice: accept a candidate only for the first lane that names its cell
+        bool mine = (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]);
+        if (mine) {
+          const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
+          hit = dx * dx + dy * dy + dz * dz < rl2;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int slot = out + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < row_stride) row[slot] = j;
+    }
+    out += __popcll(m);
+  }
+  if (lane == 0) {
+    if (out > row_stride) {
+      atomicMax(overflow, out);
+      out = row_stride;
+    }
+    row_len[i] = out;
+  }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void mm_build_rows_allpairs_kernel(
+    int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, R rl2, const int* __restrict__ excl,
+    int* __restrict__ rows, int* __restrict__ row_len, int row_stride, int* __restrict__ overflow) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + w;
+  if (i >= n) return;
+  const auto pi = pos[i];
+  int ex[kMaxExcl];
+#pragma unroll
+  for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
+  int* row = rows + (size_t)i * row_stride;
+  int out = 0;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < n && j != i && !mm_excluded<R>(ex, j)) {
+      const auto pj = pos[j];
+      const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
+      hit = dx * dx + dy * dy + dz * dz < rl2;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (hit) {
+      const int slot = out + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < row_stride) row[slot] = j;
+    }
+    out += __popcll(m);
+  }
+  if (lane == 0) {
+    if (out > row_stride) {
+      atomicMax(overflow, out);
+      out = row_stride;
+    }
+    row_len[i] = out;
+  }
+}
+
+}  // namespace mythos
+
+using namespace mythos;
+
+struct mythos_martini_sim {
+  mythos_martini* sys = nullptr;
+  double dt = 0.02, kT = 2.27, gamma = 1.0;
+  uint64_t seed = 0;
+  long long step = 0;
+  double skin = 0.2;
+  int rebuild_every = 10;
+  void* frame[2] = {nullptr, nullptr};
+  void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
+  int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
+  size_t cell_cap = 0;
+  int row_stride = 160;
+  double* d_epart = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  static constexpr int kMaxSamples = 64;
+  hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
+  double last_kernel_ms = 0, last_avg_ms = 0;
+  int last_launches = 0, last_samples = 0, last_max_row = 0;
+};
+
+namespace mythos {
+
+template <typename R>
+static bool upload_real_vec(void** dst, const std::vector<double>& src) {
+  std::vector<R> tmp(src.size());
+  for (size_t k = 0; k < src.size(); ++k) tmp[k] = R(src[k]);
+  return hipMalloc(dst, std::max<size_t>(tmp.size(), 1) * sizeof(R)) == hipSuccess &&
+         hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(R), hipMemcpyHostToDevice) == hipSuccess;
+}
+
+template <typename R>
+static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* pos, const MmConst<R>& K, const double box[3],
+                      hipStream_t st) {
+  mythos_martini* m = sim->sys;
+  const int n = m->n;
+  const double rl = m->r_cut + sim->skin;
+  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, sizeof(int), st));
+  CellGrid<R> g;
+  bool cells_ok = n >= 512;
+  for (int k = 0; k < 3; ++k) {
+    const int nc = (int)std::floor(box[k] / rl);
+    if (nc < 3) cells_ok = false;
+    g.nc[k] = std::max(nc, 1);
+    g.ibox[k] = R(1.0 / box[k]);
+    g.inv[k] = R(g.nc[k] / box[k]);
+  }
+  const int wb = (n + 3) / 4;
+  if (!cells_ok) {
+    hipLaunchKernelGGL(mm_build_rows_allpairs_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, R(rl * rl), m->d_excl,
+                       sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow);
+  } else {
+    const int H = next_pow2(2 * n);
+    const size_t need = CellScratch::ints(H, n);
+    if (need > sim->cell_cap) {
+      if (sim->d_cell) (void)hipFree(sim->d_cell);
+      sim->d_cell = nullptr;
+      sim->cell_cap = 0;
+      MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_cell, need * sizeof(int)));
+      sim->cell_cap = need;
+    }
+    const CellScratch cs(sim->d_cell, H, n);
+    if (cell_list_build<R, true>(n, reinterpret_cast<const R*>(pos), g, H, cs, st) != 0) {
+      set_error("martini neighbour build: cell-list scratch memset failed");
+      return MYTHOS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(mm_build_rows_cells_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl,
+                       cs.start, cs.bucket, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow);
+  }
+  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->ref_pos, pos, (size_t)n * sizeof(typename Real4<R>::type), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+template <typename R>
+static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[3], int n_steps, int save_every,
+                        R* traj_pos, double* e_trace, hipStream_t st) {
+  using V4 = typename Real4<R>::type;
+  mythos_martini* m = sim->sys;
+  const int n = m->n;
+  const int blocks = (n + kMmPPB - 1) / kMmPPB, grid = 8 * ((blocks + 7) / 8);
+  const int tb = (n + 255) / 256;
+  MmConst<R> K;
+  K.lx = R(box[0]), K.ly = R(box[1]), K.lz = R(box[2]);
+  K.ilx = R(1.0 / box[0]), K.ily = R(1.0 / box[1]), K.ilz = R(1.0 / box[2]);
+  K.rc2 = R(m->r_cut * m->r_cut);
+  K.dt = R(sim->dt), K.half_dt = R(0.5 * sim->dt), K.c1 = R(std::exp(-sim->gamma * sim->dt)), K.kT = R(sim->kT);
+  K.skin_half_sq = R(0.25 * sim->skin * sim->skin);
+  K.n_types = m->n_types, K.angle_kind = m->angle_kind;
+  V4* fr[2] = {(V4*)sim->frame[0], (V4*)sim->frame[1]};
+  V4* vel = (V4*)sim->vel;
+  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, sizeof(int), st));
+  hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
+                     fr[0], vel);
+  int cur = 0;
+  if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+  const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
+  MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
+  int launches = 0, samples = 0;
+  const int sample_stride = std::max(1, (n_steps + 1) / mythos_martini_sim::kMaxSamples);
+  for (int k = 0; k <= n_steps; ++k) {
+    const bool last = (k == n_steps);
+    const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
+    const int sidx = save ? (k / save_every - 1) : 0;
+    if (k > 0 && !last && (k % sim->rebuild_every == 0))
+      if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+    const R kick_close = (k == 0) ? R(0) : R(0.5);
+    const int do_step = last ? 0 : 1;
+    R* tp = (save && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
+    const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_martini_sim::kMaxSamples;
+#define MM_ARGS                                                                                                    \
+  n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, sim->d_rows, sim->d_row_len, sim->row_stride, (const R*)m->d_sigma,    \
+      (const R*)m->d_eps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
+      (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)m->d_angle_t0, kick_close, do_step,     \
+      sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart
+    if (save) {
+      hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+      hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
+                         e_trace ? e_trace + (size_t)sidx * kMmTrace : nullptr);
+    } else if (sampled) {
+      hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
+                            sim->sb[samples], 0, MM_ARGS);
+      ++samples;
+    } else {
+      hipLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+    }
+#undef MM_ARGS
+    ++launches;
+    cur ^= 1;
+  }
+  MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
+  MYTHOS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(mm_unpack_kernel<R>, dim3(tb), dim3(256), 0, st, n, (const V4*)fr[cur], (const V4*)vel, pos, v);
+  int flags = 0, ov = 0;
+  MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, sim->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0;
+  MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
+  sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
+  sim->last_launches = launches;
+  double acc = 0;
+  for (int k = 0; k < samples; ++k) {
+    float t = 0;
+    MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[k], sim->sb[k]));
+    acc += t;
+  }
+  sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  sim->last_samples = samples;
+  sim->step += n_steps;
+  if (flags & 2) {
+    set_error("mythos_martini_langevin_run: NaN in the state (time step too large or overlapping start configuration)");
+    return MYTHOS_ERR_NUMERIC;
+  }
+  if (ov != 0) {
+    set_error("mythos_martini_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
+              std::to_string(sim->row_stride) + ")");
+    return MYTHOS_ERR_OVERFLOW;
+  }
+  if (flags & 1) {
+    set_error("mythos_martini_langevin_run: a bead moved more than skin/2 between neighbour-list rebuilds; use a larger "
+              "skin or rebuild more often");
+    return MYTHOS_ERR_OVERFLOW;
+  }
+  return MYTHOS_OK;
+}
+
+}  // namespace mythos
+
+extern "C" {
+
+void mythos_martini_langevin_destroy(mythos_martini_sim_t* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->sys->device);
+  void* ptrs[] = {s->frame[0], s->frame[1], s->vel, s->ref_pos, s->d_inv_mass, s->d_rows, s->d_row_len,
+                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (int k = 0; k < mythos_martini_sim::kMaxSamples; ++k) {
+    if (s->sa[k]) (void)hipEventDestroy(s->sa[k]);
+    if (s->sb[k]) (void)hipEventDestroy(s->sb[k]);
+  }
+  delete s;
+}
+
+mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, double dt, double kT, double gamma,
+                                                     const double* mass, uint64_t seed) {
+  if (!sys || !(dt > 0) || !(kT > 0) || !(gamma >= 0)) {
+    set_error("mythos_martini_langevin_create: invalid argument");
+    return nullptr;
+  }
+  if (hipSetDevice(sys->device) != hipSuccess) {
+    set_error("mythos_martini_langevin_create: hipSetDevice failed");
+    return nullptr;
+  }
+  auto* s = new mythos_martini_sim();
+  s->sys = sys, s->dt = dt, s->kT = kT, s->gamma = gamma, s->seed = seed;
+  const int n = sys->n;
+  const size_t w = sys->dtype == MYTHOS_F32 ? sizeof(float) : sizeof(double);
+  std::vector<double> im(n);
+  for (int i = 0; i < n; ++i) {
+    const double mi = mass ? mass[i] : 72.0;  // MARTINI's standard bead mass (amu)
+    if (!(mi > 0)) {
+      set_error("mythos_martini_langevin_create: masses must be positive");
+      delete s;
+      return nullptr;
+    }
+    im[i] = 1.0 / mi;
+  }
+  const int blocks = (n + kMmPPB - 1) / kMmPPB;
+  bool ok = hipMalloc(&s->frame[0], (size_t)n * 4 * w) == hipSuccess && hipMalloc(&s->frame[1], (size_t)n * 4 * w) == hipSuccess &&
+            hipMalloc(&s->vel, (size_t)n * 4 * w) == hipSuccess && hipMalloc(&s->ref_pos, (size_t)n * 4 * w) == hipSuccess &&
+            hipMalloc((void**)&s->d_rows, (size_t)n * s->row_stride * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_row_len, (size_t)n * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
+  ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
+  ok = ok && hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
+  for (int k = 0; ok && k < mythos_martini_sim::kMaxSamples; ++k)
+    ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;
+  if (!ok) {
+    set_error("mythos_martini_langevin_create: device allocation failed");
+    mythos_martini_langevin_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* s, double skin, int rebuild_every) {
+  if (!s || !(skin > 0) || rebuild_every < 1) {
+    set_error("mythos_martini_langevin_set_neighbor_policy: skin > 0 and rebuild_every >= 1 required");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->skin = skin;
+  s->rebuild_every = rebuild_every;
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_init_velocities(mythos_martini_sim_t* s, void* vel, mythos_stream_t stream) {
+  if (!s || !vel) {
+    set_error("mythos_martini_langevin_init_velocities: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  if (s->sys->dtype == MYTHOS_F32)
+    hipLaunchKernelGGL(mm_init_velocities_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)stream, s->sys->n, float(s->kT),
+                       (const float*)s->d_inv_mass, s->seed, (float*)vel);
+  else
+    hipLaunchKernelGGL(mm_init_velocities_kernel<double>, dim3(1), dim3(256), 0, (hipStream_t)stream, s->sys->n, s->kT,
+                       (const double*)s->d_inv_mass, s->seed, (double*)vel);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_run(mythos_martini_sim_t* s, void* pos, void* vel, const double* box, int n_steps,
+                                int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream) {
+  if (!s || !pos || !vel || !box || n_steps < 0 || save_every < 0 || !(box[0] > 0) || !(box[1] > 0) || !(box[2] > 0)) {
+    set_error("mythos_martini_langevin_run: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  const double rl = s->sys->r_cut + s->skin;
+  if (2.0 * rl > std::min(box[0], std::min(box[1], box[2]))) {
+    set_error("mythos_martini_langevin_run: the box is smaller than twice (r_cut + skin): minimum image breaks down");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  if (s->sys->dtype == MYTHOS_F32)
+    return mm_run_typed<float>(s, (float*)pos, (float*)vel, box, n_steps, save_every, (float*)traj_pos, e_trace,
+                               (hipStream_t)stream);
+  return mm_run_typed<double>(s, (double*)pos, (double*)vel, box, n_steps, save_every, (double*)traj_pos, e_trace,
+                              (hipStream_t)stream);
+}
+
+int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* s, double* kernel_ms, double* loop_ms_per_launch,
+                                           int* launches, int* samples) {
+  if (!s) {
+    set_error("mythos_martini_langevin_last_kernel_ms: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (kernel_ms) *kernel_ms = s->last_kernel_ms;
+  if (loop_ms_per_launch) *loop_ms_per_launch = s->last_avg_ms;
+  if (launches) *launches = s->last_launches;
+  if (samples) *samples = s->last_samples;
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* s, int* max_row, double* mean_row) {
+  if (!s) {
+    set_error("mythos_martini_langevin_neighbor_stats: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  std::vector<int> len(s->sys->n);
+  MYTHOS_HIP_TRY(hipMemcpy(len.data(), s->d_row_len, len.size() * sizeof(int), hipMemcpyDeviceToHost));
+  long long tot = 0;
+  int mx = 0;
+  for (int v : len) tot += v, mx = std::max(mx, v);
+  if (max_row) *max_row = mx;
+  if (mean_row) *mean_row = double(tot) / std::max<size_t>(1, len.size());
+  return MYTHOS_OK;
+}
+
+}  // extern "C"

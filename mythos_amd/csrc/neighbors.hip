@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 
+#include "cell_list.h"
 #include "oxdna_gather.h"
 
 namespace mythos {
@@ -118,136 +119,6 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
 // index after the atomic fill and rows are filled in (cell order, bucket order), so the list is
 // reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-template <typename R>
-struct CellGrid {
-  R inv[3];   // 1 / cell edge
-  R ibox[3];  // 1 / box edge (periodic)
-  int nc[3];  // cells per box edge (periodic) or 0 (free space)
-  int hmask;
-};
-
-template <typename R>
-__device__ __forceinline__ void cell_of(const CellGrid<R>& g, R x, R y, R z, int& cx, int& cy, int& cz) {
-  const R p[3] = {x, y, z};
-  int c[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    if (g.nc[k] > 0) {
-      R f = p[k] * g.ibox[k];
-      f -= floor(f);
-      int v = (int)(f * R(g.nc[k]));
-      c[k] = v >= g.nc[k] ? g.nc[k] - 1 : v;
-    } else {
-      c[k] = (int)floor(p[k] * g.inv[k]);
-    }
-  }
-  cx = c[0], cy = c[1], cz = c[2];
-}
-
-__device__ __forceinline__ int cell_hash(int cx, int cy, int cz, int hmask) {
-  return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & hmask;
-}
-
-template <typename R, bool VEC4>
-__global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGrid<R> g, int* __restrict__ slot_of,
-                                  int* __restrict__ cnt) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  constexpr int S = VEC4 ? 4 : 3;
-  int cx, cy, cz;
-  cell_of(g, pos[S * i], pos[S * i + 1], pos[S * i + 2], cx, cy, cz);
-  const int h = cell_hash(cx, cy, cz, g.hmask);
-  slot_of[i] = h;
-  atomicAdd(&cnt[h], 1);
-}
-
-// exclusive scan of cnt[0..m) into start[0..m] in two coalesced passes; cnt is cleared for reuse as a
-// cursor.  Pass 1: each 1024-thread workgroup scans 4096 counters (int4 per lane, wave shuffles + one LDS
-// hop) and publishes its total.  Pass 2 adds the totals of the preceding workgroups.
-constexpr int kScanBlock = 1024;
-constexpr int kScanPerBlock = 4 * kScanBlock;
-
-__global__ __launch_bounds__(kScanBlock) void cell_scan_local_kernel(int m, int* __restrict__ cnt,
-                                                                      int* __restrict__ start,
-                                                                      int* __restrict__ block_sum) {
-  __shared__ int wave_tot[kScanBlock / 64];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int base = (blockIdx.x * kScanBlock + t) * 4;
-  int4 v = make_int4(0, 0, 0, 0);
-  if (base + 3 < m) {
-    v = *reinterpret_cast<const int4*>(cnt + base);
-    *reinterpret_cast<int4*>(cnt + base) = make_int4(0, 0, 0, 0);
-  } else {
-    int* pv = &v.x;
-    for (int k = 0; k < 4; ++k)
-      if (base + k < m) {
-        pv[k] = cnt[base + k];
-        cnt[base + k] = 0;
-      }
-  }
-  const int s = v.x + v.y + v.z + v.w;
-  int inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += u;
-  }
-  if (lane == 63) wave_tot[w] = inc;
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int k = 0; k < kScanBlock / 64; ++k) {
-      const int x = wave_tot[k];
-      wave_tot[k] = run;
-      run += x;
-    }
-    block_sum[blockIdx.x] = run;
-  }
-  __syncthreads();
-  const int pre = wave_tot[w] + inc - s;
-  const int o4[4] = {pre, pre + v.x, pre + v.x + v.y, pre + v.x + v.y + v.z};
-  for (int k = 0; k < 4; ++k)
-    if (base + k < m) start[base + k] = o4[k];
-}
-
-__global__ void cell_scan_fix_kernel(int m, int n_blocks, const int* __restrict__ block_sum, int* __restrict__ start) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h > m) return;
-  const int b = (h < m ? h : m - 1) / kScanPerBlock;
-  int off = 0;
-  for (int k = 0; k < b; ++k) off += block_sum[k];
-  if (h < m) {
-    start[h] += off;
-  } else {
-    int tot = 0;
-    for (int k = 0; k < n_blocks; ++k) tot += block_sum[k];
-    start[m] = tot;
-  }
-}
-
-__global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, const int* __restrict__ start,
-                                 int* __restrict__ cursor, int* __restrict__ bucket) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int h = slot_of[i];
-  bucket[start[h] + atomicAdd(&cursor[h], 1)] = i;
-}
-
-__global__ void cell_sort_kernel(int m, const int* __restrict__ start, int* __restrict__ bucket) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= m) return;
-  const int lo = start[h], hi = start[h + 1];
-  for (int a = lo + 1; a < hi; ++a) {  // insertion sort: buckets hold a few tens of entries
-    const int v = bucket[a];
-    int b = a - 1;
-    while (b >= lo && bucket[b] > v) {
-      bucket[b + 1] = bucket[b];
-      --b;
-    }
-    bucket[b + 1] = v;
-  }
-}
-
 // one wavefront per nucleotide: lanes 0..26 look up the 27 neighbour cells, the candidate lists
 // are concatenated by a wave prefix sum and swept 64 at a time with ballot compaction
 template <typename R, bool VEC4>
@@ -337,12 +208,6 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   }
 }
 
-static int next_pow2(int v) {
-  int p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
-
 template <typename R>
 static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, double skin, hipStream_t st) {
   const int n = sys->n;
@@ -377,8 +242,7 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     return 0;
   }
   const int H = next_pow2(2 * n);
-  g.hmask = H - 1;
-  const size_t need = (size_t)2 * H + 4 + (size_t)2 * n + 1024;  // cnt[H] start[H+1] pad slot_of[n] bucket[n] block_sum
+  const size_t need = CellScratch::ints(H, n);
   if (need > sys->cell_cap) {
     if (sys->d_cell) (void)hipFree(sys->d_cell);
     sys->d_cell = nullptr;
@@ -386,22 +250,13 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
     sys->cell_cap = need;
   }
-  int* cnt = sys->d_cell;
-  int* start = cnt + H;
-  int* slot_of = start + H + 4;  // keeps the int4 accesses on cnt aligned
-  int* bucket = slot_of + n;
-  int* block_sum = bucket + n;
-  MYTHOS_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)H * sizeof(int), st));
-  const int tb = (n + 255) / 256;
-  if (vec4)
-    hipLaunchKernelGGL((cell_count_kernel<R, true>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
-  else
-    hipLaunchKernelGGL((cell_count_kernel<R, false>), dim3(tb), dim3(256), 0, st, n, pos, g, slot_of, cnt);
-  const int nsb = (H + kScanPerBlock - 1) / kScanPerBlock;
-  hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nsb), dim3(kScanBlock), 0, st, H, cnt, start, block_sum);
-  hipLaunchKernelGGL(cell_scan_fix_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, st, H, nsb, block_sum, start);
-  hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, slot_of, start, cnt, bucket);
-  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, start, bucket);
+  const CellScratch cs(sys->d_cell, H, n);
+  const int* start = cs.start;
+  const int* bucket = cs.bucket;
+  if ((vec4 ? cell_list_build<R, true>(n, pos, g, H, cs, st) : cell_list_build<R, false>(n, pos, g, H, cs, st)) != 0) {
+    set_error("neighbour build: cell-list scratch memset failed");
+    return MYTHOS_ERR_HIP;
+  }
   const int wb = (n + 3) / 4;
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),

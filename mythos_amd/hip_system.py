@@ -328,3 +328,72 @@ class MartiniSystem:
             "martini_param_grads",
         )
         return out
+
+
+class MartiniLangevinIntegrator:
+    """BAOAB Langevin dynamics of a :class:`MartiniSystem` (mythos_martini_sim_t): LJ over a device-built Verlet
+    list, bonds, angles; units nm, ps, amu, kJ/mol.  ``gamma`` is the friction rate in 1/ps."""
+
+    KB = 0.0083144626  # kJ/mol/K
+
+    def __init__(self, system: MartiniSystem, dt, kT, gamma, mass=None, seed=0):
+        self.system = system
+        self._lib = system._lib
+        mptr = None
+        if mass is not None:
+            mass = np.ascontiguousarray(mass, dtype=np.float64)
+            if mass.shape != (system.n,):
+                raise ValueError(f"mass must have shape ({system.n},)")
+            mptr = mass.ctypes.data_as(_lib.c_double_p)
+        self._h = self._lib.mythos_martini_langevin_create(system._h, float(dt), float(kT), float(gamma), mptr, int(seed))
+        if not self._h:
+            raise _lib.MythosHipError(f"mythos_martini_langevin_create: {_lib.last_error()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_martini_langevin_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def set_neighbor_policy(self, skin: float, every: int) -> None:
+        _lib.check(self._lib.mythos_martini_langevin_set_neighbor_policy(self._h, float(skin), int(every)), "set_neighbor_policy")
+
+    def init_velocities(self) -> torch.Tensor:
+        v = torch.empty((self.system.n, 3), dtype=self.system.dtype, device=self.system.device)
+        _lib.check(self._lib.mythos_martini_langevin_init_velocities(self._h, _lib.ptr(v), _stream(self.system.device)), "init_velocities")
+        return v
+
+    def run(self, pos, vel, box, n_steps: int, save_every: int = 0):
+        """Advance ``pos`` / ``vel`` (n, 3) in place -> (traj_pos (S, n, 3) or None, e_trace (S, 4) float64 or None);
+        e_trace columns: lj, bond, angle, kinetic (kJ/mol) at the saved steps."""
+        s = self.system
+        for t, name in ((pos, "pos"), (vel, "vel")):
+            if t.device != s.device or t.dtype != s.dtype or tuple(t.shape) != (s.n, 3) or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {s.dtype} tensor of shape ({s.n}, 3) on {s.device}")
+        box = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3))
+        ns = n_steps // save_every if save_every > 0 else 0
+        traj = torch.empty((ns, s.n, 3), dtype=s.dtype, device=s.device) if ns else None
+        et = torch.zeros((ns, 4), dtype=torch.float64, device=s.device) if ns else None
+        _lib.check(
+            self._lib.mythos_martini_langevin_run(
+                self._h, _lib.ptr(pos), _lib.ptr(vel), box.ctypes.data_as(_lib.c_double_p), int(n_steps), int(save_every),
+                _lib.ptr(traj), _lib.ptr(et), _stream(s.device)),
+            "martini_langevin_run",
+        )
+        return traj, et
+
+    def last_kernel_ms(self) -> dict:
+        k, loop, n, ns = C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)
+        _lib.check(self._lib.mythos_martini_langevin_last_kernel_ms(self._h, C.byref(k), C.byref(loop), C.byref(n), C.byref(ns)),
+                   "last_kernel_ms")
+        return {"kernel_ms": k.value, "loop_ms_per_launch": loop.value, "launches": n.value, "samples": ns.value}
+
+    def neighbor_stats(self) -> tuple[int, float]:
+        mx, mean = C.c_int(0), C.c_double(0.0)
+        _lib.check(self._lib.mythos_martini_langevin_neighbor_stats(self._h, C.byref(mx), C.byref(mean)), "neighbor_stats")
+        return mx.value, mean.value

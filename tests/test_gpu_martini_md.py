@@ -1,0 +1,178 @@
+"""GPU tests of the MARTINI Langevin step kernel (mythos_martini_langevin_run).
+
+Nothing in the reference pins a MARTINI integrator (it delegates dynamics to GROMACS), so: step-by-step parity in
+fp64 against oracle/martini_langevin_oracle.py on the same Philox stream, the device-built Verlet list against the
+all-pairs energy kernel, physics (NVE drift, kinetic temperature), plumbing (determinism, split runs, errors), and
+the BASELINE configs[2] size (bilayer tiled 4 x 4 = 20 480 beads).
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from tests import martini_helpers as MH
+
+pytestmark = pytest.mark.gpu
+
+KB = 0.0083144626
+T = 273.0
+
+
+def _make(dtype, reps=1):
+    from mythos_amd.hip_system import MartiniSystem
+
+    s = MH.system()
+    x, box, _ = MH.frames("lj")
+    x0, b0 = x[3].copy(), box[3].copy()
+    top, types = s["top"], s["types"]
+    bk, br, ak, at = s["bond_k"], s["bond_r0"], s["angle_k"], s["angle_t0"]
+    if reps > 1:
+        for i, j in s["top"].bonded_neighbors:  # make every lipid whole before tiling (GROMACS wraps per bead)
+            d = x0[j] - x0[i]
+            x0[j] = x0[i] + d - b0 * np.round(d / b0)
+        cells = [(i, j) for i in range(reps) for j in range(reps)]
+        x0 = np.concatenate([x0 + np.array([i * b0[0], j * b0[1], 0.0]) for i, j in cells])
+        b0 = b0 * np.array([reps, reps, 1.0])
+        top = s["top"].tile(reps * reps)
+        types = np.tile(types, reps * reps)
+        bk, br, ak, at = (np.tile(a, reps * reps) for a in (bk, br, ak, at))
+    sysm = MartiniSystem(types, s["sigma"], s["eps"], top.bonded_neighbors, bk, br, top.angles, ak, at, dtype=dtype)
+    return sysm, s, top, types, (bk, br, ak, at), x0, b0
+
+
+def test_step_by_step_parity_with_oracle_fp64():
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+    from oracle.martini_langevin_oracle import MartiniLangevinOracle
+
+    sysm, s, top, types, (bk, br, ak, at), x0, b0 = _make(torch.float64)
+    rng = np.random.default_rng(5)
+    mass = rng.uniform(40.0, 90.0, size=sysm.n)
+    integ = MartiniLangevinIntegrator(sysm, dt=0.01, kT=KB * T, gamma=2.0, mass=mass, seed=0xABCDEF012345)
+    integ.set_neighbor_policy(0.25, 2)
+    pos = torch.as_tensor(x0, device=sysm.device).contiguous()
+    vel = integ.init_velocities()
+    v0 = vel.cpu().numpy().copy()
+    n_steps = 5
+    traj, et = integ.run(pos, vel, b0, n_steps, save_every=1)
+    orc = MartiniLangevinOracle(types, s["sigma"], s["eps"], top.bonded_neighbors, bk, br, top.angles, ak, at, True, b0,
+                                0.01, KB * T, 2.0, mass, seed=0xABCDEF012345)
+    xo, vo = x0.copy(), v0.copy()
+    e_ref = orc.run(xo, vo, n_steps)
+    # traj[k] / et[k] are the state after k + 1 steps (energies of x_{k+1}, kinetic energy after the closing kick)
+    np.testing.assert_allclose(pos.cpu().numpy(), xo, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(vel.cpu().numpy(), vo, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(et.cpu().numpy(), e_ref, rtol=1e-9, atol=1e-7)
+    assert traj.shape == (n_steps, sysm.n, 3)
+
+
+def test_verlet_list_forces_equal_all_pairs_energy_kernel():
+    """One step with dt -> 0 moves nothing: the saved LJ / bond / angle energies must equal mythos_martini_energy."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-5)):
+        sysm, *_rest, x0, b0 = _make(dtype)
+        integ = MartiniLangevinIntegrator(sysm, dt=1e-9, kT=KB * T, gamma=0.0, seed=1)
+        pos = torch.as_tensor(x0, dtype=dtype, device=sysm.device).contiguous()
+        vel = torch.zeros_like(pos)
+        _, et = integ.run(pos, vel, b0, 1, save_every=1)
+        e, _ = sysm.energy(torch.as_tensor(x0, dtype=dtype, device=sysm.device), torch.as_tensor(b0, dtype=dtype), grads=False)
+        np.testing.assert_allclose(et[0, :3].cpu().numpy(), e.cpu().numpy(), rtol=tol, atol=tol * abs(e.cpu().numpy()).max())
+
+
+def test_nve_energy_conservation_fp64():
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(torch.float64)
+    integ = MartiniLangevinIntegrator(sysm, dt=0.005, kT=KB * T, gamma=0.0, seed=3)
+    integ.set_neighbor_policy(0.3, 5)
+    pos = torch.as_tensor(x0, device=sysm.device).contiguous()
+    vel = integ.init_velocities()
+    _, et = integ.run(pos, vel, b0, 400, save_every=20)
+    tot = et.sum(1).cpu().numpy()
+    ke = et[:, 3].cpu().numpy()
+    # velocity-Verlet with a shifted (not force-switched) LJ: drift far below the kinetic energy scale
+    assert np.ptp(tot) < 2e-3 * ke.mean(), (tot, ke.mean())
+
+
+def test_thermostat_holds_the_temperature_fp32():
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(torch.float32)
+    integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=11)
+    integ.set_neighbor_policy(0.3, 5)
+    pos = torch.as_tensor(x0, dtype=torch.float32, device=sysm.device).contiguous()
+    vel = integ.init_velocities()
+    integ.run(pos, vel, b0, 1000)
+    _, et = integ.run(pos, vel, b0, 2000, save_every=50)
+    t_kin = 2.0 * et[:, 3].cpu().numpy() / (3.0 * sysm.n * KB)
+    assert abs(t_kin.mean() / T - 1.0) < 0.02, t_kin.mean()
+    mx, mean = integ.neighbor_stats()
+    assert 40 < mean < 120 and mx <= 160
+
+
+def test_determinism_split_runs_and_errors():
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(torch.float32)
+
+    def run(chunks, seed):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=seed)
+        integ.set_neighbor_policy(0.3, 5)
+        pos = torch.as_tensor(x0, dtype=torch.float32, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        for n in chunks:
+            integ.run(pos, vel, b0, n)
+        return pos.cpu(), vel.cpu()
+
+    a, b = run([60], 2), run([60], 2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # a split moves no rebuild (every 5 steps from step 0), but the kick that closes step 30 is then computed
+    # with the list built at step 25 instead of step 30: another summation order, fp32 round-off, amplified by
+    # 30 more steps of chaotic dynamics
+    c = run([30, 30], 2)
+    assert (a[0] - c[0]).abs().max() < 1e-4
+    d = run([60], 3)
+    assert (a[0] - d[0]).abs().max() > 1e-3
+
+    integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=2)
+    pos = torch.as_tensor(x0, dtype=torch.float32, device=sysm.device).contiguous()
+    vel = integ.init_velocities()
+    with pytest.raises(ValueError, match="box is smaller"):
+        integ.run(pos, vel, [2.0, 2.0, 2.0], 1)
+    integ.set_neighbor_policy(0.01, 1000)  # skin far too small for 200 steps without a rebuild
+    with pytest.raises(Exception, match="skin"):
+        integ.run(pos, vel, b0, 200)
+    with pytest.raises(ValueError):
+        integ.run(pos.double(), vel, b0, 1)
+
+
+def test_cfg3_bilayer_20480_beads():
+    """BASELINE configs[2]: the shipped bilayer tiled 4 x 4; the tiled system must evolve like 16 copies at step 0
+    (same energies per tile) and stay at temperature."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    big, *_r, xb, bb = _make(torch.float32, reps=4)
+    assert big.n == 20480
+    integ = MartiniLangevinIntegrator(big, dt=0.02, kT=KB * T, gamma=1.0, seed=5)
+    integ.set_neighbor_policy(0.3, 5)
+    pos = torch.as_tensor(xb, dtype=torch.float32, device=big.device).contiguous()
+    vel = integ.init_velocities()
+    _, et0 = integ.run(pos.clone(), vel.clone(), bb, 1, save_every=1)
+    e_all, _ = big.energy(torch.as_tensor(xb, dtype=torch.float32, device=big.device), torch.as_tensor(bb, dtype=torch.float32))
+    small, *_r2, xs, bs = _make(torch.float32)
+    e_one, _ = small.energy(torch.as_tensor(_whole(xs, bs), dtype=torch.float32, device=small.device), torch.as_tensor(bs, dtype=torch.float32))
+    np.testing.assert_allclose(e_all.cpu().numpy(), 16 * e_one.cpu().numpy(), rtol=2e-5)
+    _, et = integ.run(pos, vel, bb, 500, save_every=100)
+    t_kin = 2.0 * et[:, 3].cpu().numpy() / (3.0 * big.n * KB)
+    assert abs(t_kin[-1] / T - 1.0) < 0.05
+    assert torch.isfinite(pos).all()
+    assert abs(et0[0, 0].item() - e_all[0].item()) < 0.05 * abs(e_all[0].item())  # one step moved the beads a little
+
+
+def _whole(x, b):
+    s = MH.system()
+    x = x.copy()
+    for i, j in s["top"].bonded_neighbors:
+        d = x[j] - x[i]
+        x[j] = x[i] + d - b * np.round(d / b)
+    return x
