@@ -15,6 +15,7 @@ struct CellGrid {
   R ibox[3];  // 1 / box edge (periodic)
   int nc[3];  // cells per box edge (periodic) or 0 (free space)
   int hmask;
+  int direct = 0;  // 1: slots are linear cell indices (periodic grid), no hashing
 };
 
 template <typename R>
@@ -39,6 +40,14 @@ __device__ __forceinline__ int cell_hash(int cx, int cy, int cz, int hmask) {
   return (int)(((unsigned)cx * 73856093u) ^ ((unsigned)cy * 19349663u) ^ ((unsigned)cz * 83492791u)) & hmask;
 }
 
+// table slot of a cell: hashed (free space, or a periodic grid larger than the table) or, when the periodic
+// grid fits, the cell's own linear index - then a bucket holds exactly one cell and candidates need no check
+template <typename R>
+__device__ __forceinline__ int cell_slot(const CellGrid<R>& g, int cx, int cy, int cz) {
+  if (g.direct) return (cz * g.nc[1] + cy) * g.nc[0] + cx;
+  return cell_hash(cx, cy, cz, g.hmask);
+}
+
 template <typename R, bool VEC4>
 __global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGrid<R> g, int* __restrict__ slot_of,
                                   int* __restrict__ cnt) {
@@ -47,7 +56,7 @@ __global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGr
   constexpr int S = VEC4 ? 4 : 3;
   int cx, cy, cz;
   cell_of(g, pos[S * i], pos[S * i + 1], pos[S * i + 2], cx, cy, cz);
-  const int h = cell_hash(cx, cy, cz, g.hmask);
+  const int h = cell_slot(g, cx, cy, cz);
   slot_of[i] = h;
   atomicAdd(&cnt[h], 1);
 }
@@ -124,18 +133,38 @@ static __global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, 
   bucket[start[h] + atomicAdd(&cursor[h], 1)] = i;
 }
 
-static __global__ void cell_sort_kernel(int m, const int* __restrict__ start, int* __restrict__ bucket) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per bucket: buckets of up to 64 entries (all of them in practice: a cell holds a few tens of
+// particles) are sorted by a 64-lane bitonic network on registers, longer ones by one lane serially.
+static __global__ __launch_bounds__(256) void cell_sort_kernel(int m, const int* __restrict__ start,
+                                                               int* __restrict__ bucket) {
+  const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (h >= m) return;
-  const int lo = start[h], hi = start[h + 1];
-  for (int a = lo + 1; a < hi; ++a) {  // insertion sort: buckets hold a few tens of entries
-    const int v = bucket[a];
-    int b = a - 1;
-    while (b >= lo && bucket[b] > v) {
-      bucket[b + 1] = bucket[b];
-      --b;
+  const int lo = start[h], cnt = start[h + 1] - lo;
+  if (cnt <= 1) return;
+  if (cnt <= 64) {
+    int v = (lane < cnt) ? bucket[lo + lane] : 0x7fffffff;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const int o = __shfl_xor(v, j, 64);
+        const bool up = ((lane & k) == 0);        // ascending block
+        const bool lower = ((lane & j) == 0);     // this lane keeps the smaller value of the pair
+        v = (lower == up) ? min(v, o) : max(v, o);
+      }
     }
-    bucket[b + 1] = v;
+    if (lane < cnt) bucket[lo + lane] = v;
+  } else if (lane == 0) {
+    for (int a = lo + 1; a < lo + cnt; ++a) {
+      const int v = bucket[a];
+      int b2 = a - 1;
+      while (b2 >= lo && bucket[b2] > v) {
+        bucket[b2 + 1] = bucket[b2];
+        --b2;
+      }
+      bucket[b2 + 1] = v;
+    }
   }
 }
 
@@ -157,7 +186,7 @@ struct CellScratch {
 // count, scan, fill and sort for n particles at pos (stride 3 or 4 reals); H = table size (power of two)
 template <typename R, bool VEC4>
 static inline int cell_list_build(int n, const R* pos, CellGrid<R>& g, int H, const CellScratch& cs, hipStream_t st) {
-  g.hmask = H - 1;
+  if (!g.direct) g.hmask = H - 1;
   if (hipMemsetAsync(cs.cnt, 0, (size_t)H * sizeof(int), st) != hipSuccess) return -1;
   const int tb = (n + 255) / 256;
   hipLaunchKernelGGL((cell_count_kernel<R, VEC4>), dim3(tb), dim3(256), 0, st, n, pos, g, cs.slot_of, cs.cnt);
@@ -165,7 +194,7 @@ static inline int cell_list_build(int n, const R* pos, CellGrid<R>& g, int H, co
   hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nsb), dim3(kScanBlock), 0, st, H, cs.cnt, cs.start, cs.block_sum);
   hipLaunchKernelGGL(cell_scan_fix_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, st, H, nsb, cs.block_sum, cs.start);
   hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, cs.slot_of, cs.start, cs.cnt, cs.bucket);
-  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 255) / 256), dim3(256), 0, st, H, cs.start, cs.bucket);
+  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 3) / 4), dim3(256), 0, st, H, cs.start, cs.bucket);
   return 0;
 }
 

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int c[3] = {cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1};
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = (c[k] + g.nc[k]) % g.nc[k];
-    const int h = cell_hash(c[0], c[1], c[2], g.hmask);
+    const int h = cell_slot(g, c[0], c[1], c[2]);
     const int st = start[h];
     cnt = start[h + 1] - st;
     s_st[w][lane] = st;
@@ -349,24 +349,24 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
   for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
   int* row = rows + (size_t)i * row_stride;
   int out = 0;
+  int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by 64 per sweep
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
     bool hit = false;
     int j = -1;
     if (t < total) {
-      int lo = 0, hi = 27;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_pre[w][mid] <= t) lo = mid; else hi = mid;
-      }
+      while (s_pre[w][lo + 1] <= t) ++lo;
       j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
       if (j != i && !mm_excluded<R>(ex, j)) {
         const auto pj = pos[j];
-        int jx, jy, jz;
-        cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
-        // a bucket may mix cells that collide in the hash, and with fewer than 3 distinct cells along an edge
-        // the same cell would be visited twice: accept a candidate only for the first lane that names its cell
-        bool mine = (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]);
+        // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
+        // direct table: a bucket is one cell
+        bool mine = true;
+        if (!g.direct) {
+          int jx, jy, jz;
+          cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
+          mine = (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]);
+        }
         if (mine) {
           const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
           hit = dx * dx + dy * dy + dz * dz < rl2;
@@ -481,7 +481,10 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
     hipLaunchKernelGGL(mm_build_rows_allpairs_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, R(rl * rl), m->d_excl,
                        sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow);
   } else {
-    const int H = next_pow2(2 * n);
+    // periodic grid: one table slot per cell (no hashing) whenever the grid is not much larger than the system
+    const long long n_cells = (long long)g.nc[0] * g.nc[1] * g.nc[2];
+    g.direct = n_cells <= 8LL * n ? 1 : 0;
+    const int H = g.direct ? (int)(4 * ((n_cells + 3) / 4)) : next_pow2(2 * n);
     const size_t need = CellScratch::ints(H, n);
     if (need > sim->cell_cap) {
       if (sim->d_cell) (void)hipFree(sim->d_cell);

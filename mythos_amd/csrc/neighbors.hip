@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       if (g.nc[k] > 0) c[k] = (c[k] + g.nc[k]) % g.nc[k];
-    const int h = cell_hash(c[0], c[1], c[2], g.hmask);
+    const int h = cell_slot(g, c[0], c[1], c[2]);
     const int st = start[h];
     cnt = start[h + 1] - st;
     s_st[w][lane] = st;
