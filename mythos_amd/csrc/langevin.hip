@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   const R eps_n = P[NEXC_EPS];
   const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
   const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
+  const DebyeP<R> dhp = (MODEL == 2) ? debye_params<R>(P) : DebyeP<R>{};
   int n_items[3] = {0, 0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
             R dVdr = tw_n * v.d;
             R en = v.f;
             if constexpr (MODEL == 2) {
-              const FD<R> dh = debye_eval(r, P);
+              const FD<R> dh = debye_eval(r, dhp);
               R mult = R(1);
               if (half_ends) {
                 const int mo = (int)o0.w;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
           const FD<R> v = f3_eval(r, eps_n, f_bb);
           R dVdr = tw_n * v.d;
           if constexpr (MODEL == 2) {
-            const FD<R> dh = debye_eval(r, P);
+            const FD<R> dh = debye_eval(r, dhp);
             R mult = R(1);
             if (half_ends) {
               const int mo = (int)o0.w;

@@ -459,6 +459,32 @@ __device__ __forceinline__ FD<R> debye_eval(R r, const PT& P) {
   }
   return o;
 }
+// the five Debye-Hueckel scalars read once (a kernel that evaluates the term in a loop keeps them in SGPRs
+// instead of issuing a scalar load and a wait at every use)
+template <typename R>
+struct DebyeP {
+  R rcut, rhigh, kappa, prefactor, bsmooth;
+};
+template <typename R, class PT>
+__device__ __forceinline__ DebyeP<R> debye_params(const PT& P) {
+  return {P[DH_RCUT], P[DH_RHIGH], P[DH_KAPPA], P[DH_PREFACTOR], P[DH_BSMOOTH]};
+}
+template <typename R>
+__device__ __forceinline__ FD<R> debye_eval(R r, const DebyeP<R>& p) {
+  FD<R> o{R(0), R(0)};
+  if (r < p.rcut) {
+    if (r < p.rhigh) {
+      const R ir = R(1) / r;
+      o.f = m_exp(-p.kappa * r) * p.prefactor * ir;
+      o.d = -o.f * (p.kappa + ir);
+    } else {
+      const R t = r - p.rcut;
+      o.f = p.bsmooth * t * t;
+      o.d = R(2) * p.bsmooth * t;
+    }
+  }
+  return o;
+}
 template <typename R, class PG, class PT>
 __device__ __forceinline__ void debye_pgrad(R r, const PT& P, R mult, PG& pg) {
   if constexpr (!PG::on) return;
