@@ -25,9 +25,19 @@ struct LdsPG {
   }
 };
 
+// workgroups per CU the register allocator makes room for: the gradient modes need ~170 (fp32) registers to stay
+// out of scratch, the energy-only mode fits in 128
+#ifndef EN_LB
+#define EN_LB 3
+#endif
+template <typename R, int MODE>
+constexpr int energy_blocks_per_cu() {
+  return sizeof(R) == 4 ? (MODE == 0 ? 4 : EN_LB) : 2;
+}
+
 template <typename R, int MODEL, int MODE, int G>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
-__global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy_kernel(
-    const OxParams<R> Pk, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
+__global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxdna_energy_kernel(
+    const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
     double* __restrict__ pg_part) {
@@ -35,9 +45,9 @@ __global__ __launch_bounds__(kBlock, (sizeof(R) == 4 ? 4 : 2)) void oxdna_energy
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
   __shared__ double pg_lds[MODE == 2 ? OXP_COUNT : 1];
-  __shared__ R p_lds[OXP_COUNT];
-  stage_params(Pk, p_lds, threadIdx.x, kBlock);
-  const LdsParams<R> P{p_lds};
+  // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
+  // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
+  const ConstParams<R> P(Pg);
 
   const int frame = blockIdx.y;
   const int grp = threadIdx.x / G;
@@ -143,7 +153,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   if (int rc = ensure(sys->d_epart, sys->epart_cap, (size_t)chunk * blocks * T_COUNT)) return rc;
   if (mode == 2)
     if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * OXP_COUNT)) return rc;
-  const OxParams<R>& P = params_of<R>(sys);
+  const R* P = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
   for (int f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = std::min(chunk, n_frames - f0);
