@@ -16,9 +16,14 @@ namespace mythos {
 
 constexpr int kBlock = 256;
 
+// Parameter-partial sink: fp64 LDS atomics into one of kPgCopies private copies of the accumulator (chosen by
+// lane), so the 64 lanes of a wave instruction that add to the SAME parameter - the common case: the index is a
+// compile-time constant at most call sites - hit 16 addresses in 16 different bank pairs instead of one.
+constexpr int kPgCopies = 16;
+constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: copy c of parameter k lands in bank pair (c + k) % 16
 struct LdsPG {
   static constexpr bool on = true;
-  double* acc;
+  double* acc;  // this lane's copy
   template <typename R>
   __device__ __forceinline__ void add(int idx, R v) const {
     atomicAdd(&acc[idx], 0.5 * double(v));
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
-  __shared__ double pg_lds[MODE == 2 ? OXP_COUNT : 1];
+  __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   const ConstParams<R> P(Pg);
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   const size_t fo = (size_t)frame * n;
 
   if constexpr (MODE == 2) {
-    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) pg_lds[k] = 0.0;
+    for (int k = threadIdx.x; k < kPgCopies * kPgStride; k += kBlock) pg_lds[k] = 0.0;
   }
   __syncthreads();
 
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     Nuc<R> self;
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
-      LdsPG pg{pg_lds};
+      LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
       gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
     } else {
       NoPG pg;
@@ -112,7 +117,12 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     e_part[bo * T_COUNT + threadIdx.x] = s;
   }
   if constexpr (MODE == 2) {
-    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) pg_part[bo * OXP_COUNT + k] = pg_lds[k];
+    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) {
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < kPgCopies; ++c) s += pg_lds[c * kPgStride + k];  // fixed order
+      pg_part[bo * OXP_COUNT + k] = s;
+    }
   }
 }
 
