@@ -93,3 +93,114 @@ def reweighted_mean_and_grad(observable, energies_grad, weights, beta):
     mean_og = ((w * o)[:, None] * g).sum(0)
     b = torch.as_tensor(beta, dtype=torch.float64, device=w.device)
     return mean_o, -b * (mean_og - mean_o * mean_g)
+
+
+# ------------------------------------------------------------------------------------------------
+# objective protocol (mythos/optimization/objective.py:33-136, 239-389)
+# ------------------------------------------------------------------------------------------------
+import dataclasses as _dc
+import math as _math
+
+
+@_dc.dataclass(frozen=True, kw_only=True)
+class ObjectiveOutput:
+    """What ``Objective.calculate`` hands back (objective.py:33-50): gradients when ready, otherwise the names of
+    the observables that have to be produced again; ``state`` travels to the next call."""
+
+    is_ready: bool
+    grads: dict | None = None
+    observables: dict = _dc.field(default_factory=dict)
+    state: dict = _dc.field(default_factory=dict)
+    needs_update: tuple = ()
+
+
+@_dc.dataclass(frozen=True, kw_only=True)
+class Objective:
+    """Immutable objective: ``grad_or_loss_fn(*observables) -> (grads, [(name, value), ...])`` (objective.py:53-136)."""
+
+    name: str
+    required_observables: tuple
+    grad_or_loss_fn: Callable = _dc.field(repr=False)
+    logging_observables: tuple = ()
+
+    def __post_init__(self):
+        for field in ("name", "required_observables", "grad_or_loss_fn"):
+            if getattr(self, field) is None:
+                raise ValueError(f"Missing required argument: {field}.")
+
+    def _missing(self, observables) -> tuple:
+        return tuple(o for o in self.required_observables if o not in observables)
+
+    def calculate(self, observables: dict, opt_params=None, **_kwargs) -> ObjectiveOutput:  # noqa: ARG002
+        missing = self._missing(observables)
+        if missing:
+            return ObjectiveOutput(is_ready=False, needs_update=missing)
+        ordered = [observables[k] for k in self.required_observables]
+        grads, aux = self.grad_or_loss_fn(*ordered)
+        out = dict(aux)
+        out.update(dict(zip(self.required_observables, ordered)))
+        return ObjectiveOutput(is_ready=True, grads=grads, observables=out)
+
+    def get_logging_observables(self, observables: dict) -> list:
+        return [(n, observables[n]) for n in self.logging_observables if n in observables]
+
+
+@_dc.dataclass(frozen=True, kw_only=True)
+class DiffTReObjective(Objective):
+    """Gradients by trajectory reweighting (objective.py:239-389).
+
+    ``grad_or_loss_fn(ref_states, weights, energy_fn, opt_params, observables) -> (loss, ((name, value), aux))``.
+    The stored trajectory stays valid while the normalised effective sample size of the reweighting from
+    ``reference_opt_params`` to ``opt_params`` is at least ``min_n_eff_factor`` (minimum over temperature segments)
+    and fewer than ``max_valid_opt_steps`` optimisation steps used it; otherwise new trajectories are requested.
+    Energies and dU/dtheta of all stored frames come from one launch of the HIP energy kernel per evaluation.
+    """
+
+    energy_fn: Any = _dc.field(repr=False)
+    n_equilibration_steps: int = 0
+    min_n_eff_factor: float = 0.95
+    max_valid_opt_steps: float = _math.inf
+
+    def __post_init__(self):
+        Objective.__post_init__(self)
+        if self.energy_fn is None:
+            raise ValueError("Missing required argument: energy_fn.")
+        if self.n_equilibration_steps is None or self.n_equilibration_steps < 0:
+            raise ValueError(f"n_equilibration_steps must be non-negative, got {self.n_equilibration_steps}.")
+        if self.max_valid_opt_steps <= 0:
+            raise ValueError("max_valid_opt_steps must be positive or infinity.")
+
+    def calculate(self, observables: dict, opt_params: dict, opt_steps: int = 0, reference_opt_params: dict | None = None,
+                  **_kwargs) -> ObjectiveOutput:
+        from mythos_amd.simulators.io import SimulatorTrajectory
+
+        if opt_steps >= self.max_valid_opt_steps:
+            return ObjectiveOutput(is_ready=False, needs_update=tuple(self.required_observables), state={"opt_steps": 0})
+        missing = self._missing(observables)
+        if missing:
+            return ObjectiveOutput(is_ready=False, needs_update=missing)
+        ordered = [observables[k] for k in self.required_observables]
+        trajectories = [o for o in ordered if isinstance(o, SimulatorTrajectory)]
+        if not trajectories:
+            raise ValueError("No SimulatorTrajectory observables found in observables.")
+        if self.n_equilibration_steps > 0:
+            trajectories = [t.slice(slice(self.n_equilibration_steps, t.length(), None)) for t in trajectories]
+        ref_states = SimulatorTrajectory.concat(trajectories)
+        if ref_states.length() == 0:
+            raise ValueError("Equilibration slicing yields no states! Note slicing is in number of snapshots, not timesteps.")
+        if ref_states.temperature is None:
+            raise ValueError("SimulatorTrajectory.temperature is None. DiffTRe requires per-state temperature (kT) on the trajectory.")
+        beta = 1.0 / torch.as_tensor(ref_states.temperature, dtype=torch.float64)
+        reference_opt_params = reference_opt_params or opt_params
+        with torch.no_grad():
+            ref_energies = self.energy_fn.with_params(reference_opt_params).map(ref_states).detach()
+            new_energies = self.energy_fn.with_params(opt_params).map(ref_states).detach()
+        neff = compute_min_segment_neff(ref_states.temperature, new_energies, ref_energies)
+        if neff < self.min_n_eff_factor:
+            return ObjectiveOutput(is_ready=False, needs_update=tuple(self.required_observables), observables={"neff": neff},
+                                   state={"opt_steps": 0})
+        (loss, (_, measured, _)), grads = compute_loss_and_grad(
+            opt_params, self.energy_fn, beta.to(ref_energies.device), self.grad_or_loss_fn, ref_states, ref_energies, ordered)
+        return ObjectiveOutput(
+            is_ready=True, grads=grads, observables={"loss": loss, "neff": neff, measured[0]: measured[1]},
+            state={"opt_steps": opt_steps + 1, "reference_opt_params": reference_opt_params})

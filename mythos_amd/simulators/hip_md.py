@@ -76,8 +76,18 @@ class HipMDSimulator(Simulator):
     save_every: int = 1
     dtype: torch.dtype = torch.float32
     device: Any = None
+    # defaults for callers that only pass parameters (SimpleOptimizer.step: simulator.run(params, **state))
+    init_state: Any = None
+    n_steps: int | None = None
+    key: int = 0
 
-    def run(self, opt_params: dict, init_state: RigidBody, n_steps: int, key: int = 0, **_) -> SimulatorOutput:
+    def run(self, opt_params: dict, init_state: RigidBody | None = None, n_steps: int | None = None, key: int | None = None,
+            **_) -> SimulatorOutput:
+        init_state = self.init_state if init_state is None else init_state
+        n_steps = self.n_steps if n_steps is None else n_steps
+        key = self.key if key is None else key
+        if init_state is None or n_steps is None:
+            raise ValueError("HipMDSimulator.run needs init_state and n_steps (as arguments or as fields)")
         if self.simulator_init is not nvt_langevin:
             raise NotImplementedError("HipMDSimulator implements nvt_langevin (the integrator every reference example uses)")
         ef = self.energy_fn.with_params(opt_params) if opt_params else self.energy_fn
@@ -138,4 +148,6 @@ class HipMDSimulator(Simulator):
             metadata=None if et is None else {"energy_terms": et[:, :8], "kinetic": et[:, 8:]},
         )
         final = RigidBody(center=c, orientation=Quaternion(vec=q))
-        return SimulatorOutput(observables=[traj], state={"final_state": final, "momentum": (p, ang), "steps": integ.step})
+        # the state handed to the next run(params, **state): continue from the last configuration with a new key
+        return SimulatorOutput(observables=[traj], state={"init_state": final, "key": int(key) + 1, "final_state": final,
+                                                          "momentum": (p, ang), "steps": integ.step})

@@ -130,3 +130,44 @@ def test_replica_sharding_collectives_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+def test_adam_matches_the_published_update_rule():
+    """optax.adam semantics: bias-corrected moments, update = -lr m_hat / (sqrt(v_hat) + eps)."""
+    from mythos_amd.optimization.optimization import Adam, apply_updates
+
+    opt = Adam(learning_rate=0.1, b1=0.9, b2=0.999, eps=1e-8)
+    params = {"a": 1.0, "b": torch.tensor(-2.0, dtype=torch.float64)}
+    state = opt.init(params)
+    g1 = {"a": torch.tensor(0.5, dtype=torch.float64), "b": torch.tensor(-4.0, dtype=torch.float64)}
+    upd, state = opt.update(g1, state, params)
+    # first step: m_hat = g, v_hat = g^2  ->  update = -lr * sign(g) (up to eps)
+    assert abs(float(upd["a"]) + 0.1) < 1e-7 and abs(float(upd["b"]) - 0.1) < 1e-7
+    params = apply_updates(params, upd)
+    g2 = {"a": torch.tensor(0.25, dtype=torch.float64), "b": torch.tensor(0.0, dtype=torch.float64)}
+    upd, state = opt.update(g2, state, params)
+    m = 0.9 * 0.05 + 0.1 * 0.25
+    v = 0.999 * (0.001 * 0.25) + 0.001 * 0.0625
+    want = -0.1 * (m / (1 - 0.9**2)) / ((v / (1 - 0.999**2)) ** 0.5 + 1e-8)
+    assert abs(float(upd["a"]) - want) < 1e-12 and state["count"] == 2
+
+
+def test_objective_protocol_without_a_gpu():
+    from mythos_amd.optimization.objective import DiffTReObjective, Objective
+
+    obj = Objective(name="o", required_observables=("x", "y"), logging_observables=("x",),
+                    grad_or_loss_fn=lambda x, y: ({"p": x + y}, [("sum", x + y)]))
+    miss = obj.calculate({"x": 1.0})
+    assert not miss.is_ready and miss.needs_update == ("y",)
+    out = obj.calculate({"x": 1.0, "y": 2.0})
+    assert out.is_ready and out.grads == {"p": 3.0} and out.observables == {"sum": 3.0, "x": 1.0, "y": 2.0}
+    assert obj.get_logging_observables(out.observables) == [("x", 1.0)]
+    with pytest.raises(ValueError, match="n_equilibration_steps"):
+        DiffTReObjective(name="d", required_observables=("t",), grad_or_loss_fn=lambda *a: None, energy_fn=object(),
+                         n_equilibration_steps=-1)
+    with pytest.raises(ValueError, match="max_valid_opt_steps"):
+        DiffTReObjective(name="d", required_observables=("t",), grad_or_loss_fn=lambda *a: None, energy_fn=object(),
+                         max_valid_opt_steps=0)
+    spent = DiffTReObjective(name="d", required_observables=("t",), grad_or_loss_fn=lambda *a: None, energy_fn=object(),
+                             max_valid_opt_steps=2).calculate({}, opt_params={}, opt_steps=2)
+    assert not spent.is_ready and spent.needs_update == ("t",) and spent.state == {"opt_steps": 0}
