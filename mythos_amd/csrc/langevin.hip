@@ -117,6 +117,9 @@ struct MdCut {
   // squared supports of the angular terms' radial factors (base-base for H-bond and cross-stacking,
   // stack-stack for coaxial stacking): the radial pass flags a neighbour without taking a square root
   R hb_lo2, hb_hi2, cr_lo2, cr_hi2, cx_lo2, cx_hi2;
+  // bit (4 * seq_p + seq_q) set where the H-bond weight table is non-zero (only complementary pairs by default):
+  // the radial pass tests one bit instead of walking the 16-entry table
+  unsigned int hb_mask;
 };
 
 template <typename R>
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
             flag[1] = cut.cr_lo2 < r2 && r2 < cut.cr_hi2;
             if (cut.hb_lo2 < r2 && r2 < cut.hb_hi2) {  // H-bond only for pairs with a non-zero weight
               const int so = (int)o0.w & 3;
-              flag[0] = weight_lookup(P, HYDR_EPS_00, role_p ? (self.seq * 4 + so) : (so * 4 + self.seq)) != R(0);
+              flag[0] = (cut.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
             }
           }
           {
@@ -834,6 +837,9 @@ static MdCut<R> make_cut(const mythos_system* sys) {
   c.hb_lo2 = sq(P[HYDR_RCLOW]), c.hb_hi2 = sq(P[HYDR_RCHIGH]);
   c.cr_lo2 = sq(P[CRST_RCLOW]), c.cr_hi2 = sq(P[CRST_RCHIGH]);
   c.cx_lo2 = sq(P[CXST_RCLOW]), c.cx_hi2 = sq(P[CXST_RCHIGH]);
+  c.hb_mask = 0;
+  for (int k = 0; k < 16; ++k)
+    if (P[HYDR_EPS_00 + k] != 0.0) c.hb_mask |= 1u << k;
   return c;
 }
 
