@@ -103,11 +103,31 @@ constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 // Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
 // produced the positions so that neighbour visits never redo the quaternion -> axes algebra:
 //   p0 = (centre, meta)   p1 = (a1, 0)   p2 = (a3, 0)   p3 = (backbone offset k1 a1 + k2 a2, 0)
+//   pl = (centre_lo, 0)   fp32 only: the centre is the unevaluated sum p0.xyz + pl.xyz (|lo| <= ulp(hi)/2), which
+//        keeps ~48 bits of position however large the coordinates are (a 12 kbp duplex is 4 800 length units long,
+//        where a bare fp32 coordinate resolves 5e-4).  Differences of nearby centres are then exact to fp32
+//        round-off of the DIFFERENCE: (hi_j - hi_i) is exact (Sterbenz), (lo_j - lo_i) is tiny.
 //   q  = quaternion
 template <typename R>
 struct Frame {
-  typename Vec4T<R>::type *p0, *p1, *p2, *p3, *q;
+  typename Vec4T<R>::type *p0, *p1, *p2, *p3, *q, *pl;
 };
+
+template <typename R>
+constexpr bool kHiLo = sizeof(R) == 4;
+
+// centre(o) - centre(s) from the hi (and, in fp32, lo) parts
+template <typename R>
+__device__ __forceinline__ V3<R> centre_diff(const typename Vec4T<R>::type& o_hi, const typename Vec4T<R>::type& o_lo,
+                                             const V3<R>& s_hi, const V3<R>& s_lo) {
+  V3<R> d{o_hi.x - s_hi.x, o_hi.y - s_hi.y, o_hi.z - s_hi.z};
+  if constexpr (kHiLo<R>) {
+    d.x += o_lo.x - s_lo.x;
+    d.y += o_lo.y - s_lo.y;
+    d.z += o_lo.z - s_lo.z;
+  }
+  return d;
+}
 
 // squared cut-offs of the radial pass, derived on the host from the parameter vector
 template <typename R>
@@ -216,9 +236,10 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
 
   // ---- owner state (also parked in LDS for the block-wide angular pass)
   Nuc<R> self;
-  V3<R> offb_s;
+  V3<R> offb_s, self_lo{R(0), R(0), R(0)};
   {
     const V4 s0 = in.p0[ii], s1 = in.p1[ii], s2 = in.p2[ii], s3 = in.p3[ii];
+    if constexpr (kHiLo<R>) self_lo = xyz<R>(in.pl[ii]);
     self.c = xyz<R>(s0);
     self.a1 = xyz<R>(s1);
     self.a3 = xyz<R>(s2);
@@ -231,6 +252,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       R* sl = self_lds[grp];
       sl[0] = s0.x, sl[1] = s0.y, sl[2] = s0.z, sl[3] = s1.x, sl[4] = s1.y, sl[5] = s1.z;
       sl[6] = s2.x, sl[7] = s2.y, sl[8] = s2.z, sl[9] = s0.w;
+      sl[10] = self_lo.x, sl[11] = self_lo.y, sl[12] = self_lo.z;
     }
   }
   const int* __restrict__ row = rows + (size_t)ii * row_stride;
@@ -260,7 +282,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // kernel has to stay inside the instruction cache that two CUs share)
   {
     int e_cur = -1, e_nxt = -1;
-    V4 n0{}, n3{}, n1{};
+    V4 n0{}, n3{}, n1{}, nl{};
     {
       const int s = ROW_BONDED_SLOTS + lane;
       e_cur = (s < close_end) ? row[s] : -1;
@@ -270,13 +292,14 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         n0 = in.p0[j];
         n3 = in.p3[j];
         n1 = in.p1[j];
+        if constexpr (kHiLo<R>) nl = in.pl[j];
       }
     }
 #pragma unroll 1
     for (int s0 = ROW_BONDED_SLOTS; s0 < close_end; s0 += G) {
       const int s = s0 + lane;
       const int entry = e_cur;
-      const V4 o0 = n0, o3 = n3, o1 = n1;
+      const V4 o0 = n0, o3 = n3, o1 = n1, ol = nl;
       e_cur = e_nxt;
       e_nxt = (s + 2 * G < close_end) ? row[s + 2 * G] : -1;
       if (e_cur >= 0) {  // the close segment reads a1 as well: nearly all of its entries need it
@@ -284,11 +307,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         n0 = in.p0[jn];
         n3 = in.p3[jn];
         n1 = in.p1[jn];
+        if constexpr (kHiLo<R>) nl = in.pl[jn];
       }
       bool flag[3] = {false, false, false};
       if (entry >= 0) {
         const bool role_p = (entry & ROW_ROLE_Q) == 0;
-        const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
+        const V3<R> dco = min_image(centre_diff<R>(o0, ol, self.c, self_lo), box);
         const V3<R> offb_o = xyz<R>(o3);
         const bool close = dot(dco, dco) < cut.rcom2;
         // backbone - backbone: excluded volume + Debye-Hueckel
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // far segment: only the backbone-backbone terms (excluded volume + Debye-Hueckel) can act
   {
     int e_cur = -1, e_nxt = -1;
-    V4 n0{}, n3{};
+    V4 n0{}, n3{}, nl{};
     {
       const int s = close_end + lane;
       e_cur = (s < len) ? row[s] : -1;
@@ -378,22 +402,24 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const int j = e_cur & ROW_INDEX_MASK;
         n0 = in.p0[j];
         n3 = in.p3[j];
+        if constexpr (kHiLo<R>) nl = in.pl[j];
       }
     }
 #pragma unroll 1
     for (int s0 = close_end; s0 < len; s0 += G) {
       const int s = s0 + lane;
       const int entry = e_cur;
-      const V4 o0 = n0, o3 = n3;
+      const V4 o0 = n0, o3 = n3, ol = nl;
       e_cur = e_nxt;
       e_nxt = (s + 2 * G < len) ? row[s + 2 * G] : -1;
       if (e_cur >= 0) {
         const int jn = e_cur & ROW_INDEX_MASK;
         n0 = in.p0[jn];
         n3 = in.p3[jn];
+        if constexpr (kHiLo<R>) nl = in.pl[jn];
       }
       if (entry >= 0) {
-        const V3<R> dco = min_image(xyz<R>(o0) - self.c, box);
+        const V3<R> dco = min_image(centre_diff<R>(o0, ol, self.c, self_lo), box);
         const V3<R> d = dco + xyz<R>(o3) - offb_s;
         const R r2 = dot(d, d);
         if (r2 < cut.rbb2) {
@@ -507,6 +533,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         me.seq = mm & 3;
         me.is_end = (mm >> 2) & 1;
         const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
+        V4 ol{};
+        if constexpr (kHiLo<R>) ol = in.pl[j];
         o.c = xyz<R>(o0);
         o.a1 = xyz<R>(o1);
         o.a3 = xyz<R>(o2);
@@ -514,7 +542,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const int mo = (int)o0.w;
         o.seq = mo & 3;
         o.is_end = (mo >> 2) & 1;
-        const V3<R> dco = min_image(o.c - me.c, box);
+        const V3<R> dco = min_image(centre_diff<R>(o0, ol, me.c, V3<R>{ms[10], ms[11], ms[12]}), box);
 #ifndef MD_DBG_SKIP
 #define MD_DBG_SKIP 0
 #endif
@@ -646,6 +674,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       }
     }
     R x[3] = {self.c.x, self.c.y, self.c.z};
+    R xl[3] = {self_lds[il][10], self_lds[il][11], self_lds[il][12]};  // low part of the centre (fp32 runs)
+    R dxa[3] = {R(0), R(0), R(0)};                                      // this step's displacement
+    R* const xd = kHiLo<R> ? dxa : x;
     V3<R> n1 = self.a1, n2 = self.a2, n3 = self.a3;
     if (do_step && !(ablate & 4)) {
       p[0] += K.half_dt * F.x;
@@ -654,14 +685,25 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       L[0] += K.half_dt * tb[0];
       L[1] += K.half_dt * tb[1];
       L[2] += K.half_dt * tb[2];
-      drift(x, qs, p, L, K.half_dt, K, !(ablate & 64));
+      drift(xd, qs, p, L, K.half_dt, K, !(ablate & 64));
       p[0] = K.c1_t * p[0] + K.c2_t * z[0];
       p[1] = K.c1_t * p[1] + K.c2_t * z[1];
       p[2] = K.c1_t * p[2] + K.c2_t * z[2];
       L[0] = K.c1_r * L[0] + K.c2_r[0] * z[3];
       L[1] = K.c1_r * L[1] + K.c2_r[1] * z[4];
       L[2] = K.c1_r * L[2] + K.c2_r[2] * z[5];
-      drift(x, qs, p, L, K.half_dt, K, !(ablate & 64));
+      drift(xd, qs, p, L, K.half_dt, K, !(ablate & 64));
+      if constexpr (kHiLo<R>) {
+        // centre += displacement in (hi, lo) form: the displacement goes to the low part, then one fast two-sum
+        // re-normalises (|hi| >= |lo + d| always holds here)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const R sdl = xl[k] + dxa[k];
+          const R t = x[k] + sdl;
+          xl[k] = sdl - (t - x[k]);
+          x[k] = t;
+        }
+      }
       // keep the quaternion on the unit sphere (fp32 round-off)
       const R inv = m_rsqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
       qs[0] *= inv;
@@ -677,6 +719,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
     }
     out.p0[i] = V4{x[0], x[1], x[2], self_lds[il][9]};
+    if constexpr (kHiLo<R>) out.pl[i] = V4{xl[0], xl[1], xl[2], R(0)};
     out.p1[i] = V4{n1.x, n1.y, n1.z, R(0)};
     out.p2[i] = V4{n3.x, n3.y, n3.z, R(0)};
     out.p3[i] = V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)};
@@ -715,10 +758,22 @@ __global__ void reduce_trace_kernel(const double* __restrict__ part, int n_block
 template <typename R>
 __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c, const R* __restrict__ q,
                                   const R* __restrict__ p, const R* __restrict__ l, const int* __restrict__ meta,
-                                  const Frame<R> f, typename Vec4T<R>::type* mom, typename Vec4T<R>::type* ang) {
+                                  const Frame<R> f, typename Vec4T<R>::type* mom, typename Vec4T<R>::type* ang,
+                                  const R* __restrict__ keep_hi, const R* __restrict__ keep_lo) {
   using V4 = typename Vec4T<R>::type;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if constexpr (kHiLo<R>) {
+    // the caller holds fp32 centres; where they are still the values the last run handed out, the low parts that
+    // run kept are restored, so a trajectory advanced in several run() calls loses nothing at the seams
+    R lo[3] = {R(0), R(0), R(0)};
+    if (keep_hi) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (c[3 * i + k] == keep_hi[3 * i + k]) lo[k] = keep_lo[3 * i + k];
+    }
+    f.pl[i] = V4{lo[0], lo[1], lo[2], R(0)};
+  }
   // the kernels assume unit quaternions (torque form); normalise on entry
   R q0 = q[4 * i], q1 = q[4 * i + 1], q2 = q[4 * i + 2], q3 = q[4 * i + 3];
   const R inv = m_rsqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
@@ -736,10 +791,16 @@ __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c
 template <typename R>
 __global__ void unpack_state_kernel(int n, const Frame<R> f, const typename Vec4T<R>::type* mom,
                                     const typename Vec4T<R>::type* ang, R* __restrict__ c, R* __restrict__ q,
-                                    R* __restrict__ p, R* __restrict__ l) {
+                                    R* __restrict__ p, R* __restrict__ l, R* __restrict__ keep_hi,
+                                    R* __restrict__ keep_lo) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const auto a = f.p0[i];
+  if constexpr (kHiLo<R>) {
+    const auto lo = f.pl[i];
+    keep_hi[3 * i] = a.x, keep_hi[3 * i + 1] = a.y, keep_hi[3 * i + 2] = a.z;
+    keep_lo[3 * i] = lo.x, keep_lo[3 * i + 1] = lo.y, keep_lo[3 * i + 2] = lo.z;
+  }
   const auto b = f.q[i];
   const auto m = mom[i];
   const auto w = ang[i];
@@ -788,8 +849,11 @@ struct mythos_sim {
   // neighbour policy
   double r_cut = 0, skin = 0;
   int rebuild_every = 0;
-  // device state: two ping-pong frames of 5 vec4 arrays each (p0, p1, p2, p3, q) + momenta
-  void* frame[2][5] = {{nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}};
+  // device state: two ping-pong frames of 6 vec4 arrays each (p0, p1, p2, p3, q, pl) + momenta
+  void* frame[2][6] = {};
+  // centres as the last run handed them out (hi) and the low parts that went with them (fp32 systems)
+  void *keep_hi = nullptr, *keep_lo = nullptr;
+  bool keep_valid = false;
   void *mom = nullptr, *ang = nullptr;
   int* d_flags = nullptr;
   double* d_epart = nullptr;
@@ -847,7 +911,7 @@ template <typename R>
 static Frame<R> frame_of(const mythos_sim* sim, int k) {
   using V4 = typename Vec4T<R>::type;
   return Frame<R>{(V4*)sim->frame[k][0], (V4*)sim->frame[k][1], (V4*)sim->frame[k][2], (V4*)sim->frame[k][3],
-                  (V4*)sim->frame[k][4]};
+                  (V4*)sim->frame[k][4], (V4*)sim->frame[k][5]};
 }
 
 template <typename R, int MODEL>
@@ -870,7 +934,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
   MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, sizeof(int), st));
   hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
-                     sys->d_meta, fr[0], mom, ang);
+                     sys->d_meta, fr[0], mom, ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
+                     (const R*)sim->keep_lo);
   int cur = 0;
   const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
   const int ablate = abl ? atoi(abl) : 0;
@@ -922,7 +987,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
   MYTHOS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, fr[cur], mom, ang, center, quat, p_lin,
-                     p_ang);
+                     p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
+  sim->keep_valid = true;
   int flags = 0, ov = 0;
   MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
   MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, sys->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -998,7 +1064,8 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
   s->epart_blocks = (sys->n + kMdPPB - 1) / kMdPPB;
   bool ok = true;
   for (int k = 0; k < 2; ++k)
-    for (int a = 0; a < 5; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
+    for (int a = 0; a < 6; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
+  ok = ok && hipMalloc(&s->keep_hi, v4) == hipSuccess && hipMalloc(&s->keep_lo, v4) == hipSuccess;
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
        hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 64 * sizeof(double)) == hipSuccess &&
@@ -1017,8 +1084,10 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
 void mythos_langevin_destroy(mythos_sim_t* s) {
   if (!s) return;
   for (int k = 0; k < 2; ++k)
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < 6; ++a)
       if (s->frame[k][a]) (void)hipFree(s->frame[k][a]);
+  if (s->keep_hi) (void)hipFree(s->keep_hi);
+  if (s->keep_lo) (void)hipFree(s->keep_lo);
   if (s->mom) (void)hipFree(s->mom);
   if (s->ang) (void)hipFree(s->ang);
   if (s->d_flags) (void)hipFree(s->d_flags);

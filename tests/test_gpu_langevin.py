@@ -190,3 +190,37 @@ def test_skin_violation_is_reported():
     p, L = integ.init_momenta()
     with pytest.raises(_lib.MythosHipError, match="skin"):
         integ.run(c, q, p, L, 200)
+
+
+def test_fp32_dynamics_do_not_depend_on_where_the_system_sits():
+    """fp32 runs carry the centre as hi + lo: a duplex 4 096 length units from the origin (one fp32 ulp of a
+    coordinate there is 4.9e-4, a third of the thermal displacement per step) must evolve like the same duplex at
+    the origin.  Momenta are compared: they feel every force error, and no output rounding of large coordinates."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s, sim = _make(2, top, None, torch.float32)
+    s.set_neighbors(top.unbonded_neighbors)
+    grid = 2.0**-11  # representable at both places
+    c0 = np.round(traj.center[0] / grid) * grid
+    q0 = traj.quaternions[0]
+    shift = np.array([4096.0, 0.0, 0.0])
+
+    def run(offset, chunks):
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=9)
+        c, q = _state(c0 + offset, q0, torch.float32, s.device)
+        p, L = integ.init_momenta()
+        for n in chunks:
+            integ.run(c, q, p, L, n)
+        return c.cpu().numpy() - offset, p.cpu().numpy(), L.cpu().numpy()
+
+    x_a, p_a, l_a = run(np.zeros(3), [60])
+    x_b, p_b, l_b = run(shift, [60])
+    scale = np.abs(p_a).max()
+    assert np.abs(p_b - p_a).max() < 2e-4 * scale and np.abs(l_b - l_a).max() < 2e-4 * np.abs(l_a).max()
+    assert np.abs(x_b - x_a).max() <= 0.5 * 4.9e-4 + 1e-5  # the caller's fp32 copy is rounded, the state is not
+    # a run cut in two keeps the low parts across the seam (the caller's array is unchanged in between); what is
+    # left is the re-normalisation of the quaternions on entry, one ulp - dropping the low parts would show up
+    # at 1e-3
+    x_c, p_c, l_c = run(shift, [30, 30])
+    assert np.abs(p_c - p_b).max() < 2e-5 * scale and np.abs(l_c - l_b).max() < 2e-5 * np.abs(l_a).max()
