@@ -1,0 +1,68 @@
+"""Provenance of the golden fixtures: the DATA files the reference ships for its own tests, copied unmodified.
+
+Run in the build container (where /root/reference exists) to re-create ``tests/golden/``:
+
+    python tests/golden/copy_fixtures.py            # copies and verifies byte-for-byte
+    python tests/golden/copy_fixtures.py --check    # only verifies
+
+oxDNA goldens (``data/test-data/dna{1,2}/<case>/``): topology, the 100-frame trajectory, oxDNA's own total and
+split energies, per-pair energies and the oxDNA input file they were produced with (reference tests:
+mythos/energy/dna1/tests/test_integration.py, mythos/energy/dna2/tests/test_integration.py).
+MARTINI goldens (``data/test-data/martini/energy/m2/``): GROMACS trajectory, per-term energies, parameter JSON
+(reference tests: mythos/energy/martini/m2/tests/test_{lj,bond,angle}.py); the system definition comes from the
+text files next to the reference's binary ``.tpr`` (``data/templates/martini/m2/DMPC/273K/``).
+``oxdna_model_constants.json`` is produced by ``make_model_constants.py``.  No reference source code is copied.
+"""
+
+import argparse
+import filecmp
+import shutil
+from pathlib import Path
+
+REF = Path("/root/reference/data")
+DST = Path(__file__).resolve().parent
+
+OXDNA_FILES = ("generated.top", "output.dat", "energy.dat", "split_energy.dat", "pair.dat", "input")
+CASES = {
+    "dna1": ("simple-helix", "simple-coax", "simple-helix-seq-dep"),
+    "dna2": ("simple-helix", "simple-coax", "simple-helix-half-charged-ends"),
+}
+EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat")}
+MARTINI = {
+    "test-data/martini/energy/m2/lj": ("martini/m2/lj", ("test.trr", "lj.xvg", "ljconf.json")),
+    "test-data/martini/energy/m2/bond": ("martini/m2/bond", ("bond.xvg", "bond_params.json")),
+    "test-data/martini/energy/m2/angle": ("martini/m2/angle", ("test.trr", "angle.xvg", "angle_params.json")),
+    "templates/martini/m2/DMPC/273K": ("martini/template", ("membrane.gro", "topol.top")),
+}
+
+
+def pairs():
+    for model, cases in CASES.items():
+        for case in cases:
+            for name in (*OXDNA_FILES, *EXTRA.get((model, case), ())):
+                src = REF / "test-data" / model / case / name
+                if src.exists():
+                    yield src, DST / model / case / name
+    for src_dir, (dst_dir, names) in MARTINI.items():
+        for name in names:
+            yield REF / src_dir / name, DST / dst_dir / name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    bad = 0
+    for src, dst in pairs():
+        if not args.check:
+            dst.parent.mkdir(parents=True, exist_ok=True)
+            shutil.copyfile(src, dst)
+        if not dst.exists() or not filecmp.cmp(src, dst, shallow=False):
+            print("MISMATCH", dst.relative_to(DST))
+            bad += 1
+    print("ok" if bad == 0 else f"{bad} file(s) differ")
+    raise SystemExit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
