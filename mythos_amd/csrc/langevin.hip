@@ -167,6 +167,9 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
   return v.f;
 }
 
+// Diagnostics are compiled in only with -DMYTHOS_MD_DIAG (make DIAG=1): in the product build no stamp executes and
+// the ablation word is a compile-time zero.
+#ifdef MYTHOS_MD_DIAG
 // Diagnostic stamps (ablate bit 7): lane 0 of every wavefront records s_memtime (bit 8: the 100 MHz
 // s_memrealtime instead) at the phase boundaries
 // into the (otherwise unused) energy scratch; no output value depends on them.
@@ -176,6 +179,11 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
       reinterpret_cast<unsigned long long*>(e_part)[(((step & 1) * n_blocks + (size_t)bid) * 4 + (threadIdx.x >> 6)) * 8 + (k)] = \
           (ablate & 256) ? __builtin_amdgcn_s_memrealtime() : __builtin_readcyclecounter();           \
   } while (0)
+#define MD_ABLATE(x) (x)
+#else
+#define MD_STAMP(k) do { } while (0)
+#define MD_ABLATE(x) 0
+#endif
 
 // One MD step (see file header).  kick_close: multiple of dt*F that closes the previous step
 // (0 for the first kernel of a run, 1/2 otherwise); do_step = 0 for the closing-only kernel.
@@ -202,8 +210,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
     R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
-    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate) {
+    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate_arg) {
   using V4 = typename Vec4T<R>::type;
+  const int ablate = MD_ABLATE(ablate_arg);
   constexpr int G = kMdG, PPB = kMdPPB;
   constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
   constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
@@ -937,8 +946,12 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
                      sys->d_meta, fr[0], mom, ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
                      (const R*)sim->keep_lo);
   int cur = 0;
+#ifdef MYTHOS_MD_DIAG
   const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
   const int ablate = abl ? atoi(abl) : 0;
+#else
+  const int ablate = 0;
+#endif
   const bool dynamic_list = sim->rebuild_every > 0;
   auto rebuild = [&](int buf) -> int {
     if (int rc = rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, st)) return rc;

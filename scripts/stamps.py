@@ -1,3 +1,4 @@
+# needs the diagnostic build: make -C mythos_amd/csrc clean && make -C mythos_amd/csrc DIAG=1
 import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 4, 8).astype(np.int64)
 d = np.diff(a[:, :, :8], axis=2)  # (blocks, waves, 7)

@@ -1,4 +1,5 @@
-"""Wall-clock view of the MD kernel from s_memrealtime stamps (MYTHOS_MD_ABLATE=384): 10 ns ticks.
+"""(needs the diagnostic build: make -C mythos_amd/csrc clean && make -C mythos_amd/csrc DIAG=1)
+Wall-clock view of the MD kernel from s_memrealtime stamps (MYTHOS_MD_ABLATE=384): 10 ns ticks.
 The dump holds the last two launches (even step | odd step)."""
 import sys, numpy as np
 a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(2, -1, 4, 8).astype(np.int64)

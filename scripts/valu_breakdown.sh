@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs the diagnostic build: make -C mythos_amd/csrc clean && make -C mythos_amd/csrc DIAG=1
 # dev: dynamic VALU instructions per wavefront of md_step_kernel under the kernel's ablation bits
 # (MYTHOS_MD_ABLATE: 1 no neighbour rows, 2 no angular pass, 8 no unbonded angular lists, 16 no bonded items, 4 no integration)
 export TMPDIR=/tmp
