@@ -89,7 +89,7 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
     }
     meta[i] = seq[i] | ((is_end && is_end[i]) ? 4 : 0);
   }
-  s->h_partners.assign((size_t)2 * n, -1);
+  s->h_partners.assign((size_t)ROW_BONDED_SLOTS * n, -1);
   for (int b = 0; b < n_bonded; ++b) {
     const int i = bonded[2 * b], j = bonded[2 * b + 1];
     if (i < 0 || j < 0 || i >= n || j >= n || i == j) {
@@ -97,19 +97,24 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
       delete s;
       return nullptr;
     }
-    if (s->h_partners[2 * i + 1] != -1 || s->h_partners[2 * j + 0] != -1) {
-      set_error("mythos_oxdna_create: a nucleotide has more than one bonded partner per side");
+    int* pi = &s->h_partners[(size_t)ROW_BONDED_SLOTS * i];
+    int* pj = &s->h_partners[(size_t)ROW_BONDED_SLOTS * j];
+    const int si = pi[1] == -1 ? 1 : 3;  // i plays nn_i: odd slots
+    const int sj = pj[0] == -1 ? 0 : 2;  // j plays nn_j: even slots
+    if (pi[si] != -1 || pj[sj] != -1) {
+      set_error("mythos_oxdna_create: a nucleotide has more than two bonded partners in one role");
       delete s;
       return nullptr;
     }
-    s->h_partners[2 * i + 1] = j;  // i plays nn_i
-    s->h_partners[2 * j + 0] = i;  // j plays nn_j
+    pi[si] = j;
+    pj[sj] = i;
+    if (si == 3 || sj == 2) s->extra_bonds = true;
   }
   bool ok = hipMalloc((void**)&s->d_meta, n * sizeof(int)) == hipSuccess &&
-            hipMalloc((void**)&s->d_row_len, (size_t)4 * n * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_row_len, (size_t)(2 + ROW_BONDED_SLOTS) * n * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
             hipMemcpy(s->d_meta, meta.data(), n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(s->d_row_len + n, s->h_partners.data(), (size_t)2 * n * sizeof(int), hipMemcpyHostToDevice) ==
+            hipMemcpy(s->d_row_len + n, s->h_partners.data(), (size_t)ROW_BONDED_SLOTS * n * sizeof(int), hipMemcpyHostToDevice) ==
                 hipSuccess &&
             hipMemset(s->d_overflow, 0, sizeof(int)) == hipSuccess;
   if (!ok) {
@@ -211,7 +216,7 @@ int mythos_oxdna_neighbor_stats(mythos_system_t* s, int* max_row, double* mean_r
 
 int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat, int n_frames, double* e_terms,
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_stream_t stream) {
-  if (!s || !center || !quat || !e_terms || n_frames < 0) {
+  if (!s || n_frames < 0 || (n_frames > 0 && (!center || !quat || !e_terms))) {
     set_error("mythos_oxdna_energy: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
@@ -219,7 +224,7 @@ int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat
     set_error("mythos_oxdna_energy: parameters and neighbours must be set first");
     return MYTHOS_ERR_NOT_READY;
   }
-  if (n_frames == 0) return MYTHOS_OK;
+  if (n_frames == 0) return MYTHOS_OK;  // an empty batch (its buffers may be null) is not an error
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
   return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams,
                              (hipStream_t)stream);

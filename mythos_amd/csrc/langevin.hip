@@ -97,7 +97,7 @@ __device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const L
 constexpr int kMdBlock = 256;
 constexpr int kMdG = 8;                    // lanes per nucleotide
 constexpr int kMdPPB = kMdBlock / kMdG;    // nucleotides per workgroup
-constexpr int kMdMaxItems = 18;            // flagged unbonded neighbours per nucleotide (phase 2)
+constexpr int kMdMaxItems = 16;            // flagged unbonded neighbours per nucleotide (phase 2)
 constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 
 // Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
-    R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
+    int extra_bonds, R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos, int* __restrict__ flags,
     R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate_arg) {
   using V4 = typename Vec4T<R>::type;
   const int ablate = MD_ABLATE(ablate_arg);
@@ -497,13 +497,15 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const int lst = bonded_wave ? 0 : wave - 1;
     const int n_total = item_pre[lst][PPB];
     const int n_sweeps = (n_total + 63) / 64;
-    const int my_sweeps = bonded_wave ? ((ablate & 16) ? 0 : 1) : ((ablate & 8) ? 0 : n_sweeps);
+    // bonded wave: one sweep over slots 0 / 1 of the 32 nucleotides, and a second over slots 2 / 3 only in
+    // systems with circular strands (a ring's two ends carry a second bond in one role)
+    const int my_sweeps = bonded_wave ? ((ablate & 16) ? 0 : (extra_bonds ? 2 : 1)) : ((ablate & 8) ? 0 : n_sweeps);
     for (int sweep = 0; sweep < ((ablate & 2) ? 0 : my_sweeps); ++sweep) {
       int p, idx, sl;
       bool active;
       if (bonded_wave) {
         p = (threadIdx.x & 63) >> 1;
-        idx = threadIdx.x & 1;
+        idx = (threadIdx.x & 1) + 2 * sweep;
         sl = idx;
         active = true;
       } else {
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         p = lo;
         const int k = q - item_pre[lst][lo];
         sl = active ? (int)items[lst][p][k] : 0;
-        // result row: bonded 0..1, then the nucleotide's H-bond, cross-stacking and coaxial items
+        // result row: bonded 0..3, then the nucleotide's H-bond, cross-stacking and coaxial items
         idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0) + (lst >= 2 ? item_cnt[1][p] : 0);
       }
       const int ip = bid * PPB + p;
@@ -531,7 +533,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       for (int k = 0; k < T_COUNT; ++k) ee[k] = R(0);
       if (entry >= 0) {
         const int j = entry & ROW_INDEX_MASK;
-        const bool role_p = bonded_wave ? (sl == 1) : ((entry & ROW_ROLE_Q) == 0);
+        const bool role_p = bonded_wave ? ((sl & 1) == 1) : ((entry & ROW_ROLE_Q) == 0);
         Nuc<R> me, o;
         const R* ms = self_lds[p];
         me.c = V3<R>{ms[0], ms[1], ms[2]};
@@ -585,7 +587,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
   if (valid) {
     const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp] + item_cnt[2][grp];
-    for (int t = lane; t < total; t += G) {
+    const int skip = extra_bonds ? 0 : 2;  // rows 2, 3 (second-bond slots) exist only in systems with circular strands
+    for (int u = lane; u < total - skip; u += G) {
+      const int t = (u < 2) ? u : u + skip;
       const R* rr = res_row(grp, t);
       sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
       sg.g1 = sg.g1 + V3<R>{rr[3], rr[4], rr[5]};
@@ -977,7 +981,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
@@ -986,12 +990,12 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       // kernel trace reports), not the time between two markers in the queue
       hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
                             sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
-                            sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close, do_step,
+                            sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
                             sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
       ++samples;
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, sys->d_row_len + 3 * (size_t)n, sys->row_stride, kick_close,
+                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
                          do_step, sim->seed, (uint64_t)(sim->step + k), ref, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
     ++launches;

@@ -25,10 +25,13 @@ int hip_fail(hipError_t e, const char* what);
 // Row entry encoding of the per-nucleotide neighbour rows:
 //   slot 0 : bonded partner on the 3' side  (bond (j, self): self plays nn_j)   or -1
 //   slot 1 : bonded partner on the 5' side  (bond (self, j): self plays nn_i)   or -1
-//   slot>=2: unbonded neighbour index | ROLE_Q if self plays op_j of the ordered pair
+//   slot 2, 3: a second partner in the nn_j / nn_i role, or -1.  Only the two ends of a circular strand have one:
+//           the reference closes a ring with the pair (first, last) in that order (mythos/input/topology.py:178-180),
+//           so `first` is nn_i of two bonds and `last` is nn_j of two.  Even slots: self is nn_j; odd: self is nn_i.
+//   slot>=4: unbonded neighbour index | ROLE_Q if self plays op_j of the ordered pair
 constexpr int ROW_ROLE_Q = 1 << 30;
 constexpr int ROW_INDEX_MASK = ROW_ROLE_Q - 1;
-constexpr int ROW_BONDED_SLOTS = 2;
+constexpr int ROW_BONDED_SLOTS = 4;
 
 template <typename R>
 struct BoxT {
@@ -59,6 +62,7 @@ struct mythos_system {
   bool nbrs_set = false;
   // host copy of the bonded partners, [n][2]
   std::vector<int> h_partners;
+  bool extra_bonds = false;  // some nucleotide uses slot 2 or 3 (circular strands)
 
   // Verlet build scratch
   int* d_overflow = nullptr;  // [1] set when a row would exceed row_stride
@@ -105,6 +109,11 @@ template <>
 inline const float* device_params_of<float>(const mythos_system* s) { return s->d_pf; }
 template <>
 inline const double* device_params_of<double>(const mythos_system* s) { return s->d_pd; }
+
+// d_row_len holds three arrays back to back: row length [n] | bonded partners [n][ROW_BONDED_SLOTS] | end of the
+// "close" segment of the row [n]
+static_assert(ROW_BONDED_SLOTS == 4, "the row builders copy four partner slots");
+inline int* row_close_of(const mythos_system* sys) { return sys->d_row_len + (size_t)(1 + ROW_BONDED_SLOTS) * sys->n; }
 
 // Largest centre-centre distance at which anything other than the backbone-backbone terms (excluded
 // volume between base / backbone sites, H-bond, cross- and coaxial stacking) can act.  Rows keep the

@@ -42,8 +42,7 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
   const int stride = ((mx + ROW_BONDED_SLOTS + 15) / 16) * 16;
   std::vector<int> rows((size_t)n * stride, -1), len(n, ROW_BONDED_SLOTS);
   for (int i = 0; i < n; ++i) {
-    rows[(size_t)i * stride + 0] = sys->h_partners[2 * i + 0];
-    rows[(size_t)i * stride + 1] = sys->h_partners[2 * i + 1];
+    for (int k = 0; k < ROW_BONDED_SLOTS; ++k) rows[(size_t)i * stride + k] = sys->h_partners[(size_t)ROW_BONDED_SLOTS * i + k];
   }
   for (int k = 0; k < n_pairs; ++k) {
     const int i = pairs[2 * k], j = pairs[2 * k + 1];
@@ -54,7 +53,7 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
   MYTHOS_HIP_TRY(hipMemcpy(sys->d_rows, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
   MYTHOS_HIP_TRY(hipMemcpy(sys->d_row_len, len.data(), n * sizeof(int), hipMemcpyHostToDevice));
   // a user-supplied pair list carries no distance classes: every entry is in the "close" segment
-  MYTHOS_HIP_TRY(hipMemcpy(sys->d_row_len + 3 * (size_t)n, len.data(), n * sizeof(int), hipMemcpyHostToDevice));
+  MYTHOS_HIP_TRY(hipMemcpy(row_close_of(sys), len.data(), n * sizeof(int), hipMemcpyHostToDevice));
   sys->nbrs_set = true;
   return 0;
 }
@@ -78,13 +77,14 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
   constexpr int S = VEC4 ? 4 : 3;
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
   int* row = rows + (size_t)i * row_stride;
-  const int b0 = partners_rows_in[2 * i], b1 = partners_rows_in[2 * i + 1];
+  const int* bq = partners_rows_in + (size_t)ROW_BONDED_SLOTS * i;
+  const int4 bp = make_int4(bq[0], bq[1], bq[2], bq[3]);
   int cnt = ROW_BONDED_SLOTS, n_close = 0;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0: "close" segment (r2 < rcl2), pass 1: the rest of the list
     for (int j0 = 0; j0 < n; j0 += 64) {
       const int j = j0 + lane;
       bool hit = false;
-      if (j < n && j != i && j != b0 && j != b1) {
+      if (j < n && j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         V3<R> d{pos[S * j] - ci.x, pos[S * j + 1] - ci.y, pos[S * j + 2] - ci.z};
         d = min_image(d, box);
         const R r2 = dot(d, d);
@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
     if (pass == 0) n_close = cnt;
   }
   if (lane == 0) {
-    row[0] = b0;
-    row[1] = b1;
+    row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
     if (cnt > row_stride) {
       atomicMax(overflow, cnt);
       cnt = row_stride;
@@ -161,7 +160,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int total = __shfl(inc, 26, 64);
   int* row = rows + (size_t)i * row_stride;
-  const int b0 = partners[2 * i], b1 = partners[2 * i + 1];
+  const int* bq = partners + (size_t)ROW_BONDED_SLOTS * i;
+  const int4 bp = make_int4(bq[0], bq[1], bq[2], bq[3]);
   int out = ROW_BONDED_SLOTS, n_close = 0;
   for (int pass = 0; pass < 2; ++pass) {  // pass 0: "close" segment, pass 1: the rest
   for (int t0 = 0; t0 < total; t0 += 64) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
         if (s_pre[w][mid] <= t) lo = mid; else hi = mid;
       }
       j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
-      if (j != i && j != b0 && j != b1) {
+      if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
         int jx, jy, jz;
         cell_of(g, xj, yj, zj, jx, jy, jz);
@@ -197,8 +197,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   if (pass == 0) n_close = out;
   }
   if (lane == 0) {
-    row[0] = b0;
-    row[1] = b1;
+    row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
     if (out > row_stride) {
       atomicMax(overflow, out);
       out = row_stride;
@@ -213,7 +212,7 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const int n = sys->n;
   // classification radius of the leading "close" segment (everything is close until parameters exist)
   const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
-  int* d_close = sys->d_row_len + 3 * (size_t)n;
+  int* d_close = row_close_of(sys);
   CellGrid<R> g;
   bool ok = true;
   for (int k = 0; k < 3; ++k) {

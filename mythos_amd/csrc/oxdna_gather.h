@@ -90,7 +90,7 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
     if (entry < 0) continue;
     const int j = entry & ROW_INDEX_MASK;
     const bool bonded = s < ROW_BONDED_SLOTS;
-    const bool role_p = bonded ? (s == 1) : ((entry & ROW_ROLE_Q) == 0);
+    const bool role_p = bonded ? ((s & 1) == 1) : ((entry & ROW_ROLE_Q) == 0);
     Nuc<R> other;
     R q4[4];
     ld.load(j, other, q4);

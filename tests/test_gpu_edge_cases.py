@@ -1,0 +1,131 @@
+"""Edge cases of the oxDNA path through the C ABI: empty and ragged inputs, circular strands (the bonded pair
+(first, last) the reference appends, mythos/input/topology.py:178-180), one-nucleotide strands, an empty
+neighbour list, zero frames, zero steps, and a ring whose closing bond is far outside the FENE well (the smoothed
+branch of mythos/energy/dna1/interactions.py:16-41)."""
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd import _lib
+from mythos_amd.energy import flat_params as fp
+from mythos_amd.input import defaults, topology
+from oracle import oxdna_oracle as orc
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _system(model, top, box, dtype=torch.float64, hce=False):
+    from mythos_amd.hip_system import OxdnaSystem
+
+    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=dtype)
+    s.set_params(flat)
+    return s
+
+
+def _oracle(model, top, c, q, box, pairs, hce=False):
+    P = H.oracle_params(model, half_charged_ends=hce)
+    tt = (torch.as_tensor(top.seq, dtype=torch.long), torch.as_tensor(top.is_end, dtype=torch.long),
+          torch.as_tensor(top.bonded_neighbors, dtype=torch.long).reshape(-1, 2), torch.as_tensor(pairs, dtype=torch.long).reshape(-1, 2))
+    e = orc.energy_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), *tt, box=box)
+    _, gc, gq = orc.energy_and_grads(model, P, torch.as_tensor(c), torch.as_tensor(q), *tt, box=box)
+    return e.numpy(), gc.numpy(), gq.numpy()
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_circular_strands_and_the_smoothed_fene_branch(model):
+    ref_top, traj, _, _ = H.load_golden(model, "simple-helix")
+    top = topology.from_arrays(ref_top.seq, ref_top.strand_counts, is_circular=[True, True])
+    assert len(top.bonded_neighbors) == len(ref_top.bonded_neighbors) + 2 and top.is_end.sum() == 0
+    c, q = traj.center[3], traj.quaternions[3]
+    s = _system(model, top, traj.box_size)
+    s.set_neighbors(top.unbonded_neighbors)
+    e, gc, gq, _ = s.energy(torch.as_tensor(c, device=s.device), torch.as_tensor(q, device=s.device), grads=True)
+    e_ref, gc_ref, gq_ref = _oracle(model, top, c, q, traj.box_size, top.unbonded_neighbors)
+    n_terms = 7 if model == 1 else 8
+    np.testing.assert_allclose(e.cpu().numpy()[:n_terms], e_ref[:n_terms], rtol=1e-9, atol=1e-9)
+    assert e_ref[0] > 10.0  # the two closing bonds span the helix: far beyond the FENE well, finite by smoothing
+    np.testing.assert_allclose(gc.cpu().numpy(), gc_ref, rtol=0, atol=1e-8 * np.abs(gc_ref).max())
+    np.testing.assert_allclose(gq.cpu().numpy(), gq_ref, rtol=0, atol=1e-8 * np.abs(gq_ref).max())
+
+
+def test_ragged_strands_single_nucleotides_and_empty_lists():
+    ref_top, traj, _, _ = H.load_golden(2, "simple-helix")
+    # 16 nucleotides cut into strands of 1, 5, 1, 2, 7: two strands have no bond at all
+    top = topology.from_arrays(ref_top.seq, [1, 5, 1, 2, 7])
+    assert len(top.bonded_neighbors) == 16 - 5
+    c, q = traj.center[0], traj.quaternions[0]
+    s = _system(2, top, traj.box_size, hce=True)
+    cd, qd = torch.as_tensor(c, device=s.device), torch.as_tensor(q, device=s.device)
+    s.set_neighbors(top.unbonded_neighbors)
+    e, gc, gq, _ = s.energy(cd, qd, grads=True)
+    e_ref, gc_ref, gq_ref = _oracle(2, top, c, q, traj.box_size, top.unbonded_neighbors, hce=True)
+    np.testing.assert_allclose(e.cpu().numpy(), e_ref, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gc.cpu().numpy(), gc_ref, rtol=0, atol=1e-8 * np.abs(gc_ref).max())
+    # empty unbonded list: only the bonded terms survive
+    s.set_neighbors(np.zeros((0, 2), dtype=np.int32))
+    e0 = s.energy(cd, qd)[0].cpu().numpy()
+    e0_ref, _, _ = _oracle(2, top, c, q, traj.box_size, np.zeros((0, 2), dtype=np.int64), hce=True)
+    np.testing.assert_allclose(e0, e0_ref, rtol=1e-9, atol=1e-9)
+    assert np.all(e0[3:] == 0.0)
+    # zero frames: nothing to do, shapes kept
+    ez, gz, _, _ = s.energy(cd[None][:0], qd[None][:0], grads=True)
+    assert ez.shape == (0, 8) and gz.shape == (0, 16, 3)
+
+
+def test_zero_steps_and_one_nucleotide_system():
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+
+    ref_top, traj, _, _ = H.load_golden(2, "simple-helix")
+    s = _system(2, ref_top, traj.box_size, dtype=torch.float32)
+    s.set_neighbors(ref_top.unbonded_neighbors)
+    integ = LangevinIntegrator(s, dt=0.005, kT=0.1, gamma_t=0.04, gamma_r=0.013, seed=1)
+    c = torch.as_tensor(traj.center[0], dtype=torch.float32, device=s.device).contiguous()
+    q = torch.as_tensor(traj.quaternions[0], dtype=torch.float32, device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    c0, p0 = c.clone(), p.clone()
+    tc, tq, et = integ.run(c, q, p, L, 0)
+    assert tc is None and torch.equal(c, c0) and torch.equal(p, p0) and integ.step == 0
+    # a free nucleotide: no forces at all, pure Ornstein-Uhlenbeck motion, and still finite
+    one = topology.from_arrays(np.array([2]), [1])
+    s1 = OxdnaSystem(2, one.seq, one.is_end, one.bonded_neighbors.reshape(-1, 2), box=None, dtype=torch.float64)
+    sim, cfg = defaults.default_configs_for("dna2")
+    s1.set_params(fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names()))
+    s1.set_neighbors(np.zeros((0, 2), dtype=np.int32))
+    e = s1.energy(torch.zeros((1, 3), dtype=torch.float64, device=s1.device),
+                  torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float64, device=s1.device))[0]
+    assert torch.all(e == 0)
+    i1 = LangevinIntegrator(s1, dt=0.005, kT=0.1, gamma_t=0.04, gamma_r=0.013, seed=2)
+    c1 = torch.zeros((1, 3), dtype=torch.float64, device=s1.device)
+    q1 = torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float64, device=s1.device)
+    p1, L1 = i1.init_momenta()
+    i1.run(c1, q1, p1, L1, 50)
+    assert torch.isfinite(c1).all() and abs(float(q1.norm()) - 1.0) < 1e-12 and float(c1.abs().max()) > 0
+
+
+def test_md_kernel_with_circular_strands_matches_the_oracle_step_by_step():
+    """The MD kernel's bonded wave makes a second sweep for the ring-closing bonds (slots 2 / 3)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle.langevin_oracle import LangevinOracle
+
+    ref_top, traj, _, _ = H.load_golden(2, "simple-helix")
+    top = topology.from_arrays(ref_top.seq, ref_top.strand_counts, is_circular=[True, False])
+    s = _system(2, top, traj.box_size)
+    s.set_neighbors(top.unbonded_neighbors)
+    kT = 0.0987
+    integ = LangevinIntegrator(s, dt=0.0005, kT=kT, gamma_t=0.04, gamma_r=0.013, seed=77)  # small dt: the ring bond pulls hard
+    c = torch.as_tensor(traj.center[0], device=s.device).contiguous()
+    q = torch.as_tensor(traj.quaternions[0], device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x0, q0, p0, L0 = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    tc, tq, et = integ.run(c, q, p, L, 4, save_every=1)
+    o = LangevinOracle(2, H.oracle_params(2), H.topo_tensors(top), traj.box_size, 0.0005, kT, 0.04, 0.013, 1.0, (1.0, 1.0, 1.0), seed=77)
+    x, qq, pp, LL = x0, q0, p0, L0
+    for k in range(4):
+        x, qq, pp, LL, u = o.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-9)
+        assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
