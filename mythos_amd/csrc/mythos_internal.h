@@ -69,6 +69,7 @@ struct mythos_system {
   int* d_cell = nullptr;      // hashed cell list scratch: cnt[H] start[H+1] slot_of[n] bucket[n]
   size_t cell_cap = 0;
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)
+  void* d_ref_off = nullptr;  // [n] real4 backbone offsets at the last build
 
   // parameters
   bool params_set = false;
@@ -136,8 +137,9 @@ int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream);
 // neighbors.hip
 int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs);
+// backbone_offsets: real4 per nucleotide (MD frames) to refine the far segment by backbone distance, or null
 int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
-                      hipStream_t stream);
+                      const void* backbone_offsets, hipStream_t stream);
 int rows_reserve(mythos_system* sys, int stride);
 
 }  // namespace mythos

@@ -63,9 +63,21 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
 // of 64 (coalesced position reads served from L2) and appends hits by ballot compaction, which
 // keeps each row in ascending index order.  O(N^2) work: the exact reference for the cell build.
 // ------------------------------------------------------------------------------------------------
+// Far-segment refinement: beyond the close range only the backbone-backbone terms act, so when the backbone
+// offsets are known (MD frames) a pair is listed only if its BACKBONE sites are within their range + skin - in a
+// duplex that keeps ~4 of the ~18 pairs a centre-distance criterion would list.  off = real4 per nucleotide
+// (backbone offset k1 a1 + k2 a2) or null (centre criterion only).
+template <typename R>
+__device__ __forceinline__ bool far_in_range(const R* __restrict__ off, int i, int j, const V3<R>& d, R rbb2) {
+  if (!off) return true;
+  const V3<R> e{d.x + off[4 * j] - off[4 * i], d.y + off[4 * j + 1] - off[4 * i + 1], d.z + off[4 * j + 2] - off[4 * i + 2]};
+  return dot(e, e) < rbb2;
+}
+
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R* __restrict__ pos,
                                                                    const BoxT<R> box, R rc2, R rcl2,
+                                                                   const R* __restrict__ off, R rbb2,
                                                                    const int* __restrict__ partners_rows_in,
                                                                    int* __restrict__ rows, int* __restrict__ row_len,
                                                                    int* __restrict__ row_close, int row_stride,
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
         V3<R> d{pos[S * j] - ci.x, pos[S * j + 1] - ci.y, pos[S * j + 2] - ci.z};
         d = min_image(d, box);
         const R r2 = dot(d, d);
-        hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2);
+        hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2 && far_in_range<R>(off, i, j, d, rbb2));
       }
       const unsigned long long m = __ballot(hit);
       if (hit) {
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* __restrict__ pos, const BoxT<R> box,
                                                                 const CellGrid<R> g, R rc2, R rcl2,
+                                                                const R* __restrict__ off, R rbb2,
                                                                 const int* __restrict__ partners,
                                                                 const int* __restrict__ start,
                                                                 const int* __restrict__ bucket, int* __restrict__ rows,
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
           V3<R> d{xj - ci.x, yj - ci.y, zj - ci.z};
           d = min_image(d, box);
           const R r2 = dot(d, d);
-          hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2);
+          hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2 && far_in_range<R>(off, i, j, d, rbb2));
         }
       }
     }
@@ -208,11 +221,21 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
 }
 
 template <typename R>
-static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, double skin, hipStream_t st) {
+static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, double skin, const R* off,
+                             hipStream_t st) {
   const int n = sys->n;
   // classification radius of the leading "close" segment (everything is close until parameters exist)
   const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
   int* d_close = row_close_of(sys);
+  // range of the backbone-backbone terms (excluded volume, and Debye-Hueckel in oxDNA2) for the far segment
+  double rbb = rl;
+  if (off && sys->params_set) {
+    rbb = sys->pd[NEXC_BACKBONE_RC];
+    if (sys->model == 2) rbb = std::max(rbb, (double)sys->pd[DH_RCUT]);
+    rbb = std::min(rl, rbb + skin);
+  }
+  if (!sys->params_set) off = nullptr;
+  const R rbb2 = R(rbb * rbb);
   CellGrid<R> g;
   bool ok = true;
   for (int k = 0; k < 3; ++k) {
@@ -234,10 +257,10 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   if (!ok || n < 512) {  // tiny systems / boxes under three cells: the all-pairs sweep is exact and cheap
     if (vec4)
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, true>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), R(rcl * rcl), d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), off, rbb2, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
     else
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, false>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), R(rcl * rcl), d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), off, rbb2, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
     return 0;
   }
   const int H = next_pow2(2 * n);
@@ -259,26 +282,26 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const int wb = (n + 3) / 4;
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), off, rbb2, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), off, rbb2, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow);
   return 0;
 }
 
 int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
-                      hipStream_t stream) {
+                      const void* backbone_offsets, hipStream_t stream) {
   if (sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
   const double rl = r_cut + skin;
   MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, sizeof(int), stream));
   int rc;
   if (sys->dtype == MYTHOS_F32)
-    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, stream);
+    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, (const float*)backbone_offsets, stream);
   else
-    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, skin, stream);
+    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, skin, (const double*)backbone_offsets, stream);
   if (rc) return rc;
   MYTHOS_HIP_TRY(hipGetLastError());
   sys->nbrs_set = true;
