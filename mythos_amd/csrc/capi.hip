@@ -135,6 +135,7 @@ void mythos_oxdna_destroy(mythos_system_t* s) {
   if (s->d_cell) (void)hipFree(s->d_cell);
   if (s->d_ref_pos) (void)hipFree(s->d_ref_pos);
   if (s->d_ref_off) (void)hipFree(s->d_ref_off);
+  if (s->d_ref_a1) (void)hipFree(s->d_ref_a1);
   if (s->d_pf) (void)hipFree(s->d_pf);
   if (s->d_pd) (void)hipFree(s->d_pd);
   if (s->d_epart) (void)hipFree(s->d_epart);
@@ -185,7 +186,7 @@ int mythos_oxdna_build_neighbors(mythos_system_t* s, const void* center, double 
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
   for (int attempt = 0; attempt < 4; ++attempt) {
-    if (int rc = rows_build_device(s, center, false, r_cut, skin, nullptr, st)) return rc;
+    if (int rc = rows_build_device(s, center, false, r_cut, skin, nullptr, nullptr, false, st)) return rc;
     int ov = 0;
     MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, s->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     MYTHOS_HIP_TRY(hipStreamSynchronize(st));

@@ -136,10 +136,11 @@ static __global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, 
 // One wavefront per bucket: buckets of up to 64 entries (all of them in practice: a cell holds a few tens of
 // particles) are sorted by a 64-lane bitonic network on registers, longer ones by one lane serially.
 static __global__ __launch_bounds__(256) void cell_sort_kernel(int m, const int* __restrict__ start,
-                                                               int* __restrict__ bucket) {
+                                                               int* __restrict__ bucket, int* __restrict__ cursor) {
   const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (h >= m) return;
+  if (lane == 0) cursor[h] = 0;  // the fill cursor: left clean for the next build (no memset between builds)
   const int lo = start[h], cnt = start[h + 1] - lo;
   if (cnt <= 1) return;
   if (cnt <= 64) {
@@ -184,17 +185,19 @@ struct CellScratch {
 };
 
 // count, scan, fill and sort for n particles at pos (stride 3 or 4 reals); H = table size (power of two)
+// clean: the counters are known to be zero (left so by the previous build on the same scratch and table size)
 template <typename R, bool VEC4>
-static inline int cell_list_build(int n, const R* pos, CellGrid<R>& g, int H, const CellScratch& cs, hipStream_t st) {
+static inline int cell_list_build(int n, const R* pos, CellGrid<R>& g, int H, const CellScratch& cs, bool clean,
+                                  hipStream_t st) {
   if (!g.direct) g.hmask = H - 1;
-  if (hipMemsetAsync(cs.cnt, 0, (size_t)H * sizeof(int), st) != hipSuccess) return -1;
+  if (!clean && hipMemsetAsync(cs.cnt, 0, (size_t)H * sizeof(int), st) != hipSuccess) return -1;
   const int tb = (n + 255) / 256;
   hipLaunchKernelGGL((cell_count_kernel<R, VEC4>), dim3(tb), dim3(256), 0, st, n, pos, g, cs.slot_of, cs.cnt);
   const int nsb = (H + kScanPerBlock - 1) / kScanPerBlock;
   hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nsb), dim3(kScanBlock), 0, st, H, cs.cnt, cs.start, cs.block_sum);
   hipLaunchKernelGGL(cell_scan_fix_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, st, H, nsb, cs.block_sum, cs.start);
   hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, cs.slot_of, cs.start, cs.cnt, cs.bucket);
-  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 3) / 4), dim3(256), 0, st, H, cs.start, cs.bucket);
+  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 3) / 4), dim3(256), 0, st, H, cs.start, cs.bucket, cs.cnt);
   return 0;
 }
 

@@ -210,7 +210,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
     int extra_bonds, R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos,
-    const typename Vec4T<R>::type* __restrict__ ref_off, int* __restrict__ flags,
+    const typename Vec4T<R>::type* __restrict__ ref_off, const typename Vec4T<R>::type* __restrict__ ref_a1,
+    int* __restrict__ flags,
     R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate_arg) {
   using V4 = typename Vec4T<R>::type;
   const int ablate = MD_ABLATE(ablate_arg);
@@ -727,13 +728,18 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
       quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
       if (K.skin_half_sq > R(0)) {
-        // the list is valid while neither the centre nor the backbone site (the far segment is selected by
-        // backbone distance, and a rotation moves that site) has travelled more than skin / 2 since the build
-        const V4 r0 = ref_pos[i], f0 = ref_off[i];
+        // the list is valid while neither the centre nor the backbone and base sites (the segments are selected
+        // by site distances, and a rotation moves the sites) have travelled more than skin / 2 since the build
+        const V4 r0 = ref_pos[i], f0 = ref_off[i], a0 = ref_a1[i];
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
         const R bx = dx + (g_k1 * n1.x + g_k2 * n2.x - f0.x), by = dy + (g_k1 * n1.y + g_k2 * n2.y - f0.y),
                 bz = dz + (g_k1 * n1.z + g_k2 * n2.z - f0.z);
-        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq || bx * bx + by * by + bz * bz > K.skin_half_sq) atomicOr(flags, 1);
+        // base site c + g_base a1 (the stacking site lies between it and the centre)
+        const R gb = P[GEO_BASE];
+        const R sx = dx + gb * (n1.x - a0.x), sy = dy + gb * (n1.y - a0.y), sz = dz + gb * (n1.z - a0.z);
+        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq || bx * bx + by * by + bz * bz > K.skin_half_sq ||
+            sx * sx + sy * sy + sz * sz > K.skin_half_sq)
+          atomicOr(flags, 1);
       }
     }
     out.p0[i] = V4{x[0], x[1], x[2], self_lds[il][9]};
@@ -963,10 +969,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
 #endif
   const bool dynamic_list = sim->rebuild_every > 0;
   auto rebuild = [&](int buf) -> int {
-    if (int rc = rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, st)) return rc;
-    MYTHOS_HIP_TRY(hipMemcpyAsync(sys->d_ref_pos, fr[buf].p0, (size_t)n * sizeof(V4), hipMemcpyDeviceToDevice, st));
-    MYTHOS_HIP_TRY(hipMemcpyAsync(sys->d_ref_off, fr[buf].p3, (size_t)n * sizeof(V4), hipMemcpyDeviceToDevice, st));
-    return 0;
+    return rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, fr[buf].p1, true, st);
   };
   if (dynamic_list)
     if (int rc = rebuild(cur)) return rc;
@@ -985,11 +988,12 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     R* tq = (save && traj_quat) ? traj_quat + (size_t)sidx * n * 4 : nullptr;
     const V4* ref = (const V4*)sys->d_ref_pos;
     const V4* ref_off = (const V4*)sys->d_ref_off;
+    const V4* ref_a1 = (const V4*)sys->d_ref_a1;
     const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else if (sampled) {
@@ -998,12 +1002,12 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
                             sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
                             sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
-                            sim->seed, (uint64_t)(sim->step + k), ref, ref_off, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                            sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
       ++samples;
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
     }
     ++launches;
     cur ^= 1;
@@ -1098,6 +1102,7 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
     ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;
   if (ok && !sys->d_ref_pos) ok = hipMalloc(&sys->d_ref_pos, v4) == hipSuccess;
   if (ok && !sys->d_ref_off) ok = hipMalloc(&sys->d_ref_off, v4) == hipSuccess;
+  if (ok && !sys->d_ref_a1) ok = hipMalloc(&sys->d_ref_a1, v4) == hipSuccess;
   if (!ok) {
     set_error("mythos_langevin_create: device allocation failed");
     mythos_langevin_destroy(s);

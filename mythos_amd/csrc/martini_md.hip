@@ -441,6 +441,7 @@ struct mythos_martini_sim {
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;
+  int cell_clean_H = 0;  // table size for which the cell counters are known to be zero
   int row_stride = 160;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -492,9 +493,12 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
       sim->cell_cap = 0;
       MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_cell, need * sizeof(int)));
       sim->cell_cap = need;
+      sim->cell_clean_H = 0;
     }
     const CellScratch cs(sim->d_cell, H, n);
-    if (cell_list_build<R, true>(n, reinterpret_cast<const R*>(pos), g, H, cs, st) != 0) {
+    const bool clean = sim->cell_clean_H == H;
+    sim->cell_clean_H = H;
+    if (cell_list_build<R, true>(n, reinterpret_cast<const R*>(pos), g, H, cs, clean, st) != 0) {
       set_error("martini neighbour build: cell-list scratch memset failed");
       return MYTHOS_ERR_HIP;
     }

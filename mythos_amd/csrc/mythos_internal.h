@@ -68,8 +68,10 @@ struct mythos_system {
   int* d_overflow = nullptr;  // [1] set when a row would exceed row_stride
   int* d_cell = nullptr;      // hashed cell list scratch: cnt[H] start[H+1] slot_of[n] bucket[n]
   size_t cell_cap = 0;
+  int cell_clean_H = 0;  // table size for which the cell counters are known to be zero (0: unknown)
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)
   void* d_ref_off = nullptr;  // [n] real4 backbone offsets at the last build
+  void* d_ref_a1 = nullptr;   // [n] real4 base vectors at the last build
 
   // parameters
   bool params_set = false;
@@ -137,9 +139,11 @@ int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream);
 // neighbors.hip
 int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs);
-// backbone_offsets: real4 per nucleotide (MD frames) to refine the far segment by backbone distance, or null
+// backbone_offsets, base_vectors: real4 per nucleotide (MD frames) to select the segments by site distances, or null
 int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
-                      const void* backbone_offsets, hipStream_t stream);
+                      const void* backbone_offsets, const void* base_vectors, bool write_refs, hipStream_t stream);
+// write_refs: also store the positions / backbone offsets / base vectors the list was built from in
+// d_ref_pos / d_ref_off / d_ref_a1 (the MD kernel's displacement check compares against them)
 int rows_reserve(mythos_system* sys, int stride);
 
 }  // namespace mythos

@@ -67,17 +67,52 @@ int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs) {
 // offsets are known (MD frames) a pair is listed only if its BACKBONE sites are within their range + skin - in a
 // duplex that keeps ~4 of the ~18 pairs a centre-distance criterion would list.  off = real4 per nucleotide
 // (backbone offset k1 a1 + k2 a2) or null (centre criterion only).
+// The same idea for the close segment: with the base vectors a1 known, a pair belongs to it only if one of its
+// base-base (H-bond, cross-stacking, excluded volume), stack-stack (coaxial) or backbone-base site distances is
+// within range + skin - ~10 entries in a duplex instead of the ~17 inside the orientation-independent centre range.
 template <typename R>
-__device__ __forceinline__ bool far_in_range(const R* __restrict__ off, int i, int j, const V3<R>& d, R rbb2) {
-  if (!off) return true;
-  const V3<R> e{d.x + off[4 * j] - off[4 * i], d.y + off[4 * j + 1] - off[4 * i + 1], d.z + off[4 * j + 2] - off[4 * i + 2]};
-  return dot(e, e) < rbb2;
+struct SiteCrit {
+  const R* off;  // backbone offsets, real4 per nucleotide; null: centre criteria only
+  const R* a1;   // base vectors, real4 per nucleotide
+  R rbb2;        // (backbone-backbone range + skin)^2
+  R rbase2, rstack2, rkb2;  // (range + skin)^2 of the base-base, stack-stack and backbone-base site pairs
+  R g_ba, g_st;  // site positions along a1
+};
+
+template <typename R>
+__device__ __forceinline__ bool far_in_range(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
+  if (!sc.off) return true;
+  const R* oi = sc.off + 4 * i;
+  const R* oj = sc.off + 4 * j;
+  const V3<R> e{d.x + oj[0] - oi[0], d.y + oj[1] - oi[1], d.z + oj[2] - oi[2]};
+  return dot(e, e) < sc.rbb2;
+}
+
+// d = centre_j - centre_i (minimum image), already known to be inside the centre range of the close segment
+template <typename R>
+__device__ __forceinline__ bool site_close(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
+  if (!sc.off) return true;
+  const R* ai = sc.a1 + 4 * i;
+  const R* aj = sc.a1 + 4 * j;
+  const R* oi = sc.off + 4 * i;
+  const R* oj = sc.off + 4 * j;
+  const V3<R> da{aj[0] - ai[0], aj[1] - ai[1], aj[2] - ai[2]};
+  V3<R> e = d;
+  axpy(e, sc.g_ba, da);
+  if (dot(e, e) < sc.rbase2) return true;
+  e = d;
+  axpy(e, sc.g_st, da);
+  if (dot(e, e) < sc.rstack2) return true;
+  e = V3<R>{d.x + sc.g_ba * aj[0] - oi[0], d.y + sc.g_ba * aj[1] - oi[1], d.z + sc.g_ba * aj[2] - oi[2]};  // base_j - back_i
+  if (dot(e, e) < sc.rkb2) return true;
+  e = V3<R>{d.x + oj[0] - sc.g_ba * ai[0], d.y + oj[1] - sc.g_ba * ai[1], d.z + oj[2] - sc.g_ba * ai[2]};  // back_j - base_i
+  return dot(e, e) < sc.rkb2;
 }
 
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R* __restrict__ pos,
                                                                    const BoxT<R> box, R rc2, R rcl2,
-                                                                   const R* __restrict__ off, R rbb2,
+                                                                   const SiteCrit<R> sc,
                                                                    const int* __restrict__ partners_rows_in,
                                                                    int* __restrict__ rows, int* __restrict__ row_len,
                                                                    int* __restrict__ row_close, int row_stride,
@@ -100,7 +135,10 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
         V3<R> d{pos[S * j] - ci.x, pos[S * j + 1] - ci.y, pos[S * j + 2] - ci.z};
         d = min_image(d, box);
         const R r2 = dot(d, d);
-        hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2 && far_in_range<R>(off, i, j, d, rbb2));
+        if (r2 < rc2) {
+          const bool cl = r2 < rcl2 && site_close(sc, i, j, d);
+          hit = (pass == 0) ? cl : (!cl && far_in_range(sc, i, j, d));
+        }
       }
       const unsigned long long m = __ballot(hit);
       if (hit) {
@@ -135,13 +173,16 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
 template <typename R, bool VEC4>
 __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* __restrict__ pos, const BoxT<R> box,
                                                                 const CellGrid<R> g, R rc2, R rcl2,
-                                                                const R* __restrict__ off, R rbb2,
+                                                                const SiteCrit<R> sc,
                                                                 const int* __restrict__ partners,
                                                                 const int* __restrict__ start,
                                                                 const int* __restrict__ bucket, int* __restrict__ rows,
                                                                 int* __restrict__ row_len, int* __restrict__ row_close,
-                                                                int row_stride, int* __restrict__ overflow) {
-  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
+                                                                int row_stride, int* __restrict__ overflow,
+                                                                R* __restrict__ ref_pos, R* __restrict__ ref_off,
+                                                                R* __restrict__ ref_a1) {
+  constexpr int kFarCap = 96;
+  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3], s_far[4][kFarCap];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
   if (i >= n) return;
@@ -175,54 +216,83 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   int* row = rows + (size_t)i * row_stride;
   const int* bq = partners + (size_t)ROW_BONDED_SLOTS * i;
   const int4 bp = make_int4(bq[0], bq[1], bq[2], bq[3]);
-  int out = ROW_BONDED_SLOTS, n_close = 0;
-  for (int pass = 0; pass < 2; ++pass) {  // pass 0: "close" segment, pass 1: the rest
+  // One sweep over the candidates: a close entry goes straight to its slot, a far one is parked in LDS and
+  // appended behind the close segment afterwards (both in candidate order, so the row is reproducible).
+  int out_c = ROW_BONDED_SLOTS, out_f = 0;
+  int lo = 0;  // cell of this lane's candidate: t grows by 64 per sweep, so it only ever advances
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
-    bool hit = false;
+    bool hit_c = false, hit_f = false;
     int j = -1;
     if (t < total) {
-      int lo = 0, hi = 27;  // largest cell index with s_pre[cell] <= t
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (s_pre[w][mid] <= t) lo = mid; else hi = mid;
-      }
+      while (s_pre[w][lo + 1] <= t) ++lo;
       j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
       if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
-        int jx, jy, jz;
-        cell_of(g, xj, yj, zj, jx, jy, jz);
-        if (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]) {
+        bool mine = true;  // hashed table: a bucket may mix cells, a candidate counts for the cell it lies in
+        if (!g.direct) {
+          int jx, jy, jz;
+          cell_of(g, xj, yj, zj, jx, jy, jz);
+          mine = jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2];
+        }
+        if (mine) {
           V3<R> d{xj - ci.x, yj - ci.y, zj - ci.z};
           d = min_image(d, box);
           const R r2 = dot(d, d);
-          hit = (pass == 0) ? (r2 < rcl2) : (r2 >= rcl2 && r2 < rc2 && far_in_range<R>(off, i, j, d, rbb2));
+          if (r2 < rc2) {
+            hit_c = r2 < rcl2 && site_close(sc, i, j, d);
+            hit_f = !hit_c && far_in_range(sc, i, j, d);
+          }
         }
       }
     }
-    const unsigned long long m = __ballot(hit);
-    if (hit) {
-      const int slot = out + __popcll(m & ((1ull << lane) - 1ull));
-      if (slot < row_stride) row[slot] = (j < i) ? (j | ROW_ROLE_Q) : j;
+    const int e = (j < i) ? (j | ROW_ROLE_Q) : j;
+    const unsigned long long mc = __ballot(hit_c), mf = __ballot(hit_f);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (hit_c) {
+      const int slot = out_c + __popcll(mc & below);
+      if (slot < row_stride) row[slot] = e;
     }
-    out += __popcll(m);
+    if (hit_f) {
+      const int k = out_f + __popcll(mf & below);
+      if (k < kFarCap) s_far[w][k] = e;
+    }
+    out_c += __popcll(mc);
+    out_f += __popcll(mf);
   }
-  if (pass == 0) n_close = out;
-  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int n_close = out_c;
+  int out = out_c + out_f;
+  for (int k = lane; k < min(out_f, kFarCap); k += 64)
+    if (out_c + k < row_stride) row[out_c + k] = s_far[w][k];
   if (lane == 0) {
     row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
-    if (out > row_stride) {
-      atomicMax(overflow, out);
-      out = row_stride;
+    if (out > row_stride || out_f > kFarCap) {
+      atomicMax(overflow, max(out, ROW_BONDED_SLOTS + out_f));
+      out = min(out, row_stride);
     }
     row_len[i] = out;
     row_close[i] = min(n_close, out);
+    if (ref_pos) {  // what the MD displacement check compares against: the state this list was built from
+      R* rp = ref_pos + 4 * (size_t)i;
+      rp[0] = ci.x, rp[1] = ci.y, rp[2] = ci.z, rp[3] = VEC4 ? pos[S * i + 3] : R(0);
+      if (sc.off) {
+        R* ro = ref_off + 4 * (size_t)i;
+        R* ra = ref_a1 + 4 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ro[k] = sc.off[4 * i + k], ra[k] = sc.a1[4 * i + k];
+      }
+    }
   }
 }
 
 template <typename R>
 static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double rl, double skin, const R* off,
-                             hipStream_t st) {
+                             const R* a1, bool write_refs, hipStream_t st) {
+  R* ref_pos = write_refs ? (R*)sys->d_ref_pos : nullptr;
+  R* ref_off = write_refs ? (R*)sys->d_ref_off : nullptr;
+  R* ref_a1 = write_refs ? (R*)sys->d_ref_a1 : nullptr;
   const int n = sys->n;
   // classification radius of the leading "close" segment (everything is close until parameters exist)
   const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
@@ -234,8 +304,17 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     if (sys->model == 2) rbb = std::max(rbb, (double)sys->pd[DH_RCUT]);
     rbb = std::min(rl, rbb + skin);
   }
-  if (!sys->params_set) off = nullptr;
-  const R rbb2 = R(rbb * rbb);
+  if (!sys->params_set || !a1) off = nullptr;
+  SiteCrit<R> sc{off, a1, R(rbb * rbb), R(0), R(0), R(0), R(0), R(0)};
+  if (off) {
+    const OxParams<double>& P = sys->pd;
+    auto sq = [&](double r) { return R((r + skin) * (r + skin)); };
+    sc.rbase2 = sq(std::max({(double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH], (double)P[NEXC_BASE_RC]}));
+    sc.rstack2 = sq(P[CXST_RCHIGH]);
+    sc.rkb2 = sq(std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]));
+    sc.g_ba = R(P[GEO_BASE]);
+    sc.g_st = R(P[GEO_STACK]);
+  }
   CellGrid<R> g;
   bool ok = true;
   for (int k = 0; k < 3; ++k) {
@@ -257,10 +336,18 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   if (!ok || n < 512) {  // tiny systems / boxes under three cells: the all-pairs sweep is exact and cheap
     if (vec4)
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, true>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), R(rcl * rcl), off, rbb2, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), sc, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
     else
       hipLaunchKernelGGL((build_rows_allpairs_kernel<R, false>), dim3(blocks_ap), dim3(256), 0, st, n, pos, box,
-                         R(rl * rl), R(rcl * rcl), off, rbb2, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
+                         R(rl * rl), R(rcl * rcl), sc, d_partners, sys->d_rows, sys->d_row_len, d_close, sys->row_stride, sys->d_overflow);
+    if (write_refs && vec4) {  // the cell-list kernel writes these itself
+      const size_t bytes = (size_t)n * 4 * sizeof(R);
+      MYTHOS_HIP_TRY(hipMemcpyAsync(ref_pos, pos, bytes, hipMemcpyDeviceToDevice, st));
+      if (sc.off) {
+        MYTHOS_HIP_TRY(hipMemcpyAsync(ref_off, sc.off, bytes, hipMemcpyDeviceToDevice, st));
+        MYTHOS_HIP_TRY(hipMemcpyAsync(ref_a1, sc.a1, bytes, hipMemcpyDeviceToDevice, st));
+      }
+    }
     return 0;
   }
   const int H = next_pow2(2 * n);
@@ -271,37 +358,40 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     sys->cell_cap = 0;
     MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
     sys->cell_cap = need;
+    sys->cell_clean_H = 0;
   }
+  const bool clean = sys->cell_clean_H == H;
+  sys->cell_clean_H = H;
   const CellScratch cs(sys->d_cell, H, n);
   const int* start = cs.start;
   const int* bucket = cs.bucket;
-  if ((vec4 ? cell_list_build<R, true>(n, pos, g, H, cs, st) : cell_list_build<R, false>(n, pos, g, H, cs, st)) != 0) {
+  if ((vec4 ? cell_list_build<R, true>(n, pos, g, H, cs, clean, st) : cell_list_build<R, false>(n, pos, g, H, cs, clean, st)) != 0) {
     set_error("neighbour build: cell-list scratch memset failed");
     return MYTHOS_ERR_HIP;
   }
   const int wb = (n + 3) / 4;
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), off, rbb2, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
-                       sys->d_overflow);
+                       R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), off, rbb2, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
-                       sys->d_overflow);
+                       R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;
 }
 
 int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
-                      const void* backbone_offsets, hipStream_t stream) {
+                      const void* backbone_offsets, const void* base_vectors, bool write_refs, hipStream_t stream) {
   if (sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
   const double rl = r_cut + skin;
   MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, sizeof(int), stream));
   int rc;
   if (sys->dtype == MYTHOS_F32)
-    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, (const float*)backbone_offsets, stream);
+    rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, (const float*)backbone_offsets, (const float*)base_vectors, write_refs, stream);
   else
-    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, skin, (const double*)backbone_offsets, stream);
+    rc = build_cells_typed<double>(sys, (const double*)center, center_is_vec4, rl, skin, (const double*)backbone_offsets, (const double*)base_vectors, write_refs, stream);
   if (rc) return rc;
   MYTHOS_HIP_TRY(hipGetLastError());
   sys->nbrs_set = true;
