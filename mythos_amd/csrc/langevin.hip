@@ -198,10 +198,10 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 //           lane; the list of flagged slots lives in LDS;
 //   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
 // workgroups per CU the register allocator is asked to make room for: what the LDS footprint of the
-// variant allows (fp32 stepping 40 KB; the trace and fp64 variants carry wider result rows)
+// variant allows (fp32 stepping 43 KB; the trace and fp64 variants carry wider result rows)
 template <typename R, bool SAVE>
 constexpr int md_blocks_per_cu() {
-  return sizeof(R) == 4 ? (SAVE ? 2 : 4) : (SAVE ? 1 : 2);
+  return sizeof(R) == 4 ? (SAVE ? 2 : 3) : (SAVE ? 1 : 2);
 }
 
 template <typename R, int MODEL, bool SAVE>
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
   constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
   // three work lists per nucleotide (flagged row slots): 0 = H-bond, 1 = cross-stacking, 2 = coaxial
-  __shared__ unsigned short items[3][PPB][kMdMaxItems];
+  __shared__ int items[3][PPB][kMdMaxItems];  // the flagged row ENTRIES (index | role bit), not their slots
   __shared__ int item_cnt[3][PPB];
   __shared__ int item_pre[3][PPB + 1];
   __shared__ R self_lds[PPB][13];
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
         if (flag[t]) {
           const int pos = n_items[t] + __popc(gm & ((1u << lane) - 1u));
-          if (pos < kMdMaxItems) items[t][grp][pos] = (unsigned short)s;
+          if (pos < kMdMaxItems) items[t][grp][pos] = entry;
         }
         n_items[t] += __popc(gm);
       }
@@ -520,13 +520,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         }
         p = lo;
         const int k = q - item_pre[lst][lo];
-        sl = active ? (int)items[lst][p][k] : 0;
+        sl = active ? items[lst][p][k] : -1;  // for these waves sl carries the row entry itself
         // result row: bonded 0..3, then the nucleotide's H-bond, cross-stacking and coaxial items
         idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0) + (lst >= 2 ? item_cnt[1][p] : 0);
       }
       const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
-      const int entry = rows[(size_t)ip * row_stride + sl];
+      const int entry = bonded_wave ? rows[(size_t)ip * row_stride + sl] : sl;
       R* out_r = res_row(p, idx);
       SelfGrad<R> g;
       g.dc = g.g1 = g.g2 = g.g3 = V3<R>{R(0), R(0), R(0)};
