@@ -47,7 +47,7 @@ def axes_to_quaternion(a1: np.ndarray, a3: np.ndarray) -> np.ndarray:
     def fill(mask, w, x, y, z):
         q[mask, 0], q[mask, 1], q[mask, 2], q[mask, 3] = w[mask], x[mask], y[mask], z[mask]
 
-    with np.errstate(invalid="ignore"):
+    with np.errstate(invalid="ignore", divide="ignore"):  # the unselected branches may divide by zero
         s0 = np.sqrt(np.maximum(1.0 + tr, 0.0)) * 2.0
         s1 = np.sqrt(np.maximum(1.0 + m00 - m11 - m22, 0.0)) * 2.0
         s2 = np.sqrt(np.maximum(1.0 - m00 + m11 - m22, 0.0)) * 2.0

@@ -1,0 +1,111 @@
+"""CPU tests of the host-side input layer (the reference's counterparts: mythos/input/tests/): topology formats
+and pair bookkeeping, trajectory parsing / quaternions / round trips, default parameters and the TOML subset."""
+
+import io
+import math
+
+import numpy as np
+import pytest
+
+from mythos_amd.input import defaults, topology, trajectory
+from tests.helpers import GOLDEN
+
+
+def test_bonded_and_unbonded_pairs_of_linear_and_circular_strands():
+    b = topology.bonded_pairs([3, 2], [False, False])
+    assert b.tolist() == [[0, 1], [1, 2], [3, 4]]
+    bc = topology.bonded_pairs([3, 2], [True, False])
+    assert bc.tolist() == [[0, 1], [1, 2], [0, 2], [3, 4]]  # a ring is closed by (first, last), topology.py:178-180
+    u = topology.unbonded_pairs(5, b)
+    assert len(u) == 5 * 4 // 2 - 3 and all(i < j for i, j in u)
+    assert not ({tuple(p) for p in u} & {tuple(p) for p in b})
+    top = topology.from_arrays(np.array([0, 1, 2, 3, 0]), [3, 2], is_circular=[True, False])
+    assert top.is_end.tolist() == [0, 0, 0, 1, 1] and top.n_nucleotides == 5
+    part = top.bonded_partners
+    assert part.shape[0] == 5
+
+
+def test_classic_and_new_topology_formats_describe_the_same_system():
+    base = GOLDEN / "dna1" / "simple-helix-seq-dep"
+    with _nowarn():
+        classic, f_classic = topology.from_oxdna_file(base / "generated.top", return_format=True)
+        new, f_new = topology.from_oxdna_file(base / "generated-new.top", return_format=True)
+    assert f_classic == topology.oxDNAFormat.CLASSIC and f_new == topology.oxDNAFormat.NEW
+    assert classic.n_nucleotides == new.n_nucleotides and np.array_equal(classic.strand_counts, new.strand_counts)
+    assert np.array_equal(classic.bonded_neighbors, new.bonded_neighbors)
+    # the new format lists 5'->3' and is reversed per strand on load (topology.py:291): same memory order
+    assert np.array_equal(classic.seq, new.seq)
+
+
+class _nowarn:
+    def __enter__(self):
+        import warnings
+
+        self._c = warnings.catch_warnings()
+        self._c.__enter__()
+        warnings.simplefilter("ignore")
+
+    def __exit__(self, *a):
+        return self._c.__exit__(*a)
+
+
+def test_quaternion_axes_round_trip_and_handedness():
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal((200, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    a1, a2, a3 = trajectory.quaternion_to_axes(q)
+    np.testing.assert_allclose(np.cross(a3, a1), a2, atol=1e-14)  # a2 = a3 x a1 (trajectory.py:164-170)
+    np.testing.assert_allclose((a1 * a1).sum(1), 1.0, atol=1e-14)
+    q2 = trajectory.axes_to_quaternion(a1, a3)
+    sign = np.sign((q * q2).sum(1, keepdims=True))
+    np.testing.assert_allclose(q2 * sign, q, atol=1e-12)
+    # near-180-degree rotations (w ~ 0) take the other Shepperd branches
+    q_pi = np.array([[1e-9, 1.0, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [1e-12, 0.0, 0.0, 1.0]])
+    q_pi /= np.linalg.norm(q_pi, axis=1, keepdims=True)
+    b1, _, b3 = trajectory.quaternion_to_axes(q_pi)
+    q3 = trajectory.axes_to_quaternion(b1, b3)
+    c1, _, c3 = trajectory.quaternion_to_axes(q3)
+    np.testing.assert_allclose(c1, b1, atol=1e-8)
+    np.testing.assert_allclose(c3, b3, atol=1e-8)
+
+
+def test_trajectory_parse_slice_and_write_round_trip(tmp_path):
+    base = GOLDEN / "dna2" / "simple-helix"
+    with _nowarn():
+        top = topology.from_oxdna_file(base / "generated.top")
+    traj = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=False)
+    assert traj.center.shape == (100, 16, 3) and traj.quaternions.shape == (100, 16, 4)
+    assert traj.box_size.shape == (3,) and np.all(traj.box_size > 0)
+    np.testing.assert_allclose(np.linalg.norm(traj.a1, axis=-1), 1.0, atol=1e-6)
+    part = traj.slice(slice(10, 13))
+    assert part.center.shape[0] == 3 and np.array_equal(part.center[0], traj.center[10])
+    out = tmp_path / "copy.dat"
+    part.to_file(out)
+    back = trajectory.from_file(out, top.strand_counts, is_5p_3p=False)
+    np.testing.assert_allclose(back.center, part.center, atol=1e-12)
+    np.testing.assert_allclose(back.a1, part.a1, atol=1e-12)
+    np.testing.assert_allclose(back.a3, part.a3, atol=1e-12)
+    # 5'->3' trajectories are reversed per strand on load (trajectory.py:309-313)
+    rev = trajectory.from_file(out, top.strand_counts, is_5p_3p=True)
+    n0 = int(top.strand_counts[0])
+    np.testing.assert_allclose(rev.center[0, :n0], part.center[0, :n0][::-1], atol=1e-12)
+
+
+def test_default_parameters_and_toml_subset(tmp_path):
+    sim1, e1 = defaults.default_configs_for("dna1")
+    sim2, e2 = defaults.default_configs_for("dna2")
+    assert abs(sim2["kT"] - 296.15 * 0.1 / 300.0) < 1e-12 and sim2["salt_conc"] == 0.5 and sim2["dt"] == 5e-3
+    assert e1["fene"]["r0_backbone"] == 0.7525 and e2["fene"]["r0_backbone"] == 0.7564
+    assert e1["stacking"]["eps_stack_base"] == 1.3448 and e2["stacking"]["eps_stack_base"] == 1.3523
+    assert abs(e2["coaxial_stacking"]["theta0_coax_1"] - (math.pi - 0.25)) < 1e-12
+    assert "debye" in e2 and "debye" not in e1
+    with pytest.raises((KeyError, ValueError)):
+        defaults.default_configs_for("rna2")
+    toml = tmp_path / "p.toml"
+    toml.write_text("# comment\n[a]\nx = 1.5\ny = \"pi - 0.25\"\nflag = true\n[b]\nz = [1, 2.0, \"3 * 2\"]\n")
+    parsed = defaults.parse_toml(toml)
+    assert parsed["a"]["x"] == 1.5 and abs(parsed["a"]["y"] - (math.pi - 0.25)) < 1e-12 and parsed["a"]["flag"] is True
+    assert parsed["b"]["z"][2] == 6 and defaults.parse_toml(toml, key="a") == parsed["a"]
+    # strings that are not arithmetic stay strings: nothing is ever evaluated as Python
+    evil = "__import__('os').system('true')"
+    assert defaults.parse_str(evil) == evil and defaults.parse_str("sqrt(4) + pi") == 2.0 + math.pi
