@@ -161,7 +161,7 @@ def martini_main(args):
                            top.angles, tile(s["angle_k"]), tile(s["angle_t0"]), dtype=dtype, device=dev)
     kT = 0.0083144626 * 273.0
     integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
-    skin, every = (args.skin if args.skin != 0.5 else 0.3), (args.rebuild_every if args.rebuild_every != 25 else 5)
+    skin, every = (args.skin if args.skin != 0.5 else 0.4), (args.rebuild_every if args.rebuild_every != 25 else 8)
     integ.set_neighbor_policy(skin, every)
     pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
     vel = integ.init_velocities()

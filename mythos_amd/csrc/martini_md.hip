@@ -442,7 +442,7 @@ struct mythos_martini_sim {
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;
   int cell_clean_H = 0;  // table size for which the cell counters are known to be zero
-  int row_stride = 160;
+  int row_stride = 256;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   static constexpr int kMaxSamples = 64;
