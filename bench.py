@@ -99,6 +99,52 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get("MYTHOS_BENCH_CPU_CORES", "16"))))
 
 
+def param_gradient_error(dev) -> dict:
+    """Second half of BASELINE.json's metric: max-abs error of dU/dtheta against the CPU reference path.
+
+    oxDNA2 16-nt golden duplex (tests/golden/dna2/simple-helix), three frames: the HIP kernel's dU/dflat carried to
+    the reference's optimisable parameters (110 section entries, 103 unique names) by the chain rule, against torch autograd of the fp64 oracle through the
+    same derivation of the dependent constants.  Reported relative to the largest gradient component."""
+    from oracle import oxdna_oracle as orc
+    from tests import helpers as H
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    sim, cfg = defaults.default_configs_for("dna2")
+    leaves, sections = {}, {}
+    for sec, d in cfg.items():
+        sections[sec] = {}
+        for k, v in d.items():
+            # the reference's optimisable set: every energy-section key (geometry is fixed, dna2/__init__.py:45-46)
+            if sec != "geometry" and isinstance(v, (int, float)) and not isinstance(v, bool) and k not in ("kt", "salt_conc", "half_charged_ends"):
+                leaf = torch.tensor(float(v), dtype=torch.float64, requires_grad=True)
+                leaves[(sec, k)] = leaf
+                sections[sec][k] = leaf
+            else:
+                sections[sec][k] = v
+    fl = fp.pack_flat(fp.derive_flat(2, sections, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    P = orc.init_all(2, sections, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True)
+    seq, is_end, b, u = H.topo_tensors(top)
+    frames = [0, 33, 77]
+    u_ref = sum(orc.energy(2, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, u, traj.box_size)
+                for f in frames)
+    g_ref = torch.autograd.grad(u_ref, list(leaves.values()), allow_unused=True)
+    g_ref = torch.stack([torch.zeros(()) .double() if g is None else g for g in g_ref])
+    out = {"system": "oxDNA2 16 nt golden duplex, 3 frames", "n_parameters": len(leaves)}
+    for name, dtype in (("f64", torch.float64), ("f32", torch.float32)):
+        s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=dtype, device=dev)
+        s.set_params(fl.detach())
+        s.set_neighbors(top.unbonded_neighbors)
+        c = torch.as_tensor(traj.center[frames], dtype=dtype, device=dev)
+        q = torch.as_tensor(traj.quaternions[frames], dtype=dtype, device=dev)
+        _, _, _, gp = s.energy(c, q, grads=True, param_grads=True)
+        g_flat = gp.sum(0).cpu()
+        g = torch.autograd.grad(fl, list(leaves.values()), grad_outputs=g_flat, allow_unused=True, retain_graph=True)
+        g = torch.stack([torch.zeros(()).double() if x is None else x for x in g])
+        out[name] = {"max_abs_err": float((g - g_ref).abs().max()), "max_abs_grad": float(g_ref.abs().max()),
+                     "rel": float((g - g_ref).abs().max() / g_ref.abs().max())}
+    return out
+
+
 def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray, budget_s: float = 20.0) -> dict:
     """Time the CPU oracle (torch fp64, vectorised over the same Verlet pair list) on the host: up to
     ``n_steps`` steps, stopping early once ``budget_s`` seconds are spent."""
@@ -314,6 +360,7 @@ def main():
 
             pairs = verlet_pairs_numpy(c0, top.bonded_neighbors, R_CUT + 0.1)
             out["cpu_baseline"] = cpu_baseline(top, c0, q0, sim, cpu_steps, pairs)
+            out["config"]["dU_dtheta_vs_cpu"] = param_gradient_error(dev)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
