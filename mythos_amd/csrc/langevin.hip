@@ -218,10 +218,11 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   constexpr int G = kMdG, PPB = kMdPPB;
   constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
   constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
-  // three work lists per nucleotide (flagged row slots): 0 = H-bond, 1 = cross-stacking, 2 = coaxial
-  __shared__ int items[3][PPB][kMdMaxItems];  // the flagged row ENTRIES (index | role bit), not their slots
-  __shared__ int item_cnt[3][PPB];
-  __shared__ int item_pre[3][PPB + 1];
+  // two work lists per nucleotide: 0 = base-pair terms (H-bond and / or cross-stacking: they share the base-base
+  // vector and all six angles, so one evaluation serves both), 1 = coaxial stacking
+  __shared__ int items[2][PPB][kMdMaxItems];  // the flagged row ENTRIES (index | role bit), not their slots
+  __shared__ int item_cnt[2][PPB];
+  __shared__ int item_pre[2][PPB + 1];
   __shared__ R self_lds[PPB][13];
   __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
   // result rows, [nucleotide][slot][RW] with the nucleotide stride padded to an odd word count: the 32
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
   const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
   const DebyeP<R> dhp = (MODEL == 2) ? debye_params<R>(P) : DebyeP<R>{};
-  int n_items[3] = {0, 0, 0};
+  int n_items[2] = {0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
   // Software pipeline: the lane's row entries are fetched kEnt at a time, and the neighbour
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         n1 = in.p1[jn];
         if constexpr (kHiLo<R>) nl = in.pl[jn];
       }
-      bool flag[3] = {false, false, false};
+      bool flag[2] = {false, false};
       if (entry >= 0) {
         const bool role_p = (entry & ROW_ROLE_Q) == 0;
         const V3<R> dco = min_image(centre_diff<R>(o0, ol, self.c, self_lo), box);
@@ -373,8 +374,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
             axpy(d, g_ba, da);
             const R r2 = dot(d, d);
             en += f3_radial(eps_n, tw_n, f_base, d, r2, gba);
-            flag[1] = cut.cr_lo2 < r2 && r2 < cut.cr_hi2;
-            if (cut.hb_lo2 < r2 && r2 < cut.hb_hi2) {  // H-bond only for pairs with a non-zero weight
+            flag[0] = cut.cr_lo2 < r2 && r2 < cut.cr_hi2;
+            if (!flag[0] && cut.hb_lo2 < r2 && r2 < cut.hb_hi2) {  // H-bond only for pairs with a non-zero weight
               const int so = (int)o0.w & 3;
               flag[0] = (cut.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
             }
@@ -383,14 +384,14 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
             V3<R> d = dco;
             axpy(d, g_st, da);
             const R r2 = dot(d, d);
-            flag[2] = cut.cx_lo2 < r2 && r2 < cut.cx_hi2;
+            flag[1] = cut.cx_lo2 < r2 && r2 < cut.cx_hi2;
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
         }
       }
-      // append the flagged slots of this group to its three LDS lists, in slot order
+      // append the flagged slots of this group to its two LDS lists, in slot order
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < 2; ++t) {
         const unsigned long long bal = __ballot(flag[t]);
         const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
         if (flag[t]) {
@@ -453,9 +454,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       }
     }
   }
-  if (n_items[0] + n_items[1] + n_items[2] > kMdMaxItems) {  // result rows of one nucleotide exhausted
+  if (n_items[0] + n_items[1] > kMdMaxItems) {  // result rows of one nucleotide exhausted
     if (lane == 0) atomicOr(flags, 4);
-    n_items[0] = n_items[1] = n_items[2] = 0;
+    n_items[0] = n_items[1] = 0;
   }
   // The radial sums are folded over the group now and parked in LDS: nothing computed so far stays in
   // registers across the angular pass (whose pair functions need the whole register budget).
@@ -465,13 +466,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     R* rl = rad_lds[grp];
     rl[0] = gbk.x, rl[1] = gbk.y, rl[2] = gbk.z, rl[3] = gba.x, rl[4] = gba.y, rl[5] = gba.z;
 #pragma unroll
-    for (int t = 0; t < 3; ++t) item_cnt[t][grp] = valid ? n_items[t] : 0;
+    for (int t = 0; t < 2; ++t) item_cnt[t][grp] = valid ? n_items[t] : 0;
   }
   MD_STAMP(1);
   __syncthreads();  // self_lds, rad_lds and item_cnt are visible
   // exclusive prefix of the 32 per-nucleotide counts of each list (waves 0..2 take one list each), so every
   // list is dense over the workgroup
-  if (threadIdx.x < 192) {
+  if (threadIdx.x < 128) {
     const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int c = (l < PPB) ? item_cnt[t][l] : 0;
     int inc = c;
@@ -492,12 +493,17 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   //      (H-bond, cross-stacking, coaxial stacking).  Results go to res[owner][slot] in LDS.
   {
     NoPG pg;
-    // role of this wavefront: 0 bonded, 1 H-bond list, 2 cross-stacking list, 3 coaxial list; rotated with
-    // the workgroup index so the heavy and the light roles spread over the four SIMDs of a CU
+    // role of this wavefront: 0 bonded, 1 and 2 the two halves of the base-pair list (~100 items per workgroup
+    // in a duplex: one sweep of 64 each instead of two sweeps on one wavefront), 3 coaxial list; rotated with the
+    // workgroup index so the heavy and the light roles spread over the four SIMDs of a CU
     const int wave = ((threadIdx.x >> 6) + bid) & 3;
     const bool bonded_wave = wave == 0;
-    const int lst = bonded_wave ? 0 : wave - 1;
-    const int n_total = item_pre[lst][PPB];
+    const int lst = wave == 3 ? 1 : 0;
+    const int n_list = item_pre[lst][PPB];
+    const int half = (n_list + 1) >> 1;
+    const int q_lo = wave == 2 ? half : 0;                      // this wavefront's slice [q_lo, q_hi) of the list
+    const int q_hi = wave == 1 ? half : n_list;
+    const int n_total = q_hi - q_lo;
     const int n_sweeps = (n_total + 63) / 64;
     // bonded wave: one sweep over slots 0 / 1 of the 32 nucleotides, and a second over slots 2 / 3 only in
     // systems with circular strands (a ring's two ends carry a second bond in one role)
@@ -511,8 +517,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         sl = idx;
         active = true;
       } else {
-        const int q = sweep * 64 + (threadIdx.x & 63);
-        active = q < n_total;
+        const int q = q_lo + sweep * 64 + (threadIdx.x & 63);
+        active = q < q_hi;
         int lo = 0, hi = PPB;  // owner: largest p with item_pre[lst][p] <= q
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const int k = q - item_pre[lst][lo];
         sl = active ? items[lst][p][k] : -1;  // for these waves sl carries the row entry itself
         // result row: bonded 0..3, then the nucleotide's H-bond, cross-stacking and coaxial items
-        idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0) + (lst >= 2 ? item_cnt[1][p] : 0);
+        idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0);
       }
       const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
@@ -561,10 +567,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
 #endif
         if (wave == 0) {
           if (!(MD_DBG_SKIP & 1)) bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
-        } else if (wave == 1) {
-          if (!(MD_DBG_SKIP & 2)) unbonded_angular<R, MODEL, true, NoPG, 1>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
-        } else if (wave == 2) {
-          if (!(MD_DBG_SKIP & 4)) unbonded_angular<R, MODEL, true, NoPG, 2>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+        } else if (wave != 3) {
+          if (!(MD_DBG_SKIP & 6)) unbonded_angular<R, MODEL, true, NoPG, 3>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else {
           if (!(MD_DBG_SKIP & 8)) unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         }
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
   if (valid) {
-    const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp] + item_cnt[2][grp];
+    const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp];
     const int skip = extra_bonds ? 0 : 2;  // rows 2, 3 (second-bond slots) exist only in systems with circular strands
     for (int u = lane; u < total - skip; u += G) {
       const int t = (u < 2) ? u : u + skip;
