@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // vector and all six angles, so one evaluation serves both), 1 = coaxial stacking
   __shared__ int items[2][PPB][kMdMaxItems];  // the flagged row ENTRIES (index | role bit), not their slots
   __shared__ int item_cnt[2][PPB];
-  __shared__ int item_pre[2][PPB + 1];
+  __shared__ int item_pre[4][PPB + 1];  // per WAVEFRONT: the prefix of the list that wavefront will walk
   __shared__ R self_lds[PPB][13];
   __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
   // result rows, [nucleotide][slot][RW] with the nucleotide stride padded to an odd word count: the 32
@@ -470,21 +470,6 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   }
   MD_STAMP(1);
   __syncthreads();  // self_lds, rad_lds and item_cnt are visible
-  // exclusive prefix of the 32 per-nucleotide counts of each list (waves 0..2 take one list each), so every
-  // list is dense over the workgroup
-  if (threadIdx.x < 128) {
-    const int t = threadIdx.x >> 6, l = threadIdx.x & 63;
-    const int c = (l < PPB) ? item_cnt[t][l] : 0;
-    int inc = c;
-#pragma unroll
-    for (int o = 1; o < PPB; o <<= 1) {
-      const int u = __shfl_up(inc, o, 64);
-      if (l >= o) inc += u;
-    }
-    if (l < PPB) item_pre[t][l + 1] = inc;
-    if (l == 0) item_pre[t][0] = 0;
-  }
-  __syncthreads();
   MD_STAMP(2);
 
   // ---- phase 2: angular pass, work items spread over the whole workgroup so that every wavefront
@@ -499,7 +484,23 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const int wave = ((threadIdx.x >> 6) + bid) & 3;
     const bool bonded_wave = wave == 0;
     const int lst = wave == 3 ? 1 : 0;
-    const int n_list = item_pre[lst][PPB];
+    // exclusive prefix of the 32 per-nucleotide counts of this wavefront's list, so the list is dense over the
+    // workgroup; every wavefront scans for itself (5 DPP-free shuffle steps) instead of meeting at a second barrier
+    const int pw = threadIdx.x >> 6;
+    {
+      const int l = threadIdx.x & 63;
+      int inc = (l < PPB) ? item_cnt[lst][l] : 0;
+#pragma unroll
+      for (int o = 1; o < PPB; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (l >= o) inc += u;
+      }
+      if (l < PPB) item_pre[pw][l + 1] = inc;
+      if (l == 0) item_pre[pw][0] = 0;
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const int n_list = item_pre[pw][PPB];
     const int half = (n_list + 1) >> 1;
     const int q_lo = wave == 2 ? half : 0;                      // this wavefront's slice [q_lo, q_hi) of the list
     const int q_hi = wave == 1 ? half : n_list;
@@ -519,13 +520,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       } else {
         const int q = q_lo + sweep * 64 + (threadIdx.x & 63);
         active = q < q_hi;
-        int lo = 0, hi = PPB;  // owner: largest p with item_pre[lst][p] <= q
+        int lo = 0, hi = PPB;  // owner: largest p with item_pre[pw][p] <= q
         while (hi - lo > 1) {
           const int mid = (lo + hi) >> 1;
-          if (item_pre[lst][mid] <= q) lo = mid; else hi = mid;
+          if (item_pre[pw][mid] <= q) lo = mid; else hi = mid;
         }
         p = lo;
-        const int k = q - item_pre[lst][lo];
+        const int k = q - item_pre[pw][lo];
         sl = active ? items[lst][p][k] : -1;  // for these waves sl carries the row entry itself
         // result row: bonded 0..3, then the nucleotide's H-bond, cross-stacking and coaxial items
         idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0);
