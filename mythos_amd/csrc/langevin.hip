@@ -976,8 +976,22 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   auto rebuild = [&](int buf) -> int {
     return rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, fr[buf].p1, true, st);
   };
-  if (dynamic_list)
-    if (int rc = rebuild(cur)) return rc;
+  if (dynamic_list) {
+    // first build of the run: grow the rows until they hold the longest one with a quarter of headroom for the
+    // builds that follow inside the run (those cannot stop to grow: an overflow there ends the run with an error)
+    for (int attempt = 0;; ++attempt) {
+      if (int rc = rebuild(cur)) return rc;
+      int ov0 = 0;
+      MYTHOS_HIP_TRY(hipMemcpyAsync(&ov0, sys->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+      MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+      if (ov0 == 0) break;
+      if (attempt == 3) {
+        set_error("mythos_langevin_run: neighbour rows keep overflowing");
+        return MYTHOS_ERR_OVERFLOW;
+      }
+      if (int rc = rows_reserve(sys, ((ov0 + ov0 / 4 + 15) / 16) * 16)) return rc;
+    }
+  }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0;
   const int sample_stride = std::max(1, (n_steps + 1) / mythos_sim::kMaxSamples);

@@ -181,11 +181,13 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
                                                                 int row_stride, int* __restrict__ overflow,
                                                                 R* __restrict__ ref_pos, R* __restrict__ ref_off,
                                                                 R* __restrict__ ref_a1) {
-  constexpr int kFarCap = 96;
-  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3], s_far[4][kFarCap];
+  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
+  extern __shared__ int s_far_all[];  // [4][row_stride]: far entries of a row wait here until its close segment is complete
+  const int kFarCap = row_stride;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
   if (i >= n) return;
+  int* s_far = s_far_all + w * row_stride;
   constexpr int S = VEC4 ? 4 : 3;
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
   int cx, cy, cz;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     }
     if (hit_f) {
       const int k = out_f + __popcll(mf & below);
-      if (k < kFarCap) s_far[w][k] = e;
+      if (k < kFarCap) s_far[k] = e;
     }
     out_c += __popcll(mc);
     out_f += __popcll(mf);
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   const int n_close = out_c;
   int out = out_c + out_f;
   for (int k = lane; k < min(out_f, kFarCap); k += 64)
-    if (out_c + k < row_stride) row[out_c + k] = s_far[w][k];
+    if (out_c + k < row_stride) row[out_c + k] = s_far[k];
   if (lane == 0) {
     row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
     if (out > row_stride || out_f > kFarCap) {
@@ -370,12 +372,13 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     return MYTHOS_ERR_HIP;
   }
   const int wb = (n + 3) / 4;
+  const size_t far_lds = (size_t)4 * sys->row_stride * sizeof(int);
   if (vec4)
-    hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
                        R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
-    hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), 0, st, n, pos, box, g, R(rl * rl),
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
                        R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;

@@ -129,3 +129,21 @@ def test_md_kernel_with_circular_strands_matches_the_oracle_step_by_step():
         np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-9)
         np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-9)
         assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
+
+
+def test_md_rows_grow_for_a_dense_system():
+    """A compact bundle of short duplexes has far more neighbours per nucleotide than a lone duplex: the first build
+    of a run must enlarge the rows instead of failing (default capacity 64)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from mythos_amd.utils import generators
+
+    top, c0, q0 = generators.duplex_bundle(40, 16, spacing=3.0, seed=3)  # 16 duplexes of 40 bp, axes 3 units apart
+    s = _system(2, top, None, dtype=torch.float32, hce=True)
+    integ = LangevinIntegrator(s, dt=0.001, kT=0.0987, gamma_t=0.04, gamma_r=0.013, seed=4)
+    integ.set_neighbor_policy(3.25, 2.5, 10)  # a generous skin: every backbone site within 4.8 units is listed
+    c = torch.as_tensor(c0, dtype=torch.float32, device=s.device).contiguous()
+    q = torch.as_tensor(q0, dtype=torch.float32, device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    integ.run(c, q, p, L, 30)
+    mx, mean = s.neighbor_stats()
+    assert mx > 64 and torch.isfinite(c).all(), (mx, mean)
