@@ -20,31 +20,21 @@ enum OxParamIndex : int {
   OXP_COUNT
 };
 
-// The flat parameter vector as it travels in the kernel-argument segment.
+// The flat parameter vector on the host (and, for the Debye / cut-off helpers, as a plain array).
 template <typename R>
 struct OxParams {
-  static constexpr bool indexed = false;  // compile-time indices only (kernel-argument segment)
+  static constexpr bool indexed = false;
   R v[OXP_COUNT];
   __host__ __device__ __forceinline__ R operator[](int i) const { return v[i]; }
 };
 
-// What the device code indexes: a copy of the vector staged in LDS by every workgroup.  Reading it with
-// a compile-time index is one broadcast ds_read (all lanes, same address); a lane-varying index - the
-// role-dependent choice between two parameter blocks, or the 4x4 sequence-weight tables - is an ordinary
-// LDS gather.  Keeping the ~270 scalars in the kernel-argument segment instead costs a scalar-cache
-// round trip (s_load + s_waitcnt) per parameter block at every use, because they cannot all stay in
-// the 100 or so SGPRs a wave owns; that was the dominant stall of the angular terms.
-template <typename R>
-struct LdsParams {
-  static constexpr bool indexed = true;
-  const R* p;
-  __device__ __forceinline__ R operator[](int i) const { return p[i]; }
-};
-
-// The vector in device memory, read through the constant address space: every access with a
-// compile-time index is one s_load at the point of use (scalar cache), so no parameter has to stay live
-// in a register between uses.  (Passed by value in the kernel-argument segment, the compiler loads all
-// used entries in the entry block and then spills them - SGPR -> VGPR -> scratch - in a large kernel.)
+// How the kernels read it: the vector lives in device memory and is read through the constant address space,
+// so every access with a compile-time index is one s_load at the point of use (scalar cache) and no parameter
+// has to stay live in a register between uses.  Two alternatives were measured and dropped: passed by value in
+// the kernel-argument segment the compiler loads all used entries in the entry block and spills them (SGPR ->
+// VGPR -> scratch, 0.5-1.4 KB per lane); staged in LDS the loads are hoisted and held in VGPRs (256 registers,
+// one wavefront per SIMD).  `indexed` = true would mean "lane-varying indices are cheap" (an LDS or global
+// gather); the role-dependent parameter blocks are instead chosen by per-value selects (the *_sel helpers).
 template <typename R>
 struct ConstParams {
   static constexpr bool indexed = false;
@@ -53,11 +43,6 @@ struct ConstParams {
   __device__ __forceinline__ explicit ConstParams(const R* g) : p((cptr)g) {}
   __device__ __forceinline__ R operator[](int i) const { return p[i]; }
 };
-
-template <typename R>
-__device__ __forceinline__ void stage_params(const OxParams<R>& P, R* lds, int tid, int nthreads) {
-  for (int k = tid; k < OXP_COUNT; k += nthreads) lds[k] = P.v[k];
-}
 
 // ------------------------------------------------------------------ tiny vector algebra
 template <typename R>
