@@ -17,9 +17,10 @@
 // x_{k+1} to the other buffer of a ping-pong pair (other workgroups are still reading x_k).
 // One launch per MD step; a run of K steps costs K+1 force evaluations.
 //
-// Per nucleotide per step (fp32): read + write {pos 4, quat 4, p 4, L 4} words, read the
-// neighbour row and the neighbours' pos/quat through L2.  Algorithmic HBM bytes are stated in
-// DESIGN.md; the working set of a 12 kbp duplex (~3 MB) is L2 / Infinity-Cache resident.
+// Per nucleotide per step (fp32): read + write the expanded frame (centre hi + lo, a1, a3, backbone
+// offset, quaternion) and the momenta, read the neighbour row and the neighbours' frames through L2.
+// Algorithmic HBM bytes are stated in DESIGN.md; the working set of a 12 kbp duplex (a few MB) is
+// L2 / Infinity-Cache resident, the kernel is bound by VALU issue and latency, not by bytes.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -189,14 +190,16 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 // (0 for the first kernel of a run, 1/2 otherwise); do_step = 0 for the closing-only kernel.
 //
 // Work decomposition: 8 lanes per nucleotide, 32 nucleotides per 256-thread workgroup.
-//   phase 1 (radial): the lanes stride over the nucleotide's unbonded row; per neighbour they read
-//           32 B (centre + backbone offset), evaluate Debye-Hueckel and the four excluded-volume
-//           site pairs with early-outs on squared distances, and flag the few neighbours whose
-//           base-base / stack-stack distance lies in the support of an angular term;
-//   phase 2 (angular): the two bonded neighbours (FENE, bonded excluded volume, stacking) and the
-//           flagged ones (H-bond, cross-stacking, coaxial stacking) are evaluated densely, one per
-//           lane; the list of flagged slots lives in LDS;
-//   fold:   DPP-shuffle reduction over the 8 lanes, then lane 0 integrates and writes the next frame.
+//   phase 1 (radial): the lanes stride over the nucleotide's unbonded row, close segment then far segment;
+//           per neighbour they read the centre (hi, lo), the backbone offset and - in the close segment -
+//           a1, evaluate Debye-Hueckel and the excluded-volume site pairs with early-outs on squared
+//           distances, and flag the few neighbours whose base-base / stack-stack distance lies in the
+//           support of an angular term (two LDS lists per nucleotide: base-pair terms, coaxial stacking);
+//   phase 2 (angular): work items of the whole workgroup, one code path per wavefront: the bonded
+//           neighbours (FENE, bonded excluded volume, stacking), the two halves of the base-pair list
+//           (H-bond + cross-stacking evaluated together), the coaxial list; results go to LDS rows;
+//   fold:   each group sums its rows (DPP reductions over the 8 lanes);
+//   integrate: one wavefront advances the 32 nucleotides of the workgroup and writes the next frame.
 // workgroups per CU the register allocator is asked to make room for: what the LDS footprint of the
 // variant allows (fp32 stepping 43 KB; the trace and fp64 variants carry wider result rows)
 template <typename R, bool SAVE>
@@ -473,9 +476,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   MD_STAMP(2);
 
   // ---- phase 2: angular pass, work items spread over the whole workgroup so that every wavefront
-  //      runs ONE code path: wave 0 takes the 2 x 32 bonded neighbours (FENE, bonded excluded volume,
-  //      stacking), waves 1-3 take the flagged unbonded neighbours, 6 per nucleotide per sweep
-  //      (H-bond, cross-stacking, coaxial stacking).  Results go to res[owner][slot] in LDS.
+  //      runs ONE code path (roles below).  Results go to the owner's result rows in LDS.
   {
     NoPG pg;
     // role of this wavefront: 0 bonded, 1 and 2 the two halves of the base-pair list (~100 items per workgroup
@@ -563,15 +564,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         o.seq = mo & 3;
         o.is_end = (mo >> 2) & 1;
         const V3<R> dco = min_image(centre_diff<R>(o0, ol, me.c, V3<R>{ms[10], ms[11], ms[12]}), box);
-#ifndef MD_DBG_SKIP
-#define MD_DBG_SKIP 0
-#endif
         if (wave == 0) {
-          if (!(MD_DBG_SKIP & 1)) bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else if (wave != 3) {
-          if (!(MD_DBG_SKIP & 6)) unbonded_angular<R, MODEL, true, NoPG, 3>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          unbonded_angular<R, MODEL, true, NoPG, 3>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else {
-          if (!(MD_DBG_SKIP & 8)) unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         }
       }
       out_r[0] = g.dc.x, out_r[1] = g.dc.y, out_r[2] = g.dc.z;
