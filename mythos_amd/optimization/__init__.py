@@ -1,0 +1,1 @@
+"""DiffTRe reweighting math, objective protocol and the in-process optimisation loop (Adam)."""
