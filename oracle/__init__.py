@@ -1,0 +1,1 @@
+"""CPU restatements of the reference arithmetic - TEST INFRASTRUCTURE ONLY (never imported by mythos_amd)."""
