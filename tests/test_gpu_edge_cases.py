@@ -147,3 +147,29 @@ def test_md_rows_grow_for_a_dense_system():
     integ.run(c, q, p, L, 30)
     mx, mean = s.neighbor_stats()
     assert mx > 64 and torch.isfinite(c).all(), (mx, mean)
+
+
+def test_md_partially_filled_workgroup_matches_the_oracle():
+    """50 nucleotides = one full 32-nucleotide workgroup and one with 18 of 32 groups idle (and a padded grid)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from mythos_amd.utils import generators
+    from oracle.langevin_oracle import LangevinOracle
+
+    top, c0, q0 = generators.ideal_duplex(25, model=2, seed=11)
+    rng = np.random.default_rng(2)
+    c0 = c0 + 0.02 * rng.standard_normal(c0.shape)
+    s = _system(2, top, None, hce=True)
+    s.set_neighbors(top.unbonded_neighbors)
+    kT = 0.0987
+    integ = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=0.04, gamma_r=0.013, seed=5)
+    c = torch.as_tensor(c0, device=s.device).contiguous()
+    q = torch.as_tensor(q0, device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    tc, tq, et = integ.run(c, q, p, L, 3, save_every=1)
+    o = LangevinOracle(2, H.oracle_params(2, half_charged_ends=True), H.topo_tensors(top), None, 0.003, kT, 0.04, 0.013, 1.0,
+                       (1.0, 1.0, 1.0), seed=5)
+    for k in range(3):
+        x, qq, pp, LL, u = o.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-10)
+        assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
