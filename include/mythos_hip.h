@@ -146,6 +146,14 @@ int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, double* loop_ms_per_launch,
                                    int* launches, int* samples);
 
+/* ---- oxDNA text trajectories (host only) -----------------------------------------------------
+ * Replaces the Python parse of mythos/input/trajectory.py:192-320 (frames of `t = / b = / E =` header lines and
+ * n rows of 15 numbers: com, a1, a3, v, L).  Call once with frames == NULL to count (n_frames out), then with
+ * host buffers times[F], box[F][3], energies[F][3], frames[F][n][15]; at most max_frames are stored.  Rows stay in
+ * file order (the 5'->3' reversal of new-format files is the caller's, trajectory.py:309-313). */
+int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double* times, double* box, double* energies,
+                                 double* frames, int* n_frames);
+
 /* ---- MARTINI 2/3 ------------------------------------------------------------------------------
  * Replaces mythos/energy/martini/m2/{lj,bond,angle}.py and m3/angle.py.
  *   types        host int32[n]            bead type index

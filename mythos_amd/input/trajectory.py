@@ -172,13 +172,26 @@ def write_state(file, time, energies, state, box_size=(0, 0, 0)) -> None:
     np.savetxt(file, np.asarray(state), fmt="%.15g")
 
 
-def from_file(path, strand_lengths, *, is_5p_3p: bool = True, n_processes: int = 1) -> Trajectory:  # noqa: ARG001
-    """Parse an oxDNA trajectory / configuration file."""
-    path = Path(path)
-    if not path.exists():
-        raise FileNotFoundError(ERR_TRAJECTORY_FILE_NOT_FOUND.format(path))
-    strand_lengths = [int(s) for s in strand_lengths]
-    n = int(sum(strand_lengths))
+def _read_native(path: Path, n: int):
+    """times, boxes, energies, (S, n, 15) frames through mythos_oxdna_read_trajectory (one strtod pass in C++)."""
+    import ctypes as C
+
+    from mythos_amd import _lib
+
+    lib = _lib.load()
+    count = C.c_int(0)
+    bpath = str(path).encode()
+    _lib.check(lib.mythos_oxdna_read_trajectory(bpath, n, 0, None, None, None, None, C.byref(count)), "read_trajectory")
+    s = count.value
+    ts, bs, es = np.empty(s), np.empty((s, 3)), np.empty((s, 3))
+    frames = np.empty((s, n, 15))
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)  # noqa: E731
+    if s:
+        _lib.check(lib.mythos_oxdna_read_trajectory(bpath, n, s, dp(ts), dp(bs), dp(es), dp(frames), C.byref(count)), "read_trajectory")
+    return ts, bs, es, frames
+
+
+def _read_python(path: Path, n: int):
     ts, bs, es, rows = [], [], [], []
     with path.open() as f:
         for line in f:
@@ -195,19 +208,43 @@ def from_file(path, strand_lengths, *, is_5p_3p: bool = True, n_processes: int =
     n_frames = len(ts)
     if data.shape[0] != n_frames * n:
         raise ValueError(ERR_N_NUCLEOTIDE_STRAND_LENGTHS)
-    frames = data.reshape(n_frames, n, 15)
+    return np.array(ts, dtype=np.float64), np.array(bs).reshape(n_frames, 3), np.array(es).reshape(n_frames, 3), data.reshape(n_frames, n, 15)
+
+
+def from_file(path, strand_lengths, *, is_5p_3p: bool = True, n_processes: int = 1, native: bool | None = None) -> Trajectory:  # noqa: ARG001
+    """Parse an oxDNA trajectory / configuration file.
+
+    ``native``: True = the C++ reader of libmythos_hip.so (host code, no GPU needed), False = the numpy parse,
+    None = native when the library is built.  Both produce identical arrays (tests/test_input_cpu.py).
+    """
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(ERR_TRAJECTORY_FILE_NOT_FOUND.format(path))
+    strand_lengths = [int(s) for s in strand_lengths]
+    n = int(sum(strand_lengths))
+    if native is None:
+        from mythos_amd import _lib
+
+        native = _lib.lib_path().exists()
+    if native:
+        try:
+            ts, bs_arr, es, frames = _read_native(path, n)
+        except ValueError as e:
+            raise ValueError(ERR_N_NUCLEOTIDE_STRAND_LENGTHS + f" ({e})") from e
+    else:
+        ts, bs_arr, es, frames = _read_python(path, n)
+    n_frames = len(ts)
     if is_5p_3p:
         bounds = list(itertools.accumulate([0, *strand_lengths]))
         order = np.concatenate([np.arange(s, e)[::-1] for s, e in itertools.pairwise(bounds)])
         frames = frames[:, order, :]
-    bs_arr = np.array(bs)
     if len(bs_arr) and not np.all(bs_arr == bs_arr[0]):
         raise ValueError(ERR_FIXED_BOX_SIZE)
     return Trajectory(
         n_nucleotides=n,
         strand_lengths=strand_lengths,
-        times=np.array(ts, dtype=np.float64),
-        energies=np.array(es, dtype=np.float64).reshape(n_frames, 3),
+        times=np.asarray(ts, dtype=np.float64),
+        energies=np.asarray(es, dtype=np.float64).reshape(n_frames, 3),
         frames=np.ascontiguousarray(frames),
         box_size=bs_arr[0] if len(bs_arr) else None,
     )

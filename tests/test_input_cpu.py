@@ -3,6 +3,7 @@ and pair bookkeeping, trajectory parsing / quaternions / round trips, default pa
 
 import io
 import math
+import re
 
 import numpy as np
 import pytest
@@ -89,6 +90,43 @@ def test_trajectory_parse_slice_and_write_round_trip(tmp_path):
     rev = trajectory.from_file(out, top.strand_counts, is_5p_3p=True)
     n0 = int(top.strand_counts[0])
     np.testing.assert_allclose(rev.center[0, :n0], part.center[0, :n0][::-1], atol=1e-12)
+
+
+def test_native_trajectory_reader_matches_the_numpy_parse(tmp_path):
+    """mythos_oxdna_read_trajectory (host C++ in libmythos_hip.so) against the line-by-line parse, bit for bit."""
+    from mythos_amd import _lib
+
+    if not _lib.lib_path().exists():
+        pytest.skip("libmythos_hip.so not built")
+    for model, case in (("dna1", "simple-helix"), ("dna2", "simple-helix"), ("dna1", "simple-coax")):
+        base = GOLDEN / model / case
+        if not (base / "output.dat").exists():
+            continue
+        with _nowarn():
+            top = topology.from_oxdna_file(base / "generated.top")
+        for rev in (False, True):
+            a = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=rev, native=True)
+            b = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=rev, native=False)
+            assert np.array_equal(a.frames, b.frames) and np.array_equal(a.times, b.times)
+            assert np.array_equal(a.energies, b.energies) and np.array_equal(a.box_size, b.box_size)
+    # exponents, missing trailing newline, blank lines between frames, CRLF
+    rows = "\n".join(" ".join(f"{(i * 15 + k) * 1e-3:.6e}" for k in range(15)) for i in range(2))
+    text = f"t = 0\nb = 10 10 10\nE = -1.5 2e-1 0\n{rows}\n\nt = 1e3\r\nb = 10 10 10\r\nE = 0 0 0\r\n{rows}"
+    f = tmp_path / "odd.dat"
+    f.write_text(text)
+    a = trajectory.from_file(f, [2], is_5p_3p=False, native=True)
+    b = trajectory.from_file(f, [2], is_5p_3p=False, native=False)
+    assert a.frames.shape == (2, 2, 15) and np.array_equal(a.frames, b.frames) and a.times.tolist() == [0.0, 1000.0]
+    # wrong strand lengths fail the same way on both paths
+    for native in (True, False):
+        with pytest.raises(ValueError, match=re.escape(trajectory.ERR_N_NUCLEOTIDE_STRAND_LENGTHS)):
+            trajectory.from_file(f, [3], is_5p_3p=False, native=native)
+        with pytest.raises(ValueError, match=re.escape(trajectory.ERR_N_NUCLEOTIDE_STRAND_LENGTHS)):
+            trajectory.from_file(f, [1], is_5p_3p=False, native=native)
+    # empty file: zero frames
+    e = tmp_path / "empty.dat"
+    e.write_text("")
+    assert trajectory.from_file(e, [2], native=True).frames.shape == (0, 2, 15)
 
 
 def test_default_parameters_and_toml_subset(tmp_path):
