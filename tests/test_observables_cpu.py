@@ -69,3 +69,62 @@ def test_sites_follow_the_geometry_section_and_periodic_displacement():
     r0 = Rise(get_duplex_quartets(4), space.free()[0], cfg2["geometry"])(traj)
     r1 = Rise(get_duplex_quartets(4), disp, cfg2["geometry"])(shifted)
     assert torch.allclose(r0, r1, atol=1e-9)
+
+
+def test_vector_autocorrelation_and_fit_follow_their_definitions():
+    from mythos_amd.observables import persistence_length_fit, vector_autocorrelate
+
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=(2, 9, 3))
+    got = vector_autocorrelate(torch.as_tensor(v)).numpy()
+    for f in range(2):
+        for d in range(9):
+            want = np.mean([v[f, i] @ v[f, i + d] for i in range(9 - d)])  # persistence_length.py:47-75
+            assert abs(got[f, d] - want) < 1e-12
+    lp, off = persistence_length_fit(torch.exp(-torch.arange(30, dtype=torch.float64) * 0.4 / 50.0) * 0.9, 0.4)
+    assert abs(float(lp) - 50.0) < 1e-8 and abs(float(off) - math.log(0.9)) < 1e-10
+
+
+def test_persistence_length_of_a_discrete_wormlike_chain():
+    """Base-pair midpoints on a chain whose successive tangents bend by a random small angle:
+    <t_k . t_(k+d)> = <cos theta>^d, so Lp = -l0 / ln <cos theta>."""
+    from mythos_amd.observables import PersistenceLength
+
+    n, frames, l0, sigma = 40, 1500, 0.4, 0.12
+    rng = np.random.default_rng(11)
+    t = np.zeros((frames, n, 3))
+    t[:, 0] = [0.0, 0.0, 1.0]
+    for k in range(1, n):
+        kick = rng.normal(scale=sigma, size=(frames, 3))
+        kick -= (kick * t[:, k - 1]).sum(-1, keepdims=True) * t[:, k - 1]
+        new = t[:, k - 1] + kick
+        t[:, k] = new / np.linalg.norm(new, axis=-1, keepdims=True)
+    pts = np.cumsum(l0 * t, axis=1)  # midpoint k
+    centre = np.concatenate([pts, pts[:, ::-1]], axis=1)  # base pair k = (k, 2n-1-k), both bases on the midpoint
+    quat = np.zeros((frames, 2 * n, 4))
+    quat[..., 0] = 1.0
+    traj = Traj(center=torch.as_tensor(centre), orientation=Quaternion(vec=torch.as_tensor(quat)))
+    _, cfg = defaults.default_configs_for("dna2")
+    disp, _ = space.free()
+    obs = PersistenceLength(get_duplex_quartets(n), disp, cfg["geometry"], model=2, truncate=20, skip_ends=True)
+    corrs, l0s = obs.get_all_corrs_and_l0s(traj)
+    assert corrs.shape == (frames, n - 1 - 4) and torch.allclose(l0s, torch.full_like(l0s, l0), atol=1e-12)
+    tangents = t[:, 1:]  # quartet k joins midpoints k, k+1
+    cos_mean = np.mean((tangents[:, :-1] * tangents[:, 1:]).sum(-1))
+    expect = -l0 / math.log(cos_mean)
+    lp, offset = obs.lp_fit(traj)
+    assert abs(float(lp) - expect) / expect < 0.08 and abs(float(offset)) < 0.02
+    # uniform weights reproduce the unweighted fit; a one-hot weight reproduces the single-frame fit
+    w = torch.full((frames,), 1.0 / frames, dtype=torch.float64)
+    assert abs(float(obs(traj, weights=w)) - float(lp)) < 1e-9 * float(lp)
+    one = torch.zeros(frames, dtype=torch.float64)
+    one[0] = 1.0
+    first = Traj(center=traj.center[:1], orientation=Quaternion(vec=traj.orientation.vec[:1]))
+    assert abs(float(obs(traj, weights=one)) - float(obs(first))) < 1e-9 * abs(float(obs(first)))
+    import pytest
+
+    with pytest.raises(TypeError):
+        obs(traj, weights=np.array([1.0, 2.0]))
+    # skip_ends=False keeps all n - 1 quartets
+    full = PersistenceLength(get_duplex_quartets(n), disp, cfg["geometry"], skip_ends=False)
+    assert full.get_all_corrs_and_l0s(traj)[0].shape == (frames, n - 1)
