@@ -186,6 +186,12 @@ __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R
 #define MD_ABLATE(x) 0
 #endif
 
+// Optimisation barrier on a register value: whatever produced it stays before this point, its uses after.
+template <typename T>
+__device__ __forceinline__ void md_pin(T& v) {
+  asm volatile("" : "+v"(v));
+}
+
 // One MD step (see file header).  kick_close: multiple of dt*F that closes the previous step
 // (0 for the first kernel of a run, 1/2 otherwise); do_step = 0 for the closing-only kernel.
 //
@@ -582,6 +588,26 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       }
     }
   }
+  // ---- integrator prologue, early: the wavefront with the coaxial role is the first to leave the angular pass
+  //      (few items) and would idle at the barrier; it is also the one that integrates below, so it draws the
+  //      thermostat noise and fetches momenta, quaternion and list-reference rows here, off the tail of the kernel
+  //      where nothing else is left to hide their latency.  md_pin keeps the values on this side of the barriers.
+  const int int_wave = (3 - bid) & 3;  // the wavefront whose role above was 3
+  const int il = threadIdx.x & 63;     // nucleotide of this lane in the integrating wave
+  const int i_int = bid * PPB + il;
+  const bool integrates = (int)(threadIdx.x >> 6) == int_wave && il < PPB && i_int < n;
+  R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+  V4 pm{}, lm{}, qv{}, r0{}, f0{}, a0{};
+  if (integrates) {
+    pm = mom[i_int], lm = ang[i_int], qv = in.q[i_int];
+    if (do_step && K.skin_half_sq > R(0)) r0 = ref_pos[i_int], f0 = ref_off[i_int], a0 = ref_a1[i_int];
+    if (do_step && !MD_ABLATE(ablate & (4 | 32))) normals6(seed, (uint32_t)i_int, step, 0u, z);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) md_pin(z[k]);
+    md_pin(pm.x), md_pin(pm.y), md_pin(pm.z);
+    md_pin(lm.x), md_pin(lm.y), md_pin(lm.z);
+    md_pin(qv.x), md_pin(qv.y), md_pin(qv.z), md_pin(qv.w);
+  }
   MD_STAMP(3);
   __syncthreads();
   MD_STAMP(4);
@@ -638,14 +664,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   __syncthreads();
   MD_STAMP(6);
   double ke_t = 0.0, ke_r = 0.0;
-  const int int_wave = (bid >> 2) & 3;  // rotates over the SIMDs from workgroup to workgroup
-  const int il = threadIdx.x & 63;      // nucleotide of this lane in the integrating wave
-  const int i_int = bid * PPB + il;
-  if ((int)(threadIdx.x >> 6) == int_wave && il < PPB && i_int < n) {
+  if (integrates) {
     const int i = i_int;
-    // ---- thermostat noise for this (nucleotide, step): two Philox blocks, three Box-Muller pairs
-    R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
-    if (do_step && !(ablate & (4 | 32))) normals6(seed, (uint32_t)i, step, 0u, z);
     Nuc<R> self;
     SelfGrad<R> sg;
     {
@@ -665,7 +685,6 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const V3<R> F = -sg.dc;
     const V3<R> tl = axes_grad_to_torque(self, sg);
     const R tb[3] = {dot(self.a1, tl), dot(self.a2, tl), dot(self.a3, tl)};
-    const V4 pm = mom[i], lm = ang[i], qv = in.q[i];
     R p[3] = {pm.x, pm.y, pm.z}, L[3] = {lm.x, lm.y, lm.z};
     R qs[4] = {qv.x, qv.y, qv.z, qv.w};
     const R kc = kick_close * K.dt;
@@ -733,7 +752,6 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       if (K.skin_half_sq > R(0)) {
         // the list is valid while neither the centre nor the backbone and base sites (the segments are selected
         // by site distances, and a rotation moves the sites) have travelled more than skin / 2 since the build
-        const V4 r0 = ref_pos[i], f0 = ref_off[i], a0 = ref_a1[i];
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
         const R bx = dx + (g_k1 * n1.x + g_k2 * n2.x - f0.x), by = dy + (g_k1 * n1.y + g_k2 * n2.y - f0.y),
                 bz = dz + (g_k1 * n1.z + g_k2 * n2.z - f0.z);
