@@ -112,11 +112,11 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
   }
   bool ok = hipMalloc((void**)&s->d_meta, n * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_row_len, (size_t)(2 + ROW_BONDED_SLOTS) * n * sizeof(int)) == hipSuccess &&
-            hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_overflow, kOverflowWords * sizeof(int)) == hipSuccess &&
             hipMemcpy(s->d_meta, meta.data(), n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(s->d_row_len + n, s->h_partners.data(), (size_t)ROW_BONDED_SLOTS * n * sizeof(int), hipMemcpyHostToDevice) ==
                 hipSuccess &&
-            hipMemset(s->d_overflow, 0, sizeof(int)) == hipSuccess;
+            hipMemset(s->d_overflow, 0, kOverflowWords * sizeof(int)) == hipSuccess;
   if (!ok) {
     set_error("mythos_oxdna_create: device allocation failed");
     mythos_oxdna_destroy(s);
@@ -185,16 +185,7 @@ int mythos_oxdna_build_neighbors(mythos_system_t* s, const void* center, double 
   }
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    if (int rc = rows_build_device(s, center, false, r_cut, skin, nullptr, nullptr, false, st)) return rc;
-    int ov = 0;
-    MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, s->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-    if (ov == 0) return MYTHOS_OK;
-    if (int rc = rows_reserve(s, ((ov + 15) / 16) * 16 + 16)) return rc;
-  }
-  set_error("mythos_oxdna_build_neighbors: neighbour rows keep overflowing");
-  return MYTHOS_ERR_OVERFLOW;
+  return rows_build_until_fit(s, center, false, r_cut, skin, nullptr, nullptr, false, false, st);
 }
 
 int mythos_oxdna_neighbor_stats(mythos_system_t* s, int* max_row, double* mean_row) {

@@ -1,11 +1,12 @@
-// Hashed cell list shared by the neighbour-row builders (oxDNA: neighbors.hip, MARTINI: martini_md.hip):
-// count -> two-pass coalesced scan -> fill -> per-bucket sort.  Buckets are sorted by particle index so the
-// rows built from them are deterministic.  Kernels are file-local (static) because this header is compiled
-// into more than one translation unit.
+// Cell list shared by the neighbour-row builders (oxDNA: neighbors.hip, MARTINI: martini_md.hip): a hashed (free
+// space) or direct-mapped (periodic) table of fixed-capacity buckets filled by one kernel.  Kernels are file-local
+// (static) because this header is compiled into more than one translation unit.
 #ifndef MYTHOS_CELL_LIST_H
 #define MYTHOS_CELL_LIST_H
 
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 namespace mythos {
 
@@ -48,103 +49,72 @@ __device__ __forceinline__ int cell_slot(const CellGrid<R>& g, int cx, int cy, i
   return cell_hash(cx, cy, cz, g.hmask);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fixed-capacity buckets: table slot h owns bucket[h * cap .. h * cap + cap).  Binning is then ONE kernel - a
+// particle takes the next free place of its slot with one atomic - instead of count, scan (two passes), fill and
+// a counter memset, five dependent launches of ~5 us each plus their gaps for a few microseconds of work.  The
+// counters are double-buffered: a build counts into one half and clears the other half for the build after it.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCellSpill = 4096;  // places of the spill list
+
+struct CellBins {
+  int* cnt_cur = nullptr;   // [H + 1] this build's counters (zero on entry); [H] counts the spill list
+  int* cnt_next = nullptr;  // [H + 1] cleared by this build
+  int* bucket = nullptr;    // [H * cap]
+  int* spill = nullptr;     // [kCellSpill] particles that found their bucket full: candidates for everybody
+  int H = 0, cap = 0;
+  static size_t half(int H) { return (size_t)4 * ((H + 1 + 3) / 4); }
+  static size_t ints(int H, int cap) { return 2 * half(H) + (size_t)H * cap + kCellSpill; }
+  // view on one allocation of ints(H, cap) ints whose first 2 * half(H) were zeroed when it was made; phase flips
+  // per build
+  CellBins(int* base, int H_, int cap_, int phase)
+      : cnt_cur(base + (phase & 1) * half(H_)), cnt_next(base + ((phase & 1) ^ 1) * half(H_)),
+        bucket(base + 2 * half(H_)), spill(base + 2 * half(H_) + (size_t)H_ * cap_), H(H_), cap(cap_) {}
+};
+
+// A full bucket does not lose particles: they go to the spill list, which every row builder sweeps after its 27
+// cells (hash collisions come and go as molecules move, so a bucket can fill up in the middle of a run; the list
+// is empty otherwise).  Only a spill list that itself overflows is an error (overflow[1]).
 template <typename R, bool VEC4>
-__global__ void cell_count_kernel(int n, const R* __restrict__ pos, const CellGrid<R> g, int* __restrict__ slot_of,
-                                  int* __restrict__ cnt) {
+static __global__ __launch_bounds__(256) void cell_bin_kernel(int n, const R* __restrict__ pos, const CellGrid<R> g,
+                                                             int H, int* __restrict__ cnt_cur,
+                                                             int* __restrict__ cnt_next, int* __restrict__ bucket,
+                                                             int cap, int* __restrict__ spill,
+                                                             int* __restrict__ overflow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= H) cnt_next[i] = 0;
   if (i >= n) return;
   constexpr int S = VEC4 ? 4 : 3;
   int cx, cy, cz;
   cell_of(g, pos[S * i], pos[S * i + 1], pos[S * i + 2], cx, cy, cz);
   const int h = cell_slot(g, cx, cy, cz);
-  slot_of[i] = h;
-  atomicAdd(&cnt[h], 1);
-}
-
-// exclusive scan of cnt[0..m) into start[0..m] in two coalesced passes; cnt is cleared for reuse as a
-// cursor.  Pass 1: each 1024-thread workgroup scans 4096 counters (int4 per lane, wave shuffles + one LDS
-// hop) and publishes its total.  Pass 2 adds the totals of the preceding workgroups.
-constexpr int kScanBlock = 1024;
-constexpr int kScanPerBlock = 4 * kScanBlock;
-
-static __global__ __launch_bounds__(kScanBlock) void cell_scan_local_kernel(int m, int* __restrict__ cnt,
-                                                                      int* __restrict__ start,
-                                                                      int* __restrict__ block_sum) {
-  __shared__ int wave_tot[kScanBlock / 64];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int base = (blockIdx.x * kScanBlock + t) * 4;
-  int4 v = make_int4(0, 0, 0, 0);
-  if (base + 3 < m) {
-    v = *reinterpret_cast<const int4*>(cnt + base);
-    *reinterpret_cast<int4*>(cnt + base) = make_int4(0, 0, 0, 0);
+  const int p = atomicAdd(&cnt_cur[h], 1);
+  if (p < cap) {
+    bucket[(size_t)h * cap + p] = i;
   } else {
-    int* pv = &v.x;
-    for (int k = 0; k < 4; ++k)
-      if (base + k < m) {
-        pv[k] = cnt[base + k];
-        cnt[base + k] = 0;
-      }
+    const int q = atomicAdd(&cnt_cur[H], 1);
+    if (q < kCellSpill)
+      spill[q] = i;
+    else
+      atomicMax(&overflow[1], q + 1);
   }
-  const int s = v.x + v.y + v.z + v.w;
-  int inc = s;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += u;
-  }
-  if (lane == 63) wave_tot[w] = inc;
-  __syncthreads();
-  if (t == 0) {
-    int run = 0;
-    for (int k = 0; k < kScanBlock / 64; ++k) {
-      const int x = wave_tot[k];
-      wave_tot[k] = run;
-      run += x;
-    }
-    block_sum[blockIdx.x] = run;
-  }
-  __syncthreads();
-  const int pre = wave_tot[w] + inc - s;
-  const int o4[4] = {pre, pre + v.x, pre + v.x + v.y, pre + v.x + v.y + v.z};
-  for (int k = 0; k < 4; ++k)
-    if (base + k < m) start[base + k] = o4[k];
+  if (2 * (p + 1) > cap) atomicMax(&overflow[2], p + 1);  // more than half full: headroom hint, rare by design
 }
 
-static __global__ void cell_scan_fix_kernel(int m, int n_blocks, const int* __restrict__ block_sum, int* __restrict__ start) {
-  const int h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h > m) return;
-  const int b = (h < m ? h : m - 1) / kScanPerBlock;
-  int off = 0;
-  for (int k = 0; k < b; ++k) off += block_sum[k];
-  if (h < m) {
-    start[h] += off;
-  } else {
-    int tot = 0;
-    for (int k = 0; k < n_blocks; ++k) tot += block_sum[k];
-    start[m] = tot;
-  }
-}
-
-static __global__ void cell_fill_kernel(int n, const int* __restrict__ slot_of, const int* __restrict__ start,
-                                 int* __restrict__ cursor, int* __restrict__ bucket) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int h = slot_of[i];
-  bucket[start[h] + atomicAdd(&cursor[h], 1)] = i;
-}
-
-// One wavefront per bucket: buckets of up to 64 entries (all of them in practice: a cell holds a few tens of
-// particles) are sorted by a 64-lane bitonic network on registers, longer ones by one lane serially.
-static __global__ __launch_bounds__(256) void cell_sort_kernel(int m, const int* __restrict__ start,
-                                                               int* __restrict__ bucket, int* __restrict__ cursor) {
+// One wavefront per slot: orders a bucket by particle index (the atomics above land in any order), for row
+// builders that copy candidates in bucket order.  Up to 64 entries by a bitonic network on registers, longer
+// buckets by one lane serially.
+static __global__ __launch_bounds__(256) void cell_sort_bins_kernel(int H, const int* __restrict__ cnt,
+                                                                    int* __restrict__ bucket, int cap,
+                                                                    int* __restrict__ spill) {
   const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (h >= m) return;
-  if (lane == 0) cursor[h] = 0;  // the fill cursor: left clean for the next build (no memset between builds)
-  const int lo = start[h], cnt = start[h + 1] - lo;
-  if (cnt <= 1) return;
-  if (cnt <= 64) {
-    int v = (lane < cnt) ? bucket[lo + lane] : 0x7fffffff;
+  if (h > H) return;
+  const int count = min(cnt[h], h < H ? cap : kCellSpill);  // h == H: the spill list
+  if (count <= 1) return;
+  int* b = h < H ? bucket + (size_t)h * cap : spill;
+  if (count <= 64) {
+    int v = (lane < count) ? b[lane] : 0x7fffffff;
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
@@ -155,18 +125,28 @@ static __global__ __launch_bounds__(256) void cell_sort_kernel(int m, const int*
         v = (lower == up) ? min(v, o) : max(v, o);
       }
     }
-    if (lane < cnt) bucket[lo + lane] = v;
+    if (lane < count) b[lane] = v;
   } else if (lane == 0) {
-    for (int a = lo + 1; a < lo + cnt; ++a) {
-      const int v = bucket[a];
-      int b2 = a - 1;
-      while (b2 >= lo && bucket[b2] > v) {
-        bucket[b2 + 1] = bucket[b2];
-        --b2;
+    for (int a = 1; a < count; ++a) {
+      const int v = b[a];
+      int q = a - 1;
+      while (q >= 0 && b[q] > v) {
+        b[q + 1] = b[q];
+        --q;
       }
-      bucket[b2 + 1] = v;
+      b[q + 1] = v;
     }
   }
+}
+
+// MYTHOS_CELL_BUCKET_CAP=<places>: fixes the bucket capacity (no growth), e.g. to a handful of places to exercise
+// the spill path in tests.  0 / unset: managed by the callers.
+static inline int cell_cap_override() {
+  static const int v = [] {
+    const char* e = getenv("MYTHOS_CELL_BUCKET_CAP");
+    return e ? atoi(e) : 0;
+  }();
+  return v > 0 ? v : 0;
 }
 
 static inline int next_pow2(int v) {
@@ -175,30 +155,17 @@ static inline int next_pow2(int v) {
   return p;
 }
 
-// Scratch layout inside one int allocation: cnt[H] start[H+1] (pad to keep int4 alignment) slot_of[n]
-// bucket[n] block_sum[...].  Returns the number of ints needed.
-struct CellScratch {
-  int *cnt, *start, *slot_of, *bucket, *block_sum;
-  static size_t ints(int H, int n) { return (size_t)2 * H + 4 + (size_t)2 * n + 1024; }
-  CellScratch(int* base, int H, int n)
-      : cnt(base), start(base + H), slot_of(base + 2 * (size_t)H + 4), bucket(slot_of + n), block_sum(bucket + n) {}
-};
-
-// count, scan, fill and sort for n particles at pos (stride 3 or 4 reals); H = table size (power of two)
-// clean: the counters are known to be zero (left so by the previous build on the same scratch and table size)
+// bins n particles at pos (stride 3 or 4 reals) into b; overflow: int[3] of the caller ([0] rows, [1] spill list over
+// capacity, [2] fullest bucket if over half its capacity), not cleared here.  sort_buckets: order every bucket by particle index afterwards (one more launch).
 template <typename R, bool VEC4>
-static inline int cell_list_build(int n, const R* pos, CellGrid<R>& g, int H, const CellScratch& cs, bool clean,
-                                  hipStream_t st) {
-  if (!g.direct) g.hmask = H - 1;
-  if (!clean && hipMemsetAsync(cs.cnt, 0, (size_t)H * sizeof(int), st) != hipSuccess) return -1;
-  const int tb = (n + 255) / 256;
-  hipLaunchKernelGGL((cell_count_kernel<R, VEC4>), dim3(tb), dim3(256), 0, st, n, pos, g, cs.slot_of, cs.cnt);
-  const int nsb = (H + kScanPerBlock - 1) / kScanPerBlock;
-  hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nsb), dim3(kScanBlock), 0, st, H, cs.cnt, cs.start, cs.block_sum);
-  hipLaunchKernelGGL(cell_scan_fix_kernel, dim3((H + 1 + 255) / 256), dim3(256), 0, st, H, nsb, cs.block_sum, cs.start);
-  hipLaunchKernelGGL(cell_fill_kernel, dim3(tb), dim3(256), 0, st, n, cs.slot_of, cs.start, cs.cnt, cs.bucket);
-  hipLaunchKernelGGL(cell_sort_kernel, dim3((H + 3) / 4), dim3(256), 0, st, H, cs.start, cs.bucket, cs.cnt);
-  return 0;
+static inline void cell_bins_build(int n, const R* pos, CellGrid<R>& g, const CellBins& b, int* overflow,
+                                   bool sort_buckets, hipStream_t st) {
+  if (!g.direct) g.hmask = b.H - 1;
+  const int threads = n > b.H + 1 ? n : b.H + 1;
+  hipLaunchKernelGGL((cell_bin_kernel<R, VEC4>), dim3((threads + 255) / 256), dim3(256), 0, st, n, pos, g, b.H, b.cnt_cur,
+                     b.cnt_next, b.bucket, b.cap, b.spill, overflow);
+  if (sort_buckets)
+    hipLaunchKernelGGL(cell_sort_bins_kernel, dim3((b.H + 1 + 3) / 4), dim3(256), 0, st, b.H, b.cnt_cur, b.bucket, b.cap, b.spill);
 }
 
 }  // namespace mythos

@@ -994,19 +994,10 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   };
   if (dynamic_list) {
     // first build of the run: grow the rows until they hold the longest one with a quarter of headroom for the
-    // builds that follow inside the run (those cannot stop to grow: an overflow there ends the run with an error)
-    for (int attempt = 0;; ++attempt) {
-      if (int rc = rebuild(cur)) return rc;
-      int ov0 = 0;
-      MYTHOS_HIP_TRY(hipMemcpyAsync(&ov0, sys->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-      MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-      if (ov0 == 0) break;
-      if (attempt == 3) {
-        set_error("mythos_langevin_run: neighbour rows keep overflowing");
-        return MYTHOS_ERR_OVERFLOW;
-      }
-      if (int rc = rows_reserve(sys, ((ov0 + ov0 / 4 + 15) / 16) * 16)) return rc;
-    }
+    // builds that follow inside the run (those cannot stop to grow: a row overflow there is sticky in d_overflow and
+    // ends the run with an error), and the cell buckets until none is more than half full
+    if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
+      return rc;
   }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0;
@@ -1052,10 +1043,11 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, fr[cur], mom, ang, center, quat, p_lin,
                      p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
   sim->keep_valid = true;
-  int flags = 0, ov = 0;
+  int flags = 0, ovw[kOverflowWords] = {0, 0, 0};
   MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, sys->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(ovw, sys->d_overflow, sizeof(ovw), hipMemcpyDeviceToHost, st));
   MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+  const int ov = dynamic_list ? ovw[0] : 0;
   float ms = 0;
   MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
   sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
@@ -1086,6 +1078,11 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   if (ov != 0) {
     set_error("mythos_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
               std::to_string(sys->row_stride) + "); rebuild with mythos_oxdna_build_neighbors first");
+    return MYTHOS_ERR_OVERFLOW;
+  }
+  if (dynamic_list && ovw[1] != 0) {
+    set_error("mythos_langevin_run: too many nucleotides (" + std::to_string(ovw[1]) +
+              ") did not fit the buckets of their cells during a neighbour rebuild");
     return MYTHOS_ERR_OVERFLOW;
   }
   if (flags & 4) {

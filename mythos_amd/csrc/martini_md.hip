@@ -313,9 +313,11 @@ __device__ __forceinline__ bool mm_excluded(const int* __restrict__ ex, int j) {
 template <typename R>
 __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, const CellGrid<R> g, R rl2,
-    const int* __restrict__ excl, const int* __restrict__ start, const int* __restrict__ bucket, int* __restrict__ rows,
-    int* __restrict__ row_len, int row_stride, int* __restrict__ overflow) {
-  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
+    const int* __restrict__ excl, const int* __restrict__ cell_cnt, const int* __restrict__ bucket, int cell_cap,
+    const int* __restrict__ spill, int cell_H,
+    int* __restrict__ rows,
+    int* __restrict__ row_len, int row_stride, int* __restrict__ overflow, typename Real4<R>::type* __restrict__ ref_pos) {
+  __shared__ int s_pre[4][29], s_st[4][28], s_c[4][28][3];
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
   if (i >= n) return;
@@ -328,10 +330,11 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
 #pragma unroll
     for (int k = 0; k < 3; ++k) c[k] = (c[k] + g.nc[k]) % g.nc[k];
     const int h = cell_slot(g, c[0], c[1], c[2]);
-    const int st = start[h];
-    cnt = start[h + 1] - st;
-    s_st[w][lane] = st;
+    cnt = min(cell_cnt[h], cell_cap);
+    s_st[w][lane] = h * cell_cap;
     s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
+  } else if (lane == 27) {  // the spill list: particles whose bucket was full, candidates for every row
+    cnt = min(cell_cnt[cell_H], kCellSpill);
   }
   int inc = cnt;
 #pragma unroll
@@ -339,11 +342,11 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     const int v = __shfl_up(inc, o, 64);
     if (lane >= o) inc += v;
   }
-  if (lane < 27) s_pre[w][lane + 1] = inc;
+  if (lane < 28) s_pre[w][lane + 1] = inc;
   if (lane == 0) s_pre[w][0] = 0;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = __shfl(inc, 26, 64);
+  const int total = __shfl(inc, 27, 64);
   int ex[kMaxExcl];
 #pragma unroll
   for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
@@ -356,13 +359,13 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int j = -1;
     if (t < total) {
       while (s_pre[w][lo + 1] <= t) ++lo;
-      j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
+      j = (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
       if (j != i && !mm_excluded<R>(ex, j)) {
         const auto pj = pos[j];
         // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
         // direct table: a bucket is one cell
         bool mine = true;
-        if (!g.direct) {
+        if (!g.direct && lo < 27) {
           int jx, jy, jz;
           cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
           mine = (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]);
@@ -386,13 +389,15 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
       out = row_stride;
     }
     row_len[i] = out;
+    ref_pos[i] = pi;  // what the displacement check of the step kernel compares against
   }
 }
 
 template <typename R>
 __global__ __launch_bounds__(256) void mm_build_rows_allpairs_kernel(
     int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, R rl2, const int* __restrict__ excl,
-    int* __restrict__ rows, int* __restrict__ row_len, int row_stride, int* __restrict__ overflow) {
+    int* __restrict__ rows, int* __restrict__ row_len, int row_stride, int* __restrict__ overflow,
+    typename Real4<R>::type* __restrict__ ref_pos) {
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
   if (i >= n) return;
@@ -423,6 +428,7 @@ __global__ __launch_bounds__(256) void mm_build_rows_allpairs_kernel(
       out = row_stride;
     }
     row_len[i] = out;
+    ref_pos[i] = pi;  // what the displacement check of the step kernel compares against
   }
 }
 
@@ -440,8 +446,8 @@ struct mythos_martini_sim {
   void* frame[2] = {nullptr, nullptr};
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
-  size_t cell_cap = 0;
-  int cell_clean_H = 0;  // table size for which the cell counters are known to be zero
+  size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
+  int cell_H = 0, cell_bucket_cap = 64, cell_phase = 0;
   int row_stride = 256;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -467,7 +473,6 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
   mythos_martini* m = sim->sys;
   const int n = m->n;
   const double rl = m->r_cut + sim->skin;
-  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, sizeof(int), st));
   CellGrid<R> g;
   bool cells_ok = n >= 512;
   for (int k = 0; k < 3; ++k) {
@@ -480,32 +485,33 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
   const int wb = (n + 3) / 4;
   if (!cells_ok) {
     hipLaunchKernelGGL(mm_build_rows_allpairs_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, R(rl * rl), m->d_excl,
-                       sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow);
+                       sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos);
   } else {
     // periodic grid: one table slot per cell (no hashing) whenever the grid is not much larger than the system
     const long long n_cells = (long long)g.nc[0] * g.nc[1] * g.nc[2];
     g.direct = n_cells <= 8LL * n ? 1 : 0;
-    const int H = g.direct ? (int)(4 * ((n_cells + 3) / 4)) : next_pow2(2 * n);
-    const size_t need = CellScratch::ints(H, n);
-    if (need > sim->cell_cap) {
+    const int H = g.direct ? (int)n_cells : next_pow2(2 * n);
+    if (cell_cap_override()) sim->cell_bucket_cap = cell_cap_override();
+    const int cap = sim->cell_bucket_cap;
+    const size_t need = CellBins::ints(H, cap);
+    if (need > sim->cell_cap || H != sim->cell_H) {
       if (sim->d_cell) (void)hipFree(sim->d_cell);
       sim->d_cell = nullptr;
       sim->cell_cap = 0;
       MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_cell, need * sizeof(int)));
+      MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_cell, 0, 2 * CellBins::half(H) * sizeof(int), st));
       sim->cell_cap = need;
-      sim->cell_clean_H = 0;
+      sim->cell_H = H;
+      sim->cell_phase = 0;
     }
-    const CellScratch cs(sim->d_cell, H, n);
-    const bool clean = sim->cell_clean_H == H;
-    sim->cell_clean_H = H;
-    if (cell_list_build<R, true>(n, reinterpret_cast<const R*>(pos), g, H, cs, clean, st) != 0) {
-      set_error("martini neighbour build: cell-list scratch memset failed");
-      return MYTHOS_ERR_HIP;
-    }
+    const CellBins bins(sim->d_cell, H, cap, sim->cell_phase);
+    sim->cell_phase ^= 1;
+    // buckets sorted by bead index: the row builder copies candidates in bucket order, and rows must not depend on
+    // the order in which the binning atomics landed
+    cell_bins_build<R, true>(n, reinterpret_cast<const R*>(pos), g, bins, sim->d_overflow, true, st);
     hipLaunchKernelGGL(mm_build_rows_cells_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl,
-                       cs.start, cs.bucket, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow);
+                       bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos);
   }
-  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->ref_pos, pos, (size_t)n * sizeof(typename Real4<R>::type), hipMemcpyDeviceToDevice, st));
   return 0;
 }
 
@@ -530,7 +536,21 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
                      fr[0], vel);
   int cur = 0;
-  if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+  // first build of the run: buckets grow until none is more than half full (fuller ones work, through the spill
+  // list, but slowly); overflows inside the run are sticky in d_overflow and end the run with an error
+  for (int attempt = 0;; ++attempt) {
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
+    if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+    int ov0[3] = {0, 0, 0};
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ov0, sim->d_overflow, sizeof(ov0), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+    const int demand = cell_cap_override() ? 0 : ov0[2];  // a bucket more than half full: double the places
+    if (demand == 0 || attempt == 4) {
+      if (ov0[2] > 0) MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow + 2, 0, sizeof(int), st));
+      break;
+    }
+    sim->cell_bucket_cap = ((2 * demand + 15) / 16) * 16;
+  }
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0;
@@ -568,10 +588,11 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
   MYTHOS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(mm_unpack_kernel<R>, dim3(tb), dim3(256), 0, st, n, (const V4*)fr[cur], (const V4*)vel, pos, v);
-  int flags = 0, ov = 0;
+  int flags = 0, ovw[3] = {0, 0, 0};
   MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipMemcpyAsync(&ov, sim->d_overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(ovw, sim->d_overflow, sizeof(ovw), hipMemcpyDeviceToHost, st));
   MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+  const int ov = ovw[0];
   float ms = 0;
   MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
   sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
@@ -592,6 +613,11 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   if (ov != 0) {
     set_error("mythos_martini_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
               std::to_string(sim->row_stride) + ")");
+    return MYTHOS_ERR_OVERFLOW;
+  }
+  if (ovw[1] != 0) {
+    set_error("mythos_martini_langevin_run: more than " + std::to_string(kCellSpill) +
+              " beads did not fit the buckets of their cells during a neighbour rebuild");
     return MYTHOS_ERR_OVERFLOW;
   }
   if (flags & 1) {
@@ -652,7 +678,7 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc((void**)&s->d_rows, (size_t)n * s->row_stride * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_row_len, (size_t)n * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
-            hipMalloc((void**)&s->d_overflow, sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_overflow, 3 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
   ok = ok && hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;

@@ -65,10 +65,12 @@ struct mythos_system {
   bool extra_bonds = false;  // some nucleotide uses slot 2 or 3 (circular strands)
 
   // Verlet build scratch
-  int* d_overflow = nullptr;  // [1] set when a row would exceed row_stride
-  int* d_cell = nullptr;      // hashed cell list scratch: cnt[H] start[H+1] slot_of[n] bucket[n]
-  size_t cell_cap = 0;
-  int cell_clean_H = 0;  // table size for which the cell counters are known to be zero (0: unknown)
+  int* d_overflow = nullptr;  // [kOverflowWords] largest demands seen since last cleared (see rows_build_until_fit)
+  int* d_cell = nullptr;      // cell table (cell_list.h CellBins): counters [2][H], buckets [H][cell_bucket_cap]
+  size_t cell_cap = 0;        // ints allocated at d_cell
+  int cell_H = 0;             // table slots of the current allocation
+  int cell_bucket_cap = 32;   // places per slot
+  int cell_phase = 0;         // which counter half the next build counts into
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)
   void* d_ref_off = nullptr;  // [n] real4 backbone offsets at the last build
   void* d_ref_a1 = nullptr;   // [n] real4 base vectors at the last build
@@ -145,5 +147,11 @@ int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec
 // write_refs: also store the positions / backbone offsets / base vectors the list was built from in
 // d_ref_pos / d_ref_off / d_ref_a1 (the MD kernel's displacement check compares against them)
 int rows_reserve(mythos_system* sys, int stride);
+// d_overflow words: [0] longest row if over row_stride, [1] fullest bucket if over its capacity, [2] fullest
+// bucket if over half its capacity (headroom hint, not an error)
+constexpr int kOverflowWords = 3;
+int rows_build_until_fit(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
+                         const void* backbone_offsets, const void* base_vectors, bool write_refs, bool headroom,
+                         hipStream_t stream);
 
 }  // namespace mythos

@@ -168,6 +168,21 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
 // index after the atomic fill and rows are filled in (cell order, bucket order), so the list is
 // reproducible run to run.
 // ------------------------------------------------------------------------------------------------
+// cnt row entries in LDS (buf, any order) -> dst[0 .. min(cnt, room)) ordered by neighbour index.  Rank sort: a
+// lane's entry goes to the slot numbered by how many entries have a smaller index (indices are distinct); the
+// comparisons read the segment as LDS broadcasts, ~cnt cycles for the ~10 entries of a segment, where a bitonic
+// network pays 21 trips through the LDS crossbar whatever the count.
+__device__ __forceinline__ void wave_sort_to_row(const int* buf, int cnt, int* __restrict__ dst, int room, int lane) {
+  for (int b = 0; b < cnt; b += 64) {
+    const int k = b + lane;
+    const int e = (k < cnt) ? buf[k] : 0;
+    const int key = e & ROW_INDEX_MASK;
+    int rank = 0;
+    for (int q = 0; q < cnt; ++q) rank += ((buf[q] & ROW_INDEX_MASK) < key) ? 1 : 0;
+    if (k < cnt && rank < room) dst[rank] = e;
+  }
+}
+
 // one wavefront per nucleotide: lanes 0..26 look up the 27 neighbour cells, the candidate lists
 // are concatenated by a wave prefix sum and swept 64 at a time with ballot compaction
 template <typename R, bool VEC4>
@@ -175,19 +190,22 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
                                                                 const CellGrid<R> g, R rc2, R rcl2,
                                                                 const SiteCrit<R> sc,
                                                                 const int* __restrict__ partners,
-                                                                const int* __restrict__ start,
-                                                                const int* __restrict__ bucket, int* __restrict__ rows,
+                                                                const int* __restrict__ cell_cnt,
+                                                                const int* __restrict__ bucket, int cell_cap,
+    const int* __restrict__ spill, int cell_H,
+                                                                int* __restrict__ rows,
                                                                 int* __restrict__ row_len, int* __restrict__ row_close,
                                                                 int row_stride, int* __restrict__ overflow,
                                                                 R* __restrict__ ref_pos, R* __restrict__ ref_off,
                                                                 R* __restrict__ ref_a1) {
-  __shared__ int s_pre[4][28], s_st[4][27], s_c[4][27][3];
-  extern __shared__ int s_far_all[];  // [4][row_stride]: far entries of a row wait here until its close segment is complete
+  __shared__ int s_pre[4][29], s_st[4][28], s_c[4][28][3];
+  extern __shared__ int s_seg_all[];  // [4][2][row_stride]: the close and the far entries of a row, in candidate order
   const int kFarCap = row_stride;
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + w;
   if (i >= n) return;
-  int* s_far = s_far_all + w * row_stride;
+  int* s_close = s_seg_all + (size_t)w * 2 * row_stride;
+  int* s_far = s_close + row_stride;
   constexpr int S = VEC4 ? 4 : 3;
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
   int cx, cy, cz;
@@ -199,10 +217,11 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     for (int k = 0; k < 3; ++k)
       if (g.nc[k] > 0) c[k] = (c[k] + g.nc[k]) % g.nc[k];
     const int h = cell_slot(g, c[0], c[1], c[2]);
-    const int st = start[h];
-    cnt = start[h + 1] - st;
-    s_st[w][lane] = st;
+    cnt = min(cell_cnt[h], cell_cap);
+    s_st[w][lane] = h * cell_cap;
     s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
+  } else if (lane == 27) {  // the spill list: particles whose bucket was full, candidates for every row
+    cnt = min(cell_cnt[cell_H], kCellSpill);
   }
   int inc = cnt;  // inclusive wave prefix sum
 #pragma unroll
@@ -210,17 +229,18 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     const int v = __shfl_up(inc, o, 64);
     if (lane >= o) inc += v;
   }
-  if (lane < 27) s_pre[w][lane + 1] = inc;
+  if (lane < 28) s_pre[w][lane + 1] = inc;
   if (lane == 0) s_pre[w][0] = 0;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = __shfl(inc, 26, 64);
+  const int total = __shfl(inc, 27, 64);
   int* row = rows + (size_t)i * row_stride;
   const int* bq = partners + (size_t)ROW_BONDED_SLOTS * i;
   const int4 bp = make_int4(bq[0], bq[1], bq[2], bq[3]);
-  // One sweep over the candidates: a close entry goes straight to its slot, a far one is parked in LDS and
-  // appended behind the close segment afterwards (both in candidate order, so the row is reproducible).
-  int out_c = ROW_BONDED_SLOTS, out_f = 0;
+  // One sweep over the candidates: close and far entries are collected in LDS in candidate order (which follows
+  // the unsorted buckets, i.e. the order in which atomics happened to land), then each segment is sorted by
+  // neighbour index on its way to the row: rows are reproducible without a bucket sort.
+  int out_c = 0, out_f = 0;
   int lo = 0;  // cell of this lane's candidate: t grows by 64 per sweep, so it only ever advances
   for (int t0 = 0; t0 < total; t0 += 64) {
     const int t = t0 + lane;
@@ -228,11 +248,11 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     int j = -1;
     if (t < total) {
       while (s_pre[w][lo + 1] <= t) ++lo;
-      j = bucket[s_st[w][lo] + (t - s_pre[w][lo])];
+      j = (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
       if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
         bool mine = true;  // hashed table: a bucket may mix cells, a candidate counts for the cell it lies in
-        if (!g.direct) {
+        if (!g.direct && lo < 27) {
           int jx, jy, jz;
           cell_of(g, xj, yj, zj, jx, jy, jz);
           mine = jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2];
@@ -252,8 +272,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     const unsigned long long mc = __ballot(hit_c), mf = __ballot(hit_f);
     const unsigned long long below = (1ull << lane) - 1ull;
     if (hit_c) {
-      const int slot = out_c + __popcll(mc & below);
-      if (slot < row_stride) row[slot] = e;
+      const int k = out_c + __popcll(mc & below);
+      if (k < kFarCap) s_close[k] = e;
     }
     if (hit_f) {
       const int k = out_f + __popcll(mf & below);
@@ -264,15 +284,15 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int n_close = out_c;
-  int out = out_c + out_f;
-  for (int k = lane; k < min(out_f, kFarCap); k += 64)
-    if (out_c + k < row_stride) row[out_c + k] = s_far[k];
+  const int n_close = ROW_BONDED_SLOTS + out_c;
+  int out = n_close + out_f;
+  wave_sort_to_row(s_close, min(out_c, kFarCap), row + ROW_BONDED_SLOTS, row_stride - ROW_BONDED_SLOTS, lane);
+  if (n_close < row_stride) wave_sort_to_row(s_far, min(out_f, kFarCap), row + n_close, row_stride - n_close, lane);
   if (lane == 0) {
     row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
-    if (out > row_stride || out_f > kFarCap) {
-      atomicMax(overflow, max(out, ROW_BONDED_SLOTS + out_f));
-      out = min(out, row_stride);
+    if (out > row_stride) {
+      atomicMax(overflow, out);
+      out = row_stride;
     }
     row_len[i] = out;
     row_close[i] = min(n_close, out);
@@ -353,33 +373,35 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     return 0;
   }
   const int H = next_pow2(2 * n);
-  const size_t need = CellScratch::ints(H, n);
-  if (need > sys->cell_cap) {
+  if (cell_cap_override()) sys->cell_bucket_cap = cell_cap_override();
+  const int cap = sys->cell_bucket_cap;
+  const size_t need = CellBins::ints(H, cap);
+  if (need > sys->cell_cap || H != sys->cell_H) {
     if (sys->d_cell) (void)hipFree(sys->d_cell);
     sys->d_cell = nullptr;
     sys->cell_cap = 0;
     MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
+    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_cell, 0, 2 * CellBins::half(H) * sizeof(int), st));
     sys->cell_cap = need;
-    sys->cell_clean_H = 0;
+    sys->cell_H = H;
+    sys->cell_phase = 0;
   }
-  const bool clean = sys->cell_clean_H == H;
-  sys->cell_clean_H = H;
-  const CellScratch cs(sys->d_cell, H, n);
-  const int* start = cs.start;
-  const int* bucket = cs.bucket;
-  if ((vec4 ? cell_list_build<R, true>(n, pos, g, H, cs, clean, st) : cell_list_build<R, false>(n, pos, g, H, cs, clean, st)) != 0) {
-    set_error("neighbour build: cell-list scratch memset failed");
-    return MYTHOS_ERR_HIP;
-  }
+  const CellBins bins(sys->d_cell, H, cap, sys->cell_phase);
+  sys->cell_phase ^= 1;
+  // the row builder orders its rows itself: no bucket sort
+  if (vec4)
+    cell_bins_build<R, true>(n, pos, g, bins, sys->d_overflow, false, st);
+  else
+    cell_bins_build<R, false>(n, pos, g, bins, sys->d_overflow, false, st);
   const int wb = (n + 3) / 4;
-  const size_t far_lds = (size_t)4 * sys->row_stride * sizeof(int);
+  const size_t far_lds = (size_t)4 * 2 * sys->row_stride * sizeof(int);
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, start, bucket, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;
 }
@@ -389,7 +411,6 @@ int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec
   if (sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
   const double rl = r_cut + skin;
-  MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, sizeof(int), stream));
   int rc;
   if (sys->dtype == MYTHOS_F32)
     rc = build_cells_typed<float>(sys, (const float*)center, center_is_vec4, rl, skin, (const float*)backbone_offsets, (const float*)base_vectors, write_refs, stream);
@@ -399,6 +420,39 @@ int rows_build_device(mythos_system* sys, const void* center, bool center_is_vec
   MYTHOS_HIP_TRY(hipGetLastError());
   sys->nbrs_set = true;
   return 0;
+}
+
+// Builds the rows, growing the row stride and the bucket capacity until the build fits (synchronises the stream).
+// Buckets end up at most half full (fuller ones work, through the spill list, but slowly).  headroom: leave a
+// quarter of spare row length for builds that follow without a chance to grow (inside an MD run, where a row
+// overflow ends the run with an error).
+int rows_build_until_fit(mythos_system* sys, const void* center, bool center_is_vec4, double r_cut, double skin,
+                         const void* backbone_offsets, const void* base_vectors, bool write_refs, bool headroom,
+                         hipStream_t stream) {
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, kOverflowWords * sizeof(int), stream));
+    if (int rc = rows_build_device(sys, center, center_is_vec4, r_cut, skin, backbone_offsets, base_vectors, write_refs, stream))
+      return rc;
+    int ov[kOverflowWords] = {0, 0, 0};
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ov, sys->d_overflow, sizeof(ov), hipMemcpyDeviceToHost, stream));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(stream));
+    if (ov[1] > 0) {
+      set_error("neighbour build: more than " + std::to_string(kCellSpill) + " particles did not fit the buckets of their cells");
+      return MYTHOS_ERR_OVERFLOW;
+    }
+    const int bucket_demand = cell_cap_override() ? 0 : ov[2];  // a bucket more than half full: double the places
+    if (ov[0] == 0 && bucket_demand == 0) {
+      if (ov[2] > 0) MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow + 2, 0, sizeof(int), stream));
+      return MYTHOS_OK;
+    }
+    if (ov[0] > 0) {
+      const int want = headroom ? ((ov[0] + ov[0] / 4 + 15) / 16) * 16 : ((ov[0] + 15) / 16) * 16 + 16;
+      if (int rc = rows_reserve(sys, want)) return rc;
+    }
+    if (bucket_demand > 0) sys->cell_bucket_cap = ((2 * bucket_demand + 15) / 16) * 16;  // reallocated by the next build
+  }
+  set_error("neighbour build: rows or cell buckets keep overflowing");
+  return MYTHOS_ERR_OVERFLOW;
 }
 
 }  // namespace mythos

@@ -173,3 +173,23 @@ def test_md_partially_filled_workgroup_matches_the_oracle():
         x, qq, pp, LL, u = o.step(x, qq, pp, LL)
         np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-10)
         assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
+
+
+def test_full_cell_buckets_spill_without_losing_neighbours():
+    """Cell buckets of three places (MYTHOS_CELL_BUCKET_CAP, read when the library first builds a list, hence the child
+    process): nearly every cell overflows into the spill list, and the lists must still be complete - the 1 kbp
+    energies against the k-d tree list of the oracle, and the MARTINI Verlet forces against the all-pairs kernel."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, MYTHOS_CELL_BUCKET_CAP="3")
+    cases = ["tests/test_gpu_full_size.py::test_cfg2_1kbp_energy_and_forces_match_oracle",
+             "tests/test_gpu_martini_md.py::test_verlet_list_forces_equal_all_pairs_energy_kernel",
+             "tests/test_gpu_martini_md.py::test_step_by_step_parity_with_oracle_fp64"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *cases],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
