@@ -54,8 +54,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--bp", type=int, default=12000, help="base pairs of the duplex (12000 = headline config)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--skin", type=float, default=0.5)
-    ap.add_argument("--rebuild-every", type=int, default=25)
+    ap.add_argument("--skin", type=float, default=None, help="Verlet skin (default: 0.6 oxDNA length units / 0.4 nm MARTINI)")
+    ap.add_argument("--rebuild-every", type=int, default=None, help="steps between list rebuilds (default: 25 oxDNA / 8 MARTINI)")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="CPU-baseline sample size in steps (-1: auto, 0: skip)")
@@ -207,7 +207,7 @@ def martini_main(args):
                            top.angles, tile(s["angle_k"]), tile(s["angle_t0"]), dtype=dtype, device=dev)
     kT = 0.0083144626 * 273.0
     integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
-    skin, every = (args.skin if args.skin != 0.5 else 0.4), (args.rebuild_every if args.rebuild_every != 25 else 8)
+    skin, every = (0.4 if args.skin is None else args.skin), (8 if args.rebuild_every is None else args.rebuild_every)
     integ.set_neighbor_policy(skin, every)
     pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
     vel = integ.init_velocities()
@@ -242,6 +242,8 @@ def main():
     args = parse_args()
     if args.workload == "martini-bilayer":
         return martini_main(args)
+    args.skin = 0.6 if args.skin is None else args.skin
+    args.rebuild_every = 25 if args.rebuild_every is None else args.rebuild_every
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
