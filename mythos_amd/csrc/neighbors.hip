@@ -168,13 +168,13 @@ __global__ __launch_bounds__(256) void build_rows_allpairs_kernel(int n, const R
 // index after the atomic fill and rows are filled in (cell order, bucket order), so the list is
 // reproducible run to run.
 // ------------------------------------------------------------------------------------------------
-// cnt row entries in LDS (buf, any order) -> dst[0 .. min(cnt, room)) ordered by neighbour index.  Rank sort: a
-// lane's entry goes to the slot numbered by how many entries have a smaller index (indices are distinct); the
-// comparisons read the segment as LDS broadcasts, ~cnt cycles for the ~10 entries of a segment, where a bitonic
-// network pays 21 trips through the LDS crossbar whatever the count.
-__device__ __forceinline__ void wave_sort_to_row(const int* buf, int cnt, int* __restrict__ dst, int room, int lane) {
-  for (int b = 0; b < cnt; b += 64) {
-    const int k = b + lane;
+// cnt row entries in LDS (buf, any order) -> dst[0 .. min(cnt, room)) ordered by neighbour index, by the G lanes of
+// one group.  Rank sort: an entry goes to the slot numbered by how many entries have a smaller index (indices are
+// distinct); the comparisons read the segment as LDS broadcasts, ~cnt cycles for the ~10 entries of a segment.
+template <int G>
+__device__ __forceinline__ void group_sort_to_row(const int* buf, int cnt, int* __restrict__ dst, int room, int l) {
+  for (int b = 0; b < cnt; b += G) {
+    const int k = b + l;
     const int e = (k < cnt) ? buf[k] : 0;
     const int key = e & ROW_INDEX_MASK;
     int rank = 0;
@@ -183,79 +183,97 @@ __device__ __forceinline__ void wave_sort_to_row(const int* buf, int cnt, int* _
   }
 }
 
-// one wavefront per nucleotide: lanes 0..26 look up the 27 neighbour cells, the candidate lists
-// are concatenated by a wave prefix sum and swept 64 at a time with ballot compaction
-template <typename R, bool VEC4>
+// ------------------------------------------------------------------------------------------------
+// Cell-list builder: G lanes per nucleotide (kRowG = 16: four nucleotides per wavefront).  A row is the end of a
+// chain of dependent reads (own position -> 27 cell counters -> bucket entries -> candidate positions -> candidate
+// sites) and a wavefront spends its life waiting on them; a 12 kbp duplex has ~57 candidates per nucleotide, so a
+// full wavefront per nucleotide filled the machine three times over with waves that each wait the whole chain.
+// Four nucleotides per wavefront fit all of them on the chip at once.  The group's lanes look up the 27 neighbour
+// cells and the spill list, the candidate lists are concatenated by a prefix sum and swept G at a time with ballot
+// compaction into LDS; close and far segments are then ordered by neighbour index on their way to the row (the
+// buckets are in the order the binning atomics landed), so rows are reproducible run to run.
+// ------------------------------------------------------------------------------------------------
+#ifndef MYTHOS_ROW_G
+#define MYTHOS_ROW_G 16
+#endif
+constexpr int kRowG = MYTHOS_ROW_G;
+
+template <typename R, bool VEC4, int G>
 __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* __restrict__ pos, const BoxT<R> box,
                                                                 const CellGrid<R> g, R rc2, R rcl2,
                                                                 const SiteCrit<R> sc,
                                                                 const int* __restrict__ partners,
                                                                 const int* __restrict__ cell_cnt,
                                                                 const int* __restrict__ bucket, int cell_cap,
-    const int* __restrict__ spill, int cell_H,
+                                                                const int* __restrict__ spill, int cell_H,
                                                                 int* __restrict__ rows,
                                                                 int* __restrict__ row_len, int* __restrict__ row_close,
                                                                 int row_stride, int* __restrict__ overflow,
                                                                 R* __restrict__ ref_pos, R* __restrict__ ref_off,
                                                                 R* __restrict__ ref_a1) {
-  __shared__ int s_pre[4][29], s_st[4][28], s_c[4][28][3];
-  extern __shared__ int s_seg_all[];  // [4][2][row_stride]: the close and the far entries of a row, in candidate order
-  const int kFarCap = row_stride;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + w;
+  constexpr int NG = 256 / G;  // nucleotides per workgroup
+  __shared__ int s_pre[NG][29], s_st[NG][28], s_c[NG][28][3];
+  extern __shared__ int s_seg_all[];  // [NG][2][row_stride]: the close and the far entries of a row, in candidate order
+  const int kSegCap = row_stride;
+  const int grp = threadIdx.x / G, l = threadIdx.x % G;
+  const int gshift = (threadIdx.x & 63) & ~(G - 1);  // first lane of this group inside its wavefront
+  const int i = blockIdx.x * NG + grp;
   if (i >= n) return;
-  int* s_close = s_seg_all + (size_t)w * 2 * row_stride;
+  int* s_close = s_seg_all + (size_t)grp * 2 * row_stride;
   int* s_far = s_close + row_stride;
   constexpr int S = VEC4 ? 4 : 3;
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
   int cx, cy, cz;
   cell_of(g, ci.x, ci.y, ci.z, cx, cy, cz);
-  int cnt = 0;
-  if (lane < 27) {
-    int c[3] = {cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1};
+  for (int k = l; k < 28; k += G) {
+    int cnt;
+    if (k < 27) {
+      int c[3] = {cx + k % 3 - 1, cy + (k / 3) % 3 - 1, cz + k / 9 - 1};
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if (g.nc[k] > 0) c[k] = (c[k] + g.nc[k]) % g.nc[k];
-    const int h = cell_slot(g, c[0], c[1], c[2]);
-    cnt = min(cell_cnt[h], cell_cap);
-    s_st[w][lane] = h * cell_cap;
-    s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
-  } else if (lane == 27) {  // the spill list: particles whose bucket was full, candidates for every row
-    cnt = min(cell_cnt[cell_H], kCellSpill);
+      for (int a = 0; a < 3; ++a)
+        if (g.nc[a] > 0) c[a] = (c[a] + g.nc[a]) % g.nc[a];
+      const int h = cell_slot(g, c[0], c[1], c[2]);
+      cnt = min(cell_cnt[h], cell_cap);
+      s_st[grp][k] = h * cell_cap;
+      s_c[grp][k][0] = c[0], s_c[grp][k][1] = c[1], s_c[grp][k][2] = c[2];
+    } else {  // the spill list: particles whose bucket was full, candidates for every row
+      cnt = min(cell_cnt[cell_H], kCellSpill);
+    }
+    s_pre[grp][k + 1] = cnt;
   }
-  int inc = cnt;  // inclusive wave prefix sum
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    const int v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  if (lane < 28) s_pre[w][lane + 1] = inc;
-  if (lane == 0) s_pre[w][0] = 0;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = __shfl(inc, 27, 64);
+  if (l == 0) {
+    int run = 0;
+    s_pre[grp][0] = 0;
+    for (int k = 1; k <= 28; ++k) {
+      run += s_pre[grp][k];
+      s_pre[grp][k] = run;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = s_pre[grp][28];
   int* row = rows + (size_t)i * row_stride;
   const int* bq = partners + (size_t)ROW_BONDED_SLOTS * i;
   const int4 bp = make_int4(bq[0], bq[1], bq[2], bq[3]);
-  // One sweep over the candidates: close and far entries are collected in LDS in candidate order (which follows
-  // the unsorted buckets, i.e. the order in which atomics happened to land), then each segment is sorted by
-  // neighbour index on its way to the row: rows are reproducible without a bucket sort.
   int out_c = 0, out_f = 0;
-  int lo = 0;  // cell of this lane's candidate: t grows by 64 per sweep, so it only ever advances
-  for (int t0 = 0; t0 < total; t0 += 64) {
-    const int t = t0 + lane;
+  int lo = 0;  // cell of this lane's candidate: t grows by G per sweep, so it only ever advances
+  constexpr unsigned int kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+  for (int t0 = 0; t0 < total; t0 += G) {
+    const int t = t0 + l;
     bool hit_c = false, hit_f = false;
     int j = -1;
     if (t < total) {
-      while (s_pre[w][lo + 1] <= t) ++lo;
-      j = (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
+      while (s_pre[grp][lo + 1] <= t) ++lo;
+      j = (lo < 27) ? bucket[s_st[grp][lo] + (t - s_pre[grp][lo])] : spill[t - s_pre[grp][27]];
       if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
         bool mine = true;  // hashed table: a bucket may mix cells, a candidate counts for the cell it lies in
         if (!g.direct && lo < 27) {
           int jx, jy, jz;
           cell_of(g, xj, yj, zj, jx, jy, jz);
-          mine = jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2];
+          mine = jx == s_c[grp][lo][0] && jy == s_c[grp][lo][1] && jz == s_c[grp][lo][2];
         }
         if (mine) {
           V3<R> d{xj - ci.x, yj - ci.y, zj - ci.z};
@@ -269,26 +287,27 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
       }
     }
     const int e = (j < i) ? (j | ROW_ROLE_Q) : j;
-    const unsigned long long mc = __ballot(hit_c), mf = __ballot(hit_f);
-    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned int mc = (unsigned int)(__ballot(hit_c) >> gshift) & kGroupMask;
+    const unsigned int mf = (unsigned int)(__ballot(hit_f) >> gshift) & kGroupMask;
+    const unsigned int below = (1u << l) - 1u;
     if (hit_c) {
-      const int k = out_c + __popcll(mc & below);
-      if (k < kFarCap) s_close[k] = e;
+      const int k = out_c + __popc(mc & below);
+      if (k < kSegCap) s_close[k] = e;
     }
     if (hit_f) {
-      const int k = out_f + __popcll(mf & below);
-      if (k < kFarCap) s_far[k] = e;
+      const int k = out_f + __popc(mf & below);
+      if (k < kSegCap) s_far[k] = e;
     }
-    out_c += __popcll(mc);
-    out_f += __popcll(mf);
+    out_c += __popc(mc);
+    out_f += __popc(mf);
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   const int n_close = ROW_BONDED_SLOTS + out_c;
   int out = n_close + out_f;
-  wave_sort_to_row(s_close, min(out_c, kFarCap), row + ROW_BONDED_SLOTS, row_stride - ROW_BONDED_SLOTS, lane);
-  if (n_close < row_stride) wave_sort_to_row(s_far, min(out_f, kFarCap), row + n_close, row_stride - n_close, lane);
-  if (lane == 0) {
+  group_sort_to_row<G>(s_close, min(out_c, kSegCap), row + ROW_BONDED_SLOTS, row_stride - ROW_BONDED_SLOTS, l);
+  if (n_close < row_stride) group_sort_to_row<G>(s_far, min(out_f, kSegCap), row + n_close, row_stride - n_close, l);
+  if (l == 0) {
     row[0] = bp.x, row[1] = bp.y, row[2] = bp.z, row[3] = bp.w;
     if (out > row_stride) {
       atomicMax(overflow, out);
@@ -393,14 +412,15 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
     cell_bins_build<R, true>(n, pos, g, bins, sys->d_overflow, false, st);
   else
     cell_bins_build<R, false>(n, pos, g, bins, sys->d_overflow, false, st);
-  const int wb = (n + 3) / 4;
-  const size_t far_lds = (size_t)4 * 2 * sys->row_stride * sizeof(int);
+  constexpr int kPerBlock = 256 / kRowG;
+  const int wb = (n + kPerBlock - 1) / kPerBlock;
+  const size_t far_lds = (size_t)kPerBlock * 2 * sys->row_stride * sizeof(int);
   if (vec4)
-    hipLaunchKernelGGL((build_rows_cells_kernel<R, true>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, true, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
                        R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
-    hipLaunchKernelGGL((build_rows_cells_kernel<R, false>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
+    hipLaunchKernelGGL((build_rows_cells_kernel<R, false, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
                        R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;
