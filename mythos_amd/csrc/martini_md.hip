@@ -353,27 +353,35 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
   int* row = rows + (size_t)i * row_stride;
   int out = 0;
   int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by 64 per sweep
+  // One sweep ahead: the bucket entry and the position of the candidate of sweep s + 1 are requested before sweep s
+  // is evaluated (a bead has ~400 candidates, seven sweeps; their two dependent reads each would otherwise add up)
+  auto candidate = [&](int t, int& cell) -> int {
+    if (t >= total) return -1;
+    while (s_pre[w][lo + 1] <= t) ++lo;
+    cell = lo;
+    return (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
+  };
+  int cell_nxt = 0;
+  int j_nxt = candidate(lane, cell_nxt);
+  auto p_nxt = pos[j_nxt >= 0 ? j_nxt : i];
   for (int t0 = 0; t0 < total; t0 += 64) {
-    const int t = t0 + lane;
+    const int j = j_nxt, cell = cell_nxt;
+    const auto pj = p_nxt;
+    j_nxt = candidate(t0 + 64 + lane, cell_nxt);
+    p_nxt = pos[j_nxt >= 0 ? j_nxt : i];
     bool hit = false;
-    int j = -1;
-    if (t < total) {
-      while (s_pre[w][lo + 1] <= t) ++lo;
-      j = (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
-      if (j != i && !mm_excluded<R>(ex, j)) {
-        const auto pj = pos[j];
-        // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
-        // direct table: a bucket is one cell
-        bool mine = true;
-        if (!g.direct && lo < 27) {
-          int jx, jy, jz;
-          cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
-          mine = (jx == s_c[w][lo][0] && jy == s_c[w][lo][1] && jz == s_c[w][lo][2]);
-        }
-        if (mine) {
-          const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
-          hit = dx * dx + dy * dy + dz * dz < rl2;
-        }
+    if (j >= 0 && j != i && !mm_excluded<R>(ex, j)) {
+      // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
+      // direct table: a bucket is one cell
+      bool mine = true;
+      if (!g.direct && cell < 27) {
+        int jx, jy, jz;
+        cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
+        mine = (jx == s_c[w][cell][0] && jy == s_c[w][cell][1] && jz == s_c[w][cell][2]);
+      }
+      if (mine) {
+        const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
+        hit = dx * dx + dy * dy + dz * dz < rl2;
       }
     }
     const unsigned long long m = __ballot(hit);
