@@ -39,11 +39,13 @@ def case(bp, frames, dtype, reps=20):
     for name, kw in (("energy", {}), ("energy+forces", {"grads": True}), ("energy+forces+dU/dtheta", {"grads": True, "param_grads": True})):
         s.energy(cd, qd, **kw)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        per_call = []  # median of synchronised calls: one allocator or clock hiccup in twenty must not set the figure
         for _ in range(reps):
+            t0 = time.perf_counter()
             s.energy(cd, qd, **kw)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / reps
+            torch.cuda.synchronize()
+            per_call.append(time.perf_counter() - t0)
+        dt = float(np.median(per_call))
         out[name] = {"ms_per_call": 1e3 * dt, "frames_per_s": frames / dt}
     return out
 
