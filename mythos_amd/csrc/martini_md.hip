@@ -310,88 +310,113 @@ __device__ __forceinline__ bool mm_excluded(const int* __restrict__ ex, int j) {
   return hit;
 }
 
-template <typename R>
+// G lanes per bead (kMmRowG): the rows of 64 / G beads are built side by side in one wavefront.  The kernel is
+// VALU-bound (SQ_ACTIVE_INST_VALU x 4 clocks / SIMDs = 75 % of its time): ~2.2 instructions per candidate, but a bead
+// has 400-750 candidates in its 27 cells of which ~112 are inside the list range (cells of the full range: the
+// sphere is 15 % of the 27-cell volume).  16, 32 and 64 lanes per bead take the same time; 8 is slower.
+#ifndef MYTHOS_MM_ROW_G
+#define MYTHOS_MM_ROW_G 16
+#endif
+constexpr int kMmRowG = MYTHOS_MM_ROW_G;
+
+template <typename R, int G>
 __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, const CellGrid<R> g, R rl2,
-    const int* __restrict__ excl, const int* __restrict__ cell_cnt, const int* __restrict__ bucket, int cell_cap,
-    const int* __restrict__ spill, int cell_H,
-    int* __restrict__ rows,
-    int* __restrict__ row_len, int row_stride, int* __restrict__ overflow, typename Real4<R>::type* __restrict__ ref_pos) {
-  __shared__ int s_pre[4][29], s_st[4][28], s_c[4][28][3];
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + w;
+    const int* __restrict__ excl, const int* __restrict__ cell_cnt,
+    const typename CellPlace<R>::type* __restrict__ place, int cell_cap, const int* __restrict__ spill, int cell_H,
+    int* __restrict__ rows, int* __restrict__ row_len, int row_stride, int* __restrict__ overflow,
+    typename Real4<R>::type* __restrict__ ref_pos) {
+  constexpr int NG = 256 / G;  // beads per workgroup
+  __shared__ int s_pre[NG][29], s_st[NG][28], s_c[NG][28][3];
+  const int grp = threadIdx.x / G, l = threadIdx.x % G;
+  const int gshift = (threadIdx.x & 63) & ~(G - 1);  // first lane of this group inside its wavefront
+  const int i = blockIdx.x * NG + grp;
   if (i >= n) return;
   const auto pi = pos[i];
   int cx, cy, cz;
   cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
-  int cnt = 0;
-  if (lane < 27) {
-    int c[3] = {cx + lane % 3 - 1, cy + (lane / 3) % 3 - 1, cz + lane / 9 - 1};
+  for (int k = l; k < 28; k += G) {
+    int cnt;
+    if (k < 27) {
+      int c[3] = {cx + k % 3 - 1, cy + (k / 3) % 3 - 1, cz + k / 9 - 1};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) c[k] = (c[k] + g.nc[k]) % g.nc[k];
-    const int h = cell_slot(g, c[0], c[1], c[2]);
-    cnt = min(cell_cnt[h], cell_cap);
-    s_st[w][lane] = h * cell_cap;
-    s_c[w][lane][0] = c[0], s_c[w][lane][1] = c[1], s_c[w][lane][2] = c[2];
-  } else if (lane == 27) {  // the spill list: particles whose bucket was full, candidates for every row
-    cnt = min(cell_cnt[cell_H], kCellSpill);
+      for (int a = 0; a < 3; ++a) c[a] = (c[a] + g.nc[a]) % g.nc[a];
+      const int h = cell_slot(g, c[0], c[1], c[2]);
+      cnt = min(cell_cnt[h], cell_cap);
+      s_st[grp][k] = h * cell_cap;
+      s_c[grp][k][0] = c[0], s_c[grp][k][1] = c[1], s_c[grp][k][2] = c[2];
+    } else {  // the spill list: particles whose bucket was full, candidates for every row
+      cnt = min(cell_cnt[cell_H], kCellSpill);
+    }
+    s_pre[grp][k + 1] = cnt;
   }
-  int inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 32; o <<= 1) {
-    const int v = __shfl_up(inc, o, 64);
-    if (lane >= o) inc += v;
-  }
-  if (lane < 28) s_pre[w][lane + 1] = inc;
-  if (lane == 0) s_pre[w][0] = 0;
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = __shfl(inc, 27, 64);
+  if (l == 0) {
+    int run = 0;
+    s_pre[grp][0] = 0;
+    for (int k = 1; k <= 28; ++k) {
+      run += s_pre[grp][k];
+      s_pre[grp][k] = run;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = s_pre[grp][28];
   int ex[kMaxExcl];
 #pragma unroll
   for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
+  // excluded partners are beads of the same molecule, whose indices lie in a short window around i: the eight
+  // comparisons run only in sweeps where some candidate falls inside it
+  int ex_lo = 0x7fffffff, ex_hi = -1;
+#pragma unroll
+  for (int q = 0; q < kMaxExcl; ++q)
+    if (ex[q] >= 0) ex_lo = min(ex_lo, ex[q]), ex_hi = max(ex_hi, ex[q]);
   int* row = rows + (size_t)i * row_stride;
+  constexpr unsigned int kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+  const unsigned int below = (1u << l) - 1u;
   int out = 0;
-  int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by 64 per sweep
-  // One sweep ahead: the bucket entry and the position of the candidate of sweep s + 1 are requested before sweep s
-  // is evaluated (a bead has ~400 candidates, seven sweeps; their two dependent reads each would otherwise add up)
-  auto candidate = [&](int t, int& cell) -> int {
-    if (t >= total) return -1;
-    while (s_pre[w][lo + 1] <= t) ++lo;
-    cell = lo;
-    return (lo < 27) ? bucket[s_st[w][lo] + (t - s_pre[w][lo])] : spill[t - s_pre[w][27]];
-  };
-  int cell_nxt = 0;
-  int j_nxt = candidate(lane, cell_nxt);
-  auto p_nxt = pos[j_nxt >= 0 ? j_nxt : i];
-  for (int t0 = 0; t0 < total; t0 += 64) {
-    const int j = j_nxt, cell = cell_nxt;
-    const auto pj = p_nxt;
-    j_nxt = candidate(t0 + 64 + lane, cell_nxt);
-    p_nxt = pos[j_nxt >= 0 ? j_nxt : i];
+  int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by G per sweep
+  for (int t0 = 0; t0 < total; t0 += G) {
+    const int t = t0 + l;
     bool hit = false;
-    if (j >= 0 && j != i && !mm_excluded<R>(ex, j)) {
-      // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
-      // direct table: a bucket is one cell
-      bool mine = true;
-      if (!g.direct && cell < 27) {
-        int jx, jy, jz;
-        cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
-        mine = (jx == s_c[w][cell][0] && jy == s_c[w][cell][1] && jz == s_c[w][cell][2]);
+    int j = -1;
+    if (t < total) {
+      while (s_pre[grp][lo + 1] <= t) ++lo;
+      typename CellPlace<R>::type pj;  // position and index of the candidate arrive together, a contiguous stream per cell
+      if (lo < 27) {
+        pj = place[s_st[grp][lo] + (t - s_pre[grp][lo])];
+        j = cell_index_of(pj.w);
+      } else {
+        j = spill[t - s_pre[grp][27]];
+        const auto q = pos[j];
+        pj.x = q.x, pj.y = q.y, pj.z = q.z;
       }
-      if (mine) {
-        const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
-        hit = dx * dx + dy * dy + dz * dz < rl2;
+      bool keep = j != i;
+      if (keep && j >= ex_lo && j <= ex_hi) keep = !mm_excluded<R>(ex, j);
+      if (keep) {
+        // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
+        // direct table: a bucket is one cell
+        bool mine = true;
+        if (!g.direct && lo < 27) {
+          int jx, jy, jz;
+          cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
+          mine = (jx == s_c[grp][lo][0] && jy == s_c[grp][lo][1] && jz == s_c[grp][lo][2]);
+        }
+        if (mine) {
+          const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
+          hit = dx * dx + dy * dy + dz * dz < rl2;
+        }
       }
     }
-    const unsigned long long m = __ballot(hit);
+    const unsigned int m = (unsigned int)(__ballot(hit) >> gshift) & kGroupMask;
     if (hit) {
-      const int slot = out + __popcll(m & ((1ull << lane) - 1ull));
+      const int slot = out + __popc(m & below);
       if (slot < row_stride) row[slot] = j;
     }
-    out += __popcll(m);
+    out += __popc(m);
   }
-  if (lane == 0) {
+  if (l == 0) {
     if (out > row_stride) {
       atomicMax(overflow, out);
       out = row_stride;
@@ -455,7 +480,7 @@ struct mythos_martini_sim {
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
-  int cell_H = 0, cell_bucket_cap = 64, cell_phase = 0;
+  int cell_H = 0, cell_alloc_bucket_cap = 0, cell_bucket_cap = 64, cell_phase = 0;
   int row_stride = 256;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -501,24 +526,25 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
     const int H = g.direct ? (int)n_cells : next_pow2(2 * n);
     if (cell_cap_override()) sim->cell_bucket_cap = cell_cap_override();
     const int cap = sim->cell_bucket_cap;
-    const size_t need = CellBins::ints(H, cap);
-    if (need > sim->cell_cap || H != sim->cell_H) {
+    const size_t need = CellBins::ints(H, cap, sizeof(R));
+    if (need > sim->cell_cap || H != sim->cell_H || cap != sim->cell_alloc_bucket_cap) {
       if (sim->d_cell) (void)hipFree(sim->d_cell);
       sim->d_cell = nullptr;
       sim->cell_cap = 0;
       MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_cell, need * sizeof(int)));
-      MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_cell, 0, 2 * CellBins::half(H) * sizeof(int), st));
+      MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_cell + CellBins::zero_offset(H, cap, sizeof(R)), 0, CellBins::zero_ints(H) * sizeof(int), st));
       sim->cell_cap = need;
       sim->cell_H = H;
+      sim->cell_alloc_bucket_cap = cap;
       sim->cell_phase = 0;
     }
-    const CellBins bins(sim->d_cell, H, cap, sim->cell_phase);
+    const CellBins bins(sim->d_cell, H, cap, sizeof(R), sim->cell_phase);
     sim->cell_phase ^= 1;
     // buckets sorted by bead index: the row builder copies candidates in bucket order, and rows must not depend on
     // the order in which the binning atomics landed
     cell_bins_build<R, true>(n, reinterpret_cast<const R*>(pos), g, bins, sim->d_overflow, true, st);
-    hipLaunchKernelGGL(mm_build_rows_cells_kernel<R>, dim3(wb), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl,
-                       bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos);
+    hipLaunchKernelGGL((mm_build_rows_cells_kernel<R, kMmRowG>), dim3((n + 256 / kMmRowG - 1) / (256 / kMmRowG)), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl,
+                       bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos);
   }
   return 0;
 }

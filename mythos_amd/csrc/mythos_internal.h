@@ -69,6 +69,7 @@ struct mythos_system {
   int* d_cell = nullptr;      // cell table (cell_list.h CellBins): counters [2][H], buckets [H][cell_bucket_cap]
   size_t cell_cap = 0;        // ints allocated at d_cell
   int cell_H = 0;             // table slots of the current allocation
+  int cell_alloc_bucket_cap = 0;  // places per slot the allocation was laid out for
   int cell_bucket_cap = 32;   // places per slot
   int cell_phase = 0;         // which counter half the next build counts into
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)

@@ -204,8 +204,8 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
                                                                 const SiteCrit<R> sc,
                                                                 const int* __restrict__ partners,
                                                                 const int* __restrict__ cell_cnt,
-                                                                const int* __restrict__ bucket, int cell_cap,
-                                                                const int* __restrict__ spill, int cell_H,
+                                                                const typename CellPlace<R>::type* __restrict__ place,
+                                                                int cell_cap, const int* __restrict__ spill, int cell_H,
                                                                 int* __restrict__ rows,
                                                                 int* __restrict__ row_len, int* __restrict__ row_close,
                                                                 int row_stride, int* __restrict__ overflow,
@@ -266,9 +266,16 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     int j = -1;
     if (t < total) {
       while (s_pre[grp][lo + 1] <= t) ++lo;
-      j = (lo < 27) ? bucket[s_st[grp][lo] + (t - s_pre[grp][lo])] : spill[t - s_pre[grp][27]];
+      R xj, yj, zj;
+      if (lo < 27) {  // position and index of the candidate arrive together, as a contiguous stream per cell
+        const typename CellPlace<R>::type pl = place[s_st[grp][lo] + (t - s_pre[grp][lo])];
+        xj = pl.x, yj = pl.y, zj = pl.z;
+        j = cell_index_of(pl.w);
+      } else {
+        j = spill[t - s_pre[grp][27]];
+        xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
+      }
       if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
-        const R xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
         bool mine = true;  // hashed table: a bucket may mix cells, a candidate counts for the cell it lies in
         if (!g.direct && lo < 27) {
           int jx, jy, jz;
@@ -394,18 +401,19 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const int H = next_pow2(2 * n);
   if (cell_cap_override()) sys->cell_bucket_cap = cell_cap_override();
   const int cap = sys->cell_bucket_cap;
-  const size_t need = CellBins::ints(H, cap);
-  if (need > sys->cell_cap || H != sys->cell_H) {
+  const size_t need = CellBins::ints(H, cap, sizeof(R));
+  if (need > sys->cell_cap || H != sys->cell_H || cap != sys->cell_alloc_bucket_cap) {
     if (sys->d_cell) (void)hipFree(sys->d_cell);
     sys->d_cell = nullptr;
     sys->cell_cap = 0;
     MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
-    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_cell, 0, 2 * CellBins::half(H) * sizeof(int), st));
+    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_cell + CellBins::zero_offset(H, cap, sizeof(R)), 0, CellBins::zero_ints(H) * sizeof(int), st));
     sys->cell_cap = need;
     sys->cell_H = H;
+    sys->cell_alloc_bucket_cap = cap;
     sys->cell_phase = 0;
   }
-  const CellBins bins(sys->d_cell, H, cap, sys->cell_phase);
+  const CellBins bins(sys->d_cell, H, cap, sizeof(R), sys->cell_phase);
   sys->cell_phase ^= 1;
   // the row builder orders its rows itself: no bucket sort
   if (vec4)
@@ -417,11 +425,11 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const size_t far_lds = (size_t)kPerBlock * 2 * sys->row_stride * sizeof(int);
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, bins.bucket, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;
 }
