@@ -154,6 +154,11 @@ int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, d
 int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double* times, double* box, double* energies,
                                  double* frames, int* n_frames);
 
+/* Writer for the same format (mythos/input/trajectory.py:322-331, mythos/simulators/io.py:146-170): host buffers
+ * times[F], box[F][3], energies[F][3], frames[F][n][15]; 15 significant digits; append != 0 adds to an existing file. */
+int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const double* times, const double* box,
+                                  const double* energies, const double* frames, int append);
+
 /* ---- MARTINI 2/3 ------------------------------------------------------------------------------
  * Replaces mythos/energy/martini/m2/{lj,bond,angle}.py and m3/angle.py.
  *   types        host int32[n]            bead type index

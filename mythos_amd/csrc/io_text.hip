@@ -177,4 +177,67 @@ int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double
   return MYTHOS_OK;
 }
 
+// Writer: the text of every frame is produced concurrently into its own buffer (std::to_chars, 15 significant
+// digits like "%.15g"), then the buffers are written in order.  Replaces the reference's per-frame numpy.savetxt
+// (mythos/input/trajectory.py:322-331, mythos/simulators/io.py:146-170).
+int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const double* times, const double* box,
+                                  const double* energies, const double* frames, int append) {
+  if (!path || n < 1 || n_frames < 0 || (n_frames > 0 && (!times || !box || !energies || !frames))) {
+    mythos::set_error("mythos_oxdna_write_trajectory: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  FILE* f = std::fopen(path, append ? "ab" : "wb");
+  if (!f) {
+    mythos::set_error(std::string("mythos_oxdna_write_trajectory: cannot open ") + path);
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  auto put = [](std::string& out, double v) {
+    char tmp[40];
+    const auto r = std::to_chars(tmp, tmp + sizeof(tmp), v, std::chars_format::general, 15);
+    out.append(tmp, r.ptr);
+  };
+  auto format_frame = [&](int k, std::string& out) {
+    out.clear();
+    out.reserve((size_t)n * 15 * 20 + 128);
+    out += "t = ";
+    put(out, times[k]);
+    out += "\nb =";
+    for (int a = 0; a < 3; ++a) out += ' ', put(out, box[3 * (size_t)k + a]);
+    out += "\nE =";
+    for (int a = 0; a < 3; ++a) out += ' ', put(out, energies[3 * (size_t)k + a]);
+    out += '\n';
+    const double* fr = frames + (size_t)k * n * 15;
+    for (int i = 0; i < n; ++i) {
+      for (int c = 0; c < 15; ++c) {
+        if (c) out += ' ';
+        put(out, fr[(size_t)i * 15 + c]);
+      }
+      out += '\n';
+    }
+  };
+  const size_t frame_bytes = (size_t)n * 15 * 20;
+  const int threads = (int)std::min<size_t>({(size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)8,
+                                             (size_t)std::max(n_frames, 1), frame_bytes * (size_t)n_frames / (4u << 20) + 1});
+  // batches of `threads` frames: formatted side by side, written in order
+  std::vector<std::string> buf((size_t)threads);
+  bool ok = true;
+  for (int k0 = 0; k0 < n_frames && ok; k0 += threads) {
+    const int m = std::min(threads, n_frames - k0);
+    if (m == 1) {
+      format_frame(k0, buf[0]);
+    } else {
+      std::vector<std::thread> pool;
+      for (int q = 0; q < m; ++q) pool.emplace_back([&, q] { format_frame(k0 + q, buf[(size_t)q]); });
+      for (auto& th : pool) th.join();
+    }
+    for (int q = 0; q < m && ok; ++q) ok = std::fwrite(buf[(size_t)q].data(), 1, buf[(size_t)q].size(), f) == buf[(size_t)q].size();
+  }
+  if (std::fclose(f) != 0) ok = false;
+  if (!ok) {
+    mythos::set_error(std::string("mythos_oxdna_write_trajectory: write to ") + path + " failed");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  return MYTHOS_OK;
+}
+
 }  // extern "C"

@@ -157,11 +157,12 @@ class Trajectory:
             box_size=self.box_size,
         )
 
-    def to_file(self, filepath) -> None:
+    def to_file(self, filepath, *, native: bool | None = None) -> None:
+        """``native``: True = the C++ writer of libmythos_hip.so (frames formatted concurrently), False = numpy,
+        None = native when the library is built.  Both write 15 significant digits."""
         box = self.box_size if self.box_size is not None else (0, 0, 0)
-        with Path(filepath).open("w") as f:
-            for t, e, fr in zip(self.times, self.energies, self.frames):
-                write_state(f, float(t), e, fr, box)
+        write_frames(filepath, self.times, np.broadcast_to(np.asarray(box, dtype=np.float64), (len(self.times), 3)),
+                     self.energies, self.frames, native=native)
 
 
 def write_state(file, time, energies, state, box_size=(0, 0, 0)) -> None:
@@ -170,6 +171,31 @@ def write_state(file, time, energies, state, box_size=(0, 0, 0)) -> None:
     file.write(f"b = {box_size[0]} {box_size[1]} {box_size[2]}\n")
     file.write(f"E = {energies[0]} {energies[1]} {energies[2]}\n")
     np.savetxt(file, np.asarray(state), fmt="%.15g")
+
+
+def write_frames(filepath, times, boxes, energies, frames, *, native: bool | None = None) -> None:
+    """Write (S,) times, (S, 3) boxes, (S, 3) energies and (S, N, 15) frames as an oxDNA text trajectory."""
+    times = np.ascontiguousarray(times, dtype=np.float64).reshape(-1)
+    s = len(times)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64).reshape(s, 3)
+    energies = np.ascontiguousarray(energies, dtype=np.float64).reshape(s, 3)
+    frames = np.ascontiguousarray(frames, dtype=np.float64)
+    if frames.ndim != 3 or frames.shape[0] != s or frames.shape[2] != 15:
+        raise ValueError(ERR_STATE_SHAPE + str(frames.shape))
+    if native is None:
+        from mythos_amd import _lib
+
+        native = _lib.lib_path().exists()
+    if native and s and frames.shape[1]:
+        from mythos_amd import _lib
+
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)  # noqa: E731
+        _lib.check(_lib.load().mythos_oxdna_write_trajectory(str(filepath).encode(), frames.shape[1], s, dp(times), dp(boxes),
+                                                             dp(energies), dp(frames), 0), "write_trajectory")
+        return
+    with Path(filepath).open("w") as f:
+        for k in range(s):
+            write_state(f, float(times[k]), energies[k], frames[k], boxes[k])
 
 
 def _read_native(path: Path, n: int):

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from mythos_amd.energy.base import Quaternion, RigidBody
-from mythos_amd.input.trajectory import quaternion_to_axes, write_state
+from mythos_amd.input.trajectory import quaternion_to_axes, write_frames
 
 
 @dc.dataclass(frozen=True)
@@ -76,16 +76,16 @@ class SimulatorTrajectory(RigidBody):
     def __add__(self, other: "SimulatorTrajectory") -> "SimulatorTrajectory":
         return type(self).concat([self, other])
 
-    def to_file(self, filepath, box_size=(0, 0, 0)) -> None:
+    def to_file(self, filepath, box_size=(0, 0, 0), *, native: bool | None = None) -> None:
         """oxDNA text trajectory; velocities, angular momenta and energies are written as zeros
         (mythos/simulators/io.py:146-170)."""
         c = self.center.detach().cpu().double().numpy()
         a1, _, a3 = quaternion_to_axes(self.orientation.vec.detach().cpu().double().numpy())
-        with Path(filepath).open("w") as f:
-            for i in range(self.length()):
-                state = np.hstack([c[i], a1[i], a3[i], np.zeros((c.shape[1], 6))])
-                box = self.box_size[i].tolist() if self.box_size is not None else box_size
-                write_state(f, float(i), np.zeros(3), state, box)
+        s, n = c.shape[0], c.shape[1]
+        frames = np.concatenate([c, a1, a3, np.zeros((s, n, 6))], axis=2)
+        boxes = self.box_size.detach().cpu().double().numpy() if self.box_size is not None else np.broadcast_to(
+            np.asarray(box_size, dtype=np.float64), (s, 3))
+        write_frames(filepath, np.arange(s, dtype=np.float64), boxes, np.zeros((s, 3)), frames, native=native)
 
 
 def _concat_optional(values, label):

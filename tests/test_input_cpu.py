@@ -129,6 +129,48 @@ def test_native_trajectory_reader_matches_the_numpy_parse(tmp_path):
     assert trajectory.from_file(e, [2], native=True).frames.shape == (0, 2, 15)
 
 
+def test_native_trajectory_writer_round_trips_and_matches_the_numpy_writer(tmp_path):
+    """mythos_oxdna_write_trajectory: what it writes parses back to the same arrays as what numpy.savetxt writes
+    (15 significant digits both), headers included; written by several threads, frames stay in order."""
+    from mythos_amd import _lib
+
+    if not _lib.lib_path().exists():
+        pytest.skip("libmythos_hip.so not built")
+    rng = np.random.default_rng(5)
+    n, s = 37, 23
+    frames = rng.normal(size=(s, n, 15)) * 10.0 ** rng.integers(-8, 8, size=(s, n, 15))
+    frames[0, 0, :3] = [0.0, -0.0, 1e-300]
+    traj = trajectory.Trajectory(n_nucleotides=n, strand_lengths=[30, 7], times=np.arange(s) * 1e3 + 0.5,
+                                 energies=rng.normal(size=(s, 3)), frames=frames, box_size=np.array([12.5, 13.0, 1e2]))
+    a, b = tmp_path / "native.dat", tmp_path / "numpy.dat"
+    traj.to_file(a, native=True)
+    traj.to_file(b, native=False)
+    ra = trajectory.from_file(a, [30, 7], is_5p_3p=False, native=False)
+    rb = trajectory.from_file(b, [30, 7], is_5p_3p=False, native=False)
+    assert np.array_equal(ra.frames, rb.frames) and np.array_equal(ra.times, rb.times)
+    assert np.array_equal(ra.box_size, rb.box_size)
+    np.testing.assert_allclose(ra.energies, rb.energies, rtol=1e-14)  # the Python header prints floats in full
+    np.testing.assert_allclose(ra.frames, frames, rtol=1e-14, atol=0)
+    assert np.array_equal(ra.times, traj.times)
+    # the frame text itself is the same as numpy's (the header lines differ only in how Python prints a float)
+    body = lambda p: [ln for ln in p.read_text().splitlines() if ln[0] not in "tbE"]  # noqa: E731
+    assert body(a) == body(b)
+    # SimulatorTrajectory.to_file goes through the same writer
+    import torch
+
+    from mythos_amd.energy.base import Quaternion
+    from mythos_amd.simulators.io import SimulatorTrajectory
+
+    q = rng.normal(size=(3, n, 4))
+    q /= np.linalg.norm(q, axis=-1, keepdims=True)
+    st = SimulatorTrajectory(center=torch.as_tensor(frames[:3, :, :3]), orientation=Quaternion(vec=torch.as_tensor(q)))
+    st.to_file(tmp_path / "sim_native.dat", native=True)
+    st.to_file(tmp_path / "sim_numpy.dat", native=False)
+    sa = trajectory.from_file(tmp_path / "sim_native.dat", [30, 7], is_5p_3p=False)
+    sb = trajectory.from_file(tmp_path / "sim_numpy.dat", [30, 7], is_5p_3p=False)
+    assert np.array_equal(sa.frames, sb.frames) and sa.times.tolist() == [0.0, 1.0, 2.0]
+
+
 def test_default_parameters_and_toml_subset(tmp_path):
     sim1, e1 = defaults.default_configs_for("dna1")
     sim2, e2 = defaults.default_configs_for("dna2")
