@@ -28,6 +28,7 @@
 
 #include <hip/hip_ext.h>
 
+#include "chunk_order.h"
 #include "oxdna_gather.h"
 #include "philox.h"
 
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     int extra_bonds, R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos,
     const typename Vec4T<R>::type* __restrict__ ref_off, const typename Vec4T<R>::type* __restrict__ ref_a1,
     int* __restrict__ flags,
-    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, int ablate_arg) {
+    R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, const int* __restrict__ chunk_order,
+    int ablate_arg) {
   using V4 = typename Vec4T<R>::type;
   const int ablate = MD_ABLATE(ablate_arg);
   constexpr int G = kMdG, PPB = kMdPPB;
@@ -247,8 +249,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // takes chunk (b % 8) * ceil(n_blocks / 8) + b / 8 - every XCD then owns one contiguous eighth of the
   // nucleotide index range and neighbouring chunks (same strand, adjacent cells) share its L2.
   const int n_blocks = (n + PPB - 1) / PPB;
-  const int bid = (int)(blockIdx.x & 7) * ((n_blocks + 7) >> 3) + (int)(blockIdx.x >> 3);
-  if (bid >= n_blocks) return;  // grid is padded to a multiple of 8; whole workgroup leaves together
+  const int vb = (int)(blockIdx.x & 7) * ((n_blocks + 7) >> 3) + (int)(blockIdx.x >> 3);
+  if (vb >= n_blocks) return;  // grid is padded to a multiple of 8; whole workgroup leaves together
+  // chunk_order (host, from the positions at the start of a run): the chunks of 32 nucleotides in spatial order, so
+  // the contiguous eighth an XCD works on is also contiguous in space - in a duplex the two complementary
+  // stretches of the strands, which are far apart in index, land on the same XCD and share its L2
+  const int bid = chunk_order ? chunk_order[vb] : vb;
   const int i = bid * PPB + grp;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;  // out-of-range groups shadow the last nucleotide and discard
@@ -901,6 +907,8 @@ struct mythos_sim {
   bool keep_valid = false;
   void *mom = nullptr, *ang = nullptr;
   int* d_flags = nullptr;
+  int* d_chunk_order = nullptr;  // [blocks] spatial order of the 32-nucleotide chunks (null: index order)
+  int chunk_order_age = 0;       // runs since it was computed
   double* d_epart = nullptr;
   int epart_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -959,6 +967,18 @@ static Frame<R> frame_of(const mythos_sim* sim, int k) {
                   (V4*)sim->frame[k][4], (V4*)sim->frame[k][5]};
 }
 
+// Spatial order of the workgroups' chunks (chunk_order.h): one strided copy of a position per chunk to the host, a
+// sort, one small upload; redone every 16th run (molecules drift slowly, and a stale order costs speed, not
+// correctness).  Systems under 64 chunks do not bother.
+template <typename R>
+static int update_chunk_order(mythos_sim* sim, const typename Vec4T<R>::type* p0, int blocks, hipStream_t st) {
+  if (blocks < 64) return 0;
+  if (sim->d_chunk_order && (++sim->chunk_order_age & 15) != 0) return 0;
+  MYTHOS_HIP_TRY(chunk_order_update(p0, blocks, kMdPPB, std::max(1.0, sim->r_cut > 0 ? sim->r_cut : 4.0), &sim->d_chunk_order, st));
+  sim->chunk_order_age = 0;
+  return 0;
+}
+
 template <typename R, int MODEL>
 static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, int n_steps, int save_every,
                      R* traj_center, R* traj_quat, double* e_trace, hipStream_t st) {
@@ -989,6 +1009,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   const int ablate = 0;
 #endif
   const bool dynamic_list = sim->rebuild_every > 0;
+  if (int rc = update_chunk_order<R>(sim, fr[cur].p0, blocks, st)) return rc;
   auto rebuild = [&](int buf) -> int {
     return rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, fr[buf].p1, true, st);
   };
@@ -1019,7 +1040,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     if (save) {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
       hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                          e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
     } else if (sampled) {
@@ -1028,12 +1049,12 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
                             sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
                             sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
-                            sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                            sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
       ++samples;
     } else {
       hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                          fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, ablate);
+                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
     }
     ++launches;
     cur ^= 1;
@@ -1153,6 +1174,7 @@ void mythos_langevin_destroy(mythos_sim_t* s) {
   if (s->mom) (void)hipFree(s->mom);
   if (s->ang) (void)hipFree(s->ang);
   if (s->d_flags) (void)hipFree(s->d_flags);
+  if (s->d_chunk_order) (void)hipFree(s->d_chunk_order);
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
