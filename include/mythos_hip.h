@@ -146,6 +146,13 @@ int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, double* loop_ms_per_launch,
                                    int* launches, int* samples);
 
+/* How often the last run halted and resumed: a site left its skin before the scheduled rebuild, or a rebuild
+ * overflowed its rows / cell buckets.  The launches behind such an event do nothing; the run rebuilds at the last
+ * valid state (growing what overflowed) and continues there, so neither is an error - the reference's neighbour
+ * list signals `did_buffer_overflow` and leaves the reallocation to the caller (jax_md partition, used at
+ * mythos/simulators/jax_md/utils.py:70-126).  More than 64 in one run fails with MYTHOS_ERR_OVERFLOW. */
+int mythos_langevin_last_recoveries(const mythos_sim_t* sim, int* recoveries);
+
 /* ---- oxDNA text trajectories (host only) -----------------------------------------------------
  * Replaces the Python parse of mythos/input/trajectory.py:192-320 (frames of `t = / b = / E =` header lines and
  * n rows of 15 numbers: com, a1, a3, v, L).  Call once with frames == NULL to count (n_frames out), then with

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     const typename Vec4T<R>::type* __restrict__ ref_off, const typename Vec4T<R>::type* __restrict__ ref_a1,
     int* __restrict__ flags,
     R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, const int* __restrict__ chunk_order,
-    int ablate_arg) {
+    const int* __restrict__ list_overflow, int k_index, int ablate_arg) {
   using V4 = typename Vec4T<R>::type;
   const int ablate = MD_ABLATE(ablate_arg);
   constexpr int G = kMdG, PPB = kMdPPB;
@@ -251,6 +251,14 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   const int n_blocks = (n + PPB - 1) / PPB;
   const int vb = (int)(blockIdx.x & 7) * ((n_blocks + 7) >> 3) + (int)(blockIdx.x >> 3);
   if (vb >= n_blocks) return;  // grid is padded to a multiple of 8; whole workgroup leaves together
+  // Halted (flags[1], set by the previous step when a site left its skin; or a rebuild overflowed its rows or spill
+  // list): this and every later launch of the segment do nothing, the state stays at the last valid step, and the
+  // host rebuilds and resumes from flags[2] (kernel index after the last one that ran).
+  // One lane requests the words here; everybody looks at them behind the first barrier (LDS), before which the
+  // kernel writes nothing to global memory.  (Every thread loading and testing them up front cost 1.7 % of the step.)
+  __shared__ int s_halt;
+  int halt_word = 0;  // requested now, parked in LDS just before the barrier: nobody waits for it on the way
+  if (threadIdx.x == 0) halt_word = flags[1] | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
   // chunk_order (host, from the positions at the start of a run): the chunks of 32 nucleotides in spatial order, so
   // the contiguous eighth an XCD works on is also contiguous in space - in a duplex the two complementary
   // stretches of the strands, which are far apart in index, land on the same XCD and share its L2
@@ -483,9 +491,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
 #pragma unroll
     for (int t = 0; t < 2; ++t) item_cnt[t][grp] = valid ? n_items[t] : 0;
   }
+  if (threadIdx.x == 0) s_halt = halt_word;
   MD_STAMP(1);
   __syncthreads();  // self_lds, rad_lds and item_cnt are visible
   MD_STAMP(2);
+  if (s_halt != 0) return;  // halted: nothing has been written to global memory yet
+  if (vb == 0 && threadIdx.x == 0) flags[2] = k_index + 1;
 
   // ---- phase 2: angular pass, work items spread over the whole workgroup so that every wavefront
   //      runs ONE code path (roles below).  Results go to the owner's result rows in LDS.
@@ -766,7 +777,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const R sx = dx + gb * (n1.x - a0.x), sy = dy + gb * (n1.y - a0.y), sz = dz + gb * (n1.z - a0.z);
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq || bx * bx + by * by + bz * bz > K.skin_half_sq ||
             sx * sx + sy * sy + sz * sz > K.skin_half_sq)
-          atomicOr(flags, 1);
+          atomicOr(flags + 1, 1);  // the list is stale for the NEXT force evaluation: halt before it
       }
     }
     out.p0[i] = V4{x[0], x[1], x[2], self_lds[il][9]};
@@ -906,7 +917,9 @@ struct mythos_sim {
   void *keep_hi = nullptr, *keep_lo = nullptr;
   bool keep_valid = false;
   void *mom = nullptr, *ang = nullptr;
+  static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN, 4 angular items), [1] halt, [2] progress
   int* d_flags = nullptr;
+  int last_recoveries = 0;       // halts of the last run that were rebuilt and resumed
   int* d_chunk_order = nullptr;  // [blocks] spatial order of the 32-nucleotide chunks (null: index order)
   int chunk_order_age = 0;       // runs since it was computed
   double* d_epart = nullptr;
@@ -997,7 +1010,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   V4* mom = (V4*)sim->mom;
   V4* ang = (V4*)sim->ang;
   const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
-  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, sizeof(int), st));
+  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, mythos_sim::kCtlWords * sizeof(int), st));
   hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
                      sys->d_meta, fr[0], mom, ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
                      (const R*)sim->keep_lo);
@@ -1021,44 +1034,75 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       return rc;
   }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
-  int launches = 0, samples = 0;
+  int launches = 0, samples = 0, recoveries = 0;
   const int sample_stride = std::max(1, (n_steps + 1) / mythos_sim::kMaxSamples);
-  for (int k = 0; k <= n_steps; ++k) {
-    const bool last = (k == n_steps);
-    const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
-    const int sidx = save ? (k / save_every - 1) : 0;
-    if (dynamic_list && k > 0 && !last && (k % sim->rebuild_every == 0))
-      if (int rc = rebuild(cur)) return rc;
-    const R kick_close = (k == 0) ? R(0) : R(0.5);
-    const int do_step = last ? 0 : 1;
-    R* tc = (save && traj_center) ? traj_center + (size_t)sidx * n * 3 : nullptr;
-    R* tq = (save && traj_quat) ? traj_quat + (size_t)sidx * n * 4 : nullptr;
-    const V4* ref = (const V4*)sys->d_ref_pos;
-    const V4* ref_off = (const V4*)sys->d_ref_off;
-    const V4* ref_a1 = (const V4*)sys->d_ref_a1;
-    const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
-    if (save) {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
-      hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
-                         e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
-    } else if (sampled) {
-      // the event pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
-      // kernel trace reports), not the time between two markers in the queue
-      hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
-                            sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
-                            sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
-                            sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
-      ++samples;
-    } else {
-      hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                         fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                         do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, ablate);
+  const int* halt_words = dynamic_list ? sys->d_overflow : nullptr;
+  // The kernels of a run are queued in segments of kSegment; after each the host looks at the halt word.  A step that
+  // moves a site out of its skin, or a rebuild that overflows its rows or spill list, halts the launches behind it
+  // (they return at once); the host then rebuilds at the last valid state - growing what overflowed - and resumes
+  // there.  A run never integrates on a stale or truncated list, and neither condition is an error any more; what
+  // it costs is the empty launches behind the halt (at most a segment) and a synchronisation.
+  constexpr int kSegment = 8192, kMaxRecoveries = 64;
+  int k = 0;
+  while (k <= n_steps) {
+    const int seg_end = std::min(n_steps, k + kSegment - 1);
+    for (; k <= seg_end; ++k) {
+      const bool last = (k == n_steps);
+      const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
+      const int sidx = save ? (k / save_every - 1) : 0;
+      if (dynamic_list && k > 0 && !last && (k % sim->rebuild_every == 0))
+        if (int rc = rebuild(cur)) return rc;
+      const R kick_close = (k == 0) ? R(0) : R(0.5);
+      const int do_step = last ? 0 : 1;
+      R* tc = (save && traj_center) ? traj_center + (size_t)sidx * n * 3 : nullptr;
+      R* tq = (save && traj_quat) ? traj_quat + (size_t)sidx * n * 4 : nullptr;
+      const V4* ref = (const V4*)sys->d_ref_pos;
+      const V4* ref_off = (const V4*)sys->d_ref_off;
+      const V4* ref_a1 = (const V4*)sys->d_ref_a1;
+      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
+      if (save) {
+        hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
+                           fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
+                           do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+        hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
+                           e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
+      } else if (sampled) {
+        // the event pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
+        // kernel trace reports), not the time between two markers in the queue
+        hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
+                              sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
+                              sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
+                              sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+        ++samples;
+      } else {
+        hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
+                           fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
+                           do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+      }
+      ++launches;
+      cur ^= 1;
     }
-    ++launches;
-    cur ^= 1;
+    if (!dynamic_list) continue;
+    int ctl[mythos_sim::kCtlWords] = {0, 0, 0, 0}, ovs[kOverflowWords] = {0, 0, 0};
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ctl, sim->d_flags, sizeof(ctl), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ovs, sys->d_overflow, sizeof(ovs), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+    if ((ctl[0] & (2 | 4)) != 0) break;                          // NaN / angular items: reported below
+    if (ctl[1] == 0 && ovs[0] == 0 && ovs[1] == 0) continue;     // nothing halted
+    if (++recoveries > kMaxRecoveries) {
+      sim->step += ctl[2];
+      set_error("mythos_langevin_run: the neighbour list had to be rebuilt out of turn more than " + std::to_string(kMaxRecoveries) +
+                " times in one run: the skin (" + std::to_string(sim->skin) + ") is too small for a rebuild every " +
+                std::to_string(sim->rebuild_every) + " steps");
+      return MYTHOS_ERR_OVERFLOW;
+    }
+    k = ctl[2];   // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
+    cur = k & 1;
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
+    if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
+      return rc;
   }
+  sim->last_recoveries = recoveries;
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
   MYTHOS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, fr[cur], mom, ang, center, quat, p_lin,
@@ -1111,10 +1155,6 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
               " neighbours of one nucleotide are inside the range of an angular term");
     return MYTHOS_ERR_OVERFLOW;
   }
-  if (flags & 1) {
-    set_error("mythos_langevin_run: a nucleotide moved more than skin/2 between neighbour rebuilds");
-    return MYTHOS_ERR_OVERFLOW;
-  }
   return MYTHOS_OK;
 }
 
@@ -1148,7 +1188,7 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
     for (int a = 0; a < 6; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
   ok = ok && hipMalloc(&s->keep_hi, v4) == hipSuccess && hipMalloc(&s->keep_lo, v4) == hipSuccess;
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
-       hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
+       hipMalloc((void**)&s->d_flags, mythos_sim::kCtlWords * sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 64 * sizeof(double)) == hipSuccess &&
        hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
   for (int k = 0; ok && k < mythos_sim::kMaxSamples; ++k)
@@ -1266,6 +1306,15 @@ int mythos_langevin_last_kernel_ms(const mythos_sim_t* s, double* kernel_ms, dou
   if (loop_ms_per_launch) *loop_ms_per_launch = s->last_avg_ms;
   if (launches) *launches = s->last_launches;
   if (samples) *samples = s->last_samples;
+  return MYTHOS_OK;
+}
+
+int mythos_langevin_last_recoveries(const mythos_sim_t* s, int* recoveries) {
+  if (!s || !recoveries) {
+    set_error("mythos_langevin_last_recoveries: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  *recoveries = s->last_recoveries;
   return MYTHOS_OK;
 }
 

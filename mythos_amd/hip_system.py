@@ -225,6 +225,12 @@ class LangevinIntegrator:
     def step(self, value: int) -> None:
         _lib.check(self._lib.mythos_langevin_set_step(self._h, int(value)), "set_step")
 
+    def last_recoveries(self) -> int:
+        """Out-of-turn list rebuilds of the last run (a site left its skin early, or rows / buckets had to grow)."""
+        r = C.c_int(0)
+        _lib.check(self._lib.mythos_langevin_last_recoveries(self._h, C.byref(r)), "last_recoveries")
+        return int(r.value)
+
     def last_kernel_ms(self) -> dict:
         """HIP-event timings of the last run (see include/mythos_hip.h)."""
         k, loop, n, ns = C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)

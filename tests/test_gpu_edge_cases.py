@@ -149,6 +149,33 @@ def test_md_rows_grow_for_a_dense_system():
     assert mx > 64 and torch.isfinite(c).all(), (mx, mean)
 
 
+def test_md_rows_that_overflow_in_the_middle_of_a_run_grow_and_the_run_continues():
+    """Two duplexes start 12 units apart, out of each other's list range, and one drifts onto the other (NVE, a
+    centre-of-mass velocity).  Their rows, sized at the first build for a lone duplex, become too short at some
+    rebuild in the middle of the run: that rebuild halts the launches behind it, the run grows the rows and carries on
+    instead of failing."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from mythos_amd.utils import generators
+
+    top, c0, q0 = generators.duplex_bundle(24, 2, spacing=12.0, seed=5)
+    s = _system(2, top, None, dtype=torch.float32, hce=True)
+    integ = LangevinIntegrator(s, dt=0.005, kT=0.0987, gamma_t=0.0, gamma_r=0.0, seed=4)
+    integ.set_neighbor_policy(3.25, 3.5, 20)
+    c = torch.as_tensor(c0, dtype=torch.float32, device=s.device).contiguous()
+    q = torch.as_tensor(q0, dtype=torch.float32, device=s.device).contiguous()
+    p = torch.zeros_like(c)
+    L = torch.zeros_like(c)
+    half = top.n_nucleotides // 2
+    axis = torch.as_tensor(c0[half:].mean(0) - c0[:half].mean(0), dtype=torch.float32, device=s.device)
+    p[:half] = 0.8 * axis / axis.norm()  # towards the other duplex: 0.004 units per step
+    integ.run(c, q, p, L, 1)
+    first_max, _ = s.neighbor_stats()
+    integ.run(c, q, p, L, 2000)
+    mx, _ = s.neighbor_stats()
+    assert torch.isfinite(c).all() and mx > 64 and mx > 1.25 * first_max, (first_max, mx)
+    assert integ.last_recoveries() >= 1
+
+
 def test_md_partially_filled_workgroup_matches_the_oracle():
     """50 nucleotides = one full 32-nucleotide workgroup and one with 18 of 32 groups idle (and a padded grid)."""
     from mythos_amd.hip_system import LangevinIntegrator

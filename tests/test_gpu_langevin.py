@@ -179,13 +179,44 @@ def test_dynamic_verlet_list_matches_static_all_pairs():
     torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-9)
 
 
-def test_skin_violation_is_reported():
+def test_a_site_leaving_its_skin_halts_rebuilds_and_resumes_exactly():
+    """A skin far too small for the rebuild interval: the step that moves a site out of its skin halts the launches
+    queued behind it, the run rebuilds at that state and carries on.  The trajectory must equal the one on a static
+    all-pairs list (fp64, to summation order), with saved frames and energies at the right steps; the number of
+    recoveries is reported."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(48, model=2, seed=3)
+    outs, trajs, ens = [], [], []
+    for dynamic in (False, True):
+        s, _ = _make(2, top, None, torch.float64, hce=True)
+        integ = LangevinIntegrator(s, dt=0.003, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=99)
+        if dynamic:
+            integ.set_neighbor_policy(r_cut=3.3, skin=0.05, every=1000)  # skin / 2 = 0.025: a few steps
+        else:
+            s.set_neighbors(top.unbonded_neighbors)
+        c, q = _state(c0, q0, torch.float64, s.device)
+        p, L = integ.init_momenta()
+        tc, _, et = integ.run(c, q, p, L, 90, save_every=15)
+        outs.append(torch.cat([c.reshape(-1), q.reshape(-1), p.reshape(-1), L.reshape(-1)]))
+        trajs.append(tc.clone())
+        ens.append(et.clone())
+        if dynamic:
+            assert 3 <= integ.last_recoveries() <= 64, integ.last_recoveries()
+        else:
+            assert integ.last_recoveries() == 0
+    torch.testing.assert_close(outs[0], outs[1], rtol=0, atol=1e-9)
+    torch.testing.assert_close(trajs[0], trajs[1], rtol=0, atol=1e-9)
+    torch.testing.assert_close(ens[0], ens[1], rtol=1e-9, atol=1e-9)
+
+
+def test_hopeless_neighbour_policy_is_an_error_not_a_crawl():
     from mythos_amd.hip_system import LangevinIntegrator
 
     top, c0, q0 = generators.ideal_duplex(16, model=2, seed=3)
     s, _ = _make(2, top, None, torch.float32, hce=True)
     integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=1)
-    integ.set_neighbor_policy(r_cut=3.3, skin=0.002, every=1000)
+    integ.set_neighbor_policy(r_cut=3.3, skin=0.002, every=1000)  # violated by every step
     c, q = _state(c0, q0, torch.float32, s.device)
     p, L = integ.init_momenta()
     with pytest.raises(_lib.MythosHipError, match="skin"):
