@@ -216,6 +216,8 @@ int mythos_martini_langevin_run(mythos_martini_sim_t* sim, void* pos, void* vel,
                                 int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream);
 int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* sim, double* kernel_ms,
                                            double* loop_ms_per_launch, int* launches, int* samples);
+/* out-of-turn rebuilds of the last run (same protocol as mythos_langevin_last_recoveries) */
+int mythos_martini_langevin_last_recoveries(const mythos_martini_sim_t* sim, int* recoveries);
 int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* sim, int* max_row, double* mean_row);
 
 #ifdef __cplusplus

@@ -80,6 +80,7 @@ def load() -> C.CDLL:
         "mythos_martini_langevin_init_velocities": (C.c_int, [V, V, V]),
         "mythos_martini_langevin_run": (C.c_int, [V, V, V, c_double_p, C.c_int, C.c_int, V, V, V]),
         "mythos_martini_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mythos_martini_langevin_last_recoveries": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_martini_langevin_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
     }
     for name, (res, args) in sigs.items():
@@ -125,6 +126,7 @@ DECLARED_SYMBOLS = (
     "mythos_martini_langevin_run",
     "mythos_martini_langevin_last_kernel_ms",
     "mythos_martini_langevin_neighbor_stats",
+    "mythos_martini_langevin_last_recoveries",
 )
 
 

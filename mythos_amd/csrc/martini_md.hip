@@ -62,7 +62,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     const R* __restrict__ bond_r0, const int* __restrict__ angles, const R* __restrict__ angle_k,
     const R* __restrict__ angle_t0, R kick_close, int do_step, uint64_t seed, uint64_t step,
     const typename Real4<R>::type* __restrict__ ref_pos, int* __restrict__ flags, R* __restrict__ traj,
-    double* __restrict__ e_part) {
+    double* __restrict__ e_part, const int* __restrict__ list_overflow, int k_index) {
   using V4 = typename Real4<R>::type;
   constexpr int G = kMmG, PPB = kMmPPB;
   extern __shared__ unsigned char smem_raw[];
@@ -78,6 +78,12 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   const int i = bid * PPB + grp;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
+  // Halt word (see mythos_langevin_run in langevin.hip): set by the step that moved a bead out of its skin, or by a
+  // rebuild that overflowed.  One lane requests it here; everybody looks at it behind the barrier in front of the
+  // integration, before which nothing is written to global memory.
+  __shared__ int s_halt;
+  int halt_word = 0;
+  if (threadIdx.x == 0) halt_word = flags[1] | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
 
   const int tt = K.n_types * K.n_types;
   for (int k = threadIdx.x; k < tt; k += kMmBlock) {
@@ -206,7 +212,10 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       s_e[grp][3] = 0.0;
     }
   }
+  if (threadIdx.x == 0) s_halt = halt_word;
   __syncthreads();
+  if (s_halt != 0) return;  // halted: the state stays at the last valid step
+  if (bid == 0 && threadIdx.x == 0) flags[2] = k_index + 1;
   // ---- one wavefront integrates the 32 beads of the workgroup, one per lane
   const int int_wave = (bid >> 2) & 3;
   const int il = threadIdx.x & 63;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       if (K.skin_half_sq > R(0)) {
         const V4 r0 = ref_pos[ib];
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
-        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags, 1);
+        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags + 1, 1);  // stale for the NEXT forces: halt before them
       }
       if (!(x[0] == x[0]) || !(v[0] == v[0])) atomicOr(flags, 2);
     }
@@ -499,7 +508,7 @@ struct mythos_martini_sim {
   static constexpr int kMaxSamples = 64;
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_kernel_ms = 0, last_avg_ms = 0;
-  int last_launches = 0, last_samples = 0, last_max_row = 0;
+  int last_launches = 0, last_samples = 0, last_max_row = 0, last_recoveries = 0;
 };
 
 namespace mythos {
@@ -578,59 +587,105 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   K.n_types = m->n_types, K.angle_kind = m->angle_kind;
   V4* fr[2] = {(V4*)sim->frame[0], (V4*)sim->frame[1]};
   V4* vel = (V4*)sim->vel;
-  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, sizeof(int), st));
+  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, 4 * sizeof(int), st));
   hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
                      fr[0], vel);
   int cur = 0;
-  // first build of the run: buckets grow until none is more than half full (fuller ones work, through the spill
-  // list, but slowly); overflows inside the run are sticky in d_overflow and end the run with an error
-  for (int attempt = 0;; ++attempt) {
-    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
-    if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
-    int ov0[3] = {0, 0, 0};
-    MYTHOS_HIP_TRY(hipMemcpyAsync(ov0, sim->d_overflow, sizeof(ov0), hipMemcpyDeviceToHost, st));
-    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-    const int demand = cell_cap_override() ? 0 : ov0[2];  // a bucket more than half full: double the places
-    if (demand == 0 || attempt == 4) {
-      if (ov0[2] > 0) MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow + 2, 0, sizeof(int), st));
-      break;
+  // A build that may grow: rows until the longest fits with a quarter of headroom, buckets until none is more than
+  // half full (fuller ones work, through the spill list, but slowly).  Used for the first build of the run and to
+  // recover from a halt (see below); the scheduled builds inside the run cannot stop to grow.
+  auto build_until_fit = [&](int buf) -> int {
+    for (int attempt = 0;; ++attempt) {
+      MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
+      if (int rc = mm_rebuild<R>(sim, fr[buf], K, box, st)) return rc;
+      int ov0[3] = {0, 0, 0};
+      MYTHOS_HIP_TRY(hipMemcpyAsync(ov0, sim->d_overflow, sizeof(ov0), hipMemcpyDeviceToHost, st));
+      MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+      if (ov0[1] > 0) {
+        set_error("mythos_martini_langevin_run: more than " + std::to_string(kCellSpill) +
+                  " beads did not fit the buckets of their cells during a neighbour rebuild");
+        return MYTHOS_ERR_OVERFLOW;
+      }
+      const int demand = cell_cap_override() ? 0 : ov0[2];  // a bucket more than half full: double the places
+      if (ov0[0] == 0 && demand == 0) {
+        if (ov0[2] > 0) MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow + 2, 0, sizeof(int), st));
+        return 0;
+      }
+      if (attempt == 5) {
+        set_error("mythos_martini_langevin_run: neighbour rows or cell buckets keep overflowing");
+        return MYTHOS_ERR_OVERFLOW;
+      }
+      if (ov0[0] > 0) {
+        const int stride = ((ov0[0] + ov0[0] / 4 + 15) / 16) * 16;
+        (void)hipFree(sim->d_rows);
+        sim->d_rows = nullptr;
+        MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_rows, (size_t)n * stride * sizeof(int)));
+        sim->row_stride = stride;
+      }
+      if (demand > 0) sim->cell_bucket_cap = ((2 * demand + 15) / 16) * 16;
     }
-    sim->cell_bucket_cap = ((2 * demand + 15) / 16) * 16;
-  }
+  };
+  if (int rc = build_until_fit(cur)) return rc;
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
-  int launches = 0, samples = 0;
+  int launches = 0, samples = 0, recoveries = 0;
   const int sample_stride = std::max(1, (n_steps + 1) / mythos_martini_sim::kMaxSamples);
-  for (int k = 0; k <= n_steps; ++k) {
-    const bool last = (k == n_steps);
-    const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
-    const int sidx = save ? (k / save_every - 1) : 0;
-    if (k > 0 && !last && (k % sim->rebuild_every == 0))
-      if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
-    const R kick_close = (k == 0) ? R(0) : R(0.5);
-    const int do_step = last ? 0 : 1;
-    R* tp = (save && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
-    const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_martini_sim::kMaxSamples;
+  // Segments of kSegment launches; a halted segment (a bead left its skin before the scheduled rebuild, or a rebuild
+  // overflowed: the launches behind it return at once) is followed by a growing rebuild at the last valid state and
+  // a resume there - the protocol of mythos_langevin_run (langevin.hip).
+  constexpr int kSegment = 8192, kMaxRecoveries = 64;
+  int k = 0;
+  while (k <= n_steps) {
+    const int seg_end = std::min(n_steps, k + kSegment - 1);
+    for (; k <= seg_end; ++k) {
+      const bool last = (k == n_steps);
+      const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
+      const int sidx = save ? (k / save_every - 1) : 0;
+      if (k > 0 && !last && (k % sim->rebuild_every == 0))
+        if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+      const R kick_close = (k == 0) ? R(0) : R(0.5);
+      const int do_step = last ? 0 : 1;
+      R* tp = (save && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
+      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_martini_sim::kMaxSamples;
 #define MM_ARGS                                                                                                    \
   n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, sim->d_rows, sim->d_row_len, sim->row_stride, (const R*)m->d_sigma,    \
       (const R*)m->d_eps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
       (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)m->d_angle_t0, kick_close, do_step,     \
-      sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart
-    if (save) {
-      hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
-      hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
-                         e_trace ? e_trace + (size_t)sidx * kMmTrace : nullptr);
-    } else if (sampled) {
-      hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
-                            sim->sb[samples], 0, MM_ARGS);
-      ++samples;
-    } else {
-      hipLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
-    }
+      sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k
+      if (save) {
+        hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+        hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
+                           e_trace ? e_trace + (size_t)sidx * kMmTrace : nullptr);
+      } else if (sampled) {
+        hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
+                              sim->sb[samples], 0, MM_ARGS);
+        ++samples;
+      } else {
+        hipLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+      }
 #undef MM_ARGS
-    ++launches;
-    cur ^= 1;
+      ++launches;
+      cur ^= 1;
+    }
+    int ctl[4] = {0, 0, 0, 0}, ovs[3] = {0, 0, 0};
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ctl, sim->d_flags, sizeof(ctl), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipMemcpyAsync(ovs, sim->d_overflow, sizeof(ovs), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+    if ((ctl[0] & 2) != 0) break;                               // NaN: reported below
+    if (ctl[1] == 0 && ovs[0] == 0 && ovs[1] == 0) continue;    // nothing halted
+    if (++recoveries > kMaxRecoveries) {
+      sim->step += ctl[2];
+      set_error("mythos_martini_langevin_run: the neighbour list had to be rebuilt out of turn more than " +
+                std::to_string(kMaxRecoveries) + " times in one run: the skin (" + std::to_string(sim->skin) +
+                ") is too small for a rebuild every " + std::to_string(sim->rebuild_every) + " steps");
+      return MYTHOS_ERR_OVERFLOW;
+    }
+    k = ctl[2];  // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
+    cur = k & 1;
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
+    if (int rc = build_until_fit(cur)) return rc;
   }
+  sim->last_recoveries = recoveries;
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
   MYTHOS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(mm_unpack_kernel<R>, dim3(tb), dim3(256), 0, st, n, (const V4*)fr[cur], (const V4*)vel, pos, v);
@@ -664,11 +719,6 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   if (ovw[1] != 0) {
     set_error("mythos_martini_langevin_run: more than " + std::to_string(kCellSpill) +
               " beads did not fit the buckets of their cells during a neighbour rebuild");
-    return MYTHOS_ERR_OVERFLOW;
-  }
-  if (flags & 1) {
-    set_error("mythos_martini_langevin_run: a bead moved more than skin/2 between neighbour-list rebuilds; use a larger "
-              "skin or rebuild more often");
     return MYTHOS_ERR_OVERFLOW;
   }
   return MYTHOS_OK;
@@ -723,7 +773,7 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc(&s->vel, (size_t)n * 4 * w) == hipSuccess && hipMalloc(&s->ref_pos, (size_t)n * 4 * w) == hipSuccess &&
             hipMalloc((void**)&s->d_rows, (size_t)n * s->row_stride * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_row_len, (size_t)n * sizeof(int)) == hipSuccess &&
-            hipMalloc((void**)&s->d_flags, sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&s->d_flags, 4 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_overflow, 3 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
@@ -809,6 +859,15 @@ int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* s, int* m
   for (int v : len) tot += v, mx = std::max(mx, v);
   if (max_row) *max_row = mx;
   if (mean_row) *mean_row = double(tot) / std::max<size_t>(1, len.size());
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_last_recoveries(const mythos_martini_sim_t* s, int* recoveries) {
+  if (!s || !recoveries) {
+    set_error("mythos_martini_langevin_last_recoveries: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  *recoveries = s->last_recoveries;
   return MYTHOS_OK;
 }
 

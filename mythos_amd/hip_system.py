@@ -393,6 +393,12 @@ class MartiniLangevinIntegrator:
         )
         return traj, et
 
+    def last_recoveries(self) -> int:
+        """Out-of-turn list rebuilds of the last run (a bead left its skin early, or rows / buckets had to grow)."""
+        r = C.c_int(0)
+        _lib.check(self._lib.mythos_martini_langevin_last_recoveries(self._h, C.byref(r)), "last_recoveries")
+        return int(r.value)
+
     def last_kernel_ms(self) -> dict:
         k, loop, n, ns = C.c_double(0.0), C.c_double(0.0), C.c_int(0), C.c_int(0)
         _lib.check(self._lib.mythos_martini_langevin_last_kernel_ms(self._h, C.byref(k), C.byref(loop), C.byref(n), C.byref(ns)),

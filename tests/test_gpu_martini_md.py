@@ -146,6 +146,26 @@ def test_determinism_split_runs_and_errors():
         integ.run(pos.double(), vel, b0, 1)
 
 
+def test_a_bead_leaving_its_skin_halts_rebuilds_and_resumes_exactly():
+    """No scheduled rebuilds and a skin of 0.06 nm: the step that moves a bead 0.03 nm from where the list was built
+    halts the launches behind it, the run rebuilds there and carries on.  In fp64 the trajectory equals the one on a
+    comfortable policy (to summation order), saved frames and energies included."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(torch.float64)
+    outs = []
+    for skin, every in ((0.4, 5), (0.06, 1000)):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=21)
+        integ.set_neighbor_policy(skin, every)
+        pos = torch.as_tensor(x0, dtype=torch.float64, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        traj, et = integ.run(pos, vel, b0, 60, save_every=12)
+        outs.append((pos.clone(), vel.clone(), traj.clone(), et.clone()))
+        assert (integ.last_recoveries() >= 3) == (every == 1000), integ.last_recoveries()
+    for x, y in zip(*outs):
+        torch.testing.assert_close(x, y, rtol=1e-9, atol=1e-9)
+
+
 def test_cfg3_bilayer_20480_beads():
     """BASELINE configs[2]: the shipped bilayer tiled 4 x 4; the tiled system must evolve like 16 copies at step 0
     (same energies per tile) and stay at temperature."""
