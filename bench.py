@@ -229,7 +229,8 @@ def martini_main(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"MARTINI-2 DMPC bilayer (reference fixture tiled 4x4, {n} beads), shifted LJ r_c 1.1 nm + bonds + "
                    "G96 angles, Langevin dt 0.02 ps, 273 K, gamma 1/ps", "ns_per_day": args.steps / elapsed * 0.02e-3 * 86400.0,
-                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": nbar, "max_row": mx}},
+                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": nbar, "max_row": mx,
+                                     "out_of_turn_rebuilds": integ.last_recoveries()}},
         "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": (alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "martini_md_step_kernel", "kernel_ms": kms, "loop_ms_per_launch": timing["loop_ms_per_launch"],
@@ -338,7 +339,8 @@ def main():
                 f"Langevin dt {sim['dt']}, kT {kT:.6f}, free space, 1 replica per GPU",
                 "replicas": world,
                 **({"rehearsal": "all ranks on cuda:0 over gloo - not a measurement"} if args.rehearse_on_one_gpu else {}),
-                "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": nbar, "max_row": mx},
+                "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": nbar, "max_row": mx,
+                                  "out_of_turn_rebuilds": integ.last_recoveries()},
                 "ns_per_day": steps_per_s / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
             },
             "roofline": {

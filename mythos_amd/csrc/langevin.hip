@@ -1043,9 +1043,9 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   // there.  A run never integrates on a stale or truncated list, and neither condition is an error any more; what
   // it costs is the empty launches behind the halt (at most a segment) and a synchronisation.
   constexpr int kSegment = 8192, kMaxRecoveries = 64;
-  int k = 0;
+  int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
   while (k <= n_steps) {
-    const int seg_end = std::min(n_steps, k + kSegment - 1);
+    const int seg_end = std::min(n_steps, k + seg_len - 1);
     for (; k <= seg_end; ++k) {
       const bool last = (k == n_steps);
       const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
@@ -1098,6 +1098,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     }
     k = ctl[2];   // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
     cur = k & 1;
+    seg_len = std::max(256, seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
     if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
       return rc;

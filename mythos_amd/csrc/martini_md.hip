@@ -634,9 +634,9 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   // overflowed: the launches behind it return at once) is followed by a growing rebuild at the last valid state and
   // a resume there - the protocol of mythos_langevin_run (langevin.hip).
   constexpr int kSegment = 8192, kMaxRecoveries = 64;
-  int k = 0;
+  int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
   while (k <= n_steps) {
-    const int seg_end = std::min(n_steps, k + kSegment - 1);
+    const int seg_end = std::min(n_steps, k + seg_len - 1);
     for (; k <= seg_end; ++k) {
       const bool last = (k == n_steps);
       const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
@@ -682,6 +682,7 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
     }
     k = ctl[2];  // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
     cur = k & 1;
+    seg_len = std::max(256, seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
     if (int rc = build_until_fit(cur)) return rc;
   }
