@@ -398,44 +398,56 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
   const unsigned int below = (1u << l) - 1u;
   int out = 0;
   int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by G per sweep
-  for (int t0 = 0; t0 < total; t0 += G) {
-    const int t = t0 + l;
-    bool hit = false;
-    int j = -1;
-    if (t < total) {
-      while (s_pre[grp][lo + 1] <= t) ++lo;
-      typename CellPlace<R>::type pj;  // position and index of the candidate arrive together, a contiguous stream per cell
-      if (lo < 27) {
-        pj = place[s_st[grp][lo] + (t - s_pre[grp][lo])];
-        j = cell_index_of(pj.w);
-      } else {
-        j = spill[t - s_pre[grp][27]];
+  // The sweep body is written without nested branches (clamped reads, predicates folded into `hit`): as nested ifs it
+  // compiled to a dozen exec-mask branches per sweep, and the kernel is bound by the instructions of its ~164 k
+  // wave-sweeps (10.5 M candidates / 64), not by their memory traffic.
+  const int n_direct = s_pre[grp][27];  // candidates that come from buckets; the rest is the spill list
+  // kSweeps sweeps per iteration: their (clamped, unconditional) reads are issued together and waited for once.  With
+  // four beads per wavefront a dense cell is ~47 sweeps of 16 for its group, and a group's chain of sweeps - each a
+  // table look-up and a read away from its test - is what the kernel's duration follows.
+#ifndef MYTHOS_MM_SWEEPS
+#define MYTHOS_MM_SWEEPS 4
+#endif
+  constexpr int kSweeps = MYTHOS_MM_SWEEPS;
+  for (int t0 = 0; t0 < total; t0 += kSweeps * G) {
+    typename CellPlace<R>::type pj[kSweeps];
+    int cell[kSweeps], tcs[kSweeps];
+#pragma unroll
+    for (int u = 0; u < kSweeps; ++u) {
+      const int t = t0 + u * G + l;
+      const int tc = t < total ? t : total - 1;
+      while (s_pre[grp][lo + 1] <= tc) ++lo;
+      cell[u] = lo;
+      tcs[u] = tc;
+      // position and index of the candidate arrive together, a contiguous stream per cell
+      pj[u] = place[tc < n_direct ? s_st[grp][lo] + (tc - s_pre[grp][lo]) : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < kSweeps; ++u) {
+      const int t = t0 + u * G + l;
+      const bool live = t < total;
+      const bool from_bucket = tcs[u] < n_direct;
+      int j = cell_index_of(pj[u].w);
+      if (!from_bucket) {  // spill list (rare): index, then a gather
+        j = spill[tcs[u] - n_direct];
         const auto q = pos[j];
-        pj.x = q.x, pj.y = q.y, pj.z = q.z;
+        pj[u].x = q.x, pj[u].y = q.y, pj[u].z = q.z;
       }
-      bool keep = j != i;
-      if (keep && j >= ex_lo && j <= ex_hi) keep = !mm_excluded<R>(ex, j);
-      if (keep) {
-        // hashed table: a bucket may mix cells that collide, so a candidate counts only for the cell it lies in;
-        // direct table: a bucket is one cell
-        bool mine = true;
-        if (!g.direct && lo < 27) {
-          int jx, jy, jz;
-          cell_of(g, pj.x, pj.y, pj.z, jx, jy, jz);
-          mine = (jx == s_c[grp][lo][0] && jy == s_c[grp][lo][1] && jz == s_c[grp][lo][2]);
-        }
-        if (mine) {
-          const R dx = wrap(pj.x - pi.x, K.lx, K.ilx), dy = wrap(pj.y - pi.y, K.ly, K.ily), dz = wrap(pj.z - pi.z, K.lz, K.ilz);
-          hit = dx * dx + dy * dy + dz * dz < rl2;
-        }
+      bool keep = live & (j != i);
+      if (j >= ex_lo && j <= ex_hi) keep = keep & !mm_excluded<R>(ex, j);  // one or two sweeps of a row
+      if (!g.direct) {  // hashed table: a bucket may mix cells that collide, a candidate counts only for the cell it lies in
+        int jx, jy, jz;
+        cell_of(g, pj[u].x, pj[u].y, pj[u].z, jx, jy, jz);
+        const int c = cell[u];
+        keep = keep & (!from_bucket | (jx == s_c[grp][c][0] & jy == s_c[grp][c][1] & jz == s_c[grp][c][2]));
       }
-    }
-    const unsigned int m = (unsigned int)(__ballot(hit) >> gshift) & kGroupMask;
-    if (hit) {
+      const R dx = wrap(pj[u].x - pi.x, K.lx, K.ilx), dy = wrap(pj[u].y - pi.y, K.ly, K.ily), dz = wrap(pj[u].z - pi.z, K.lz, K.ilz);
+      const bool hit = keep & (dx * dx + dy * dy + dz * dz < rl2);
+      const unsigned int m = (unsigned int)(__ballot(hit) >> gshift) & kGroupMask;
       const int slot = out + __popc(m & below);
-      if (slot < row_stride) row[slot] = j;
+      if (hit & (slot < row_stride)) row[slot] = j;
+      out += __popc(m);
     }
-    out += __popc(m);
   }
   if (l == 0) {
     if (out > row_stride) {
