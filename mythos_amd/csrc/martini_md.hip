@@ -53,6 +53,12 @@ struct MmConst {
   int n_types, angle_kind;
 };
 
+// optimisation barrier on a register value: whatever produced it stays before this point, its uses after
+template <typename T>
+__device__ __forceinline__ void mm_pin(T& v) {
+  asm volatile("" : "+v"(v));
+}
+
 template <typename R, bool SAVE>
 __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     int n, const MmConst<R> K, const typename Real4<R>::type* __restrict__ in, typename Real4<R>::type* __restrict__ out,
@@ -212,17 +218,29 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       s_e[grp][3] = 0.0;
     }
   }
+  // ---- integrator prologue, before the barrier: the integrating wavefront draws its thermostat noise and fetches
+  //      position, velocity and list reference here, so the tail of the kernel behind the barrier is arithmetic only
+  //      (the oxDNA step kernel's arrangement, langevin.hip).  mm_pin keeps the values on this side of the barrier.
+  const int int_wave = (bid >> 2) & 3;
+  const int il = threadIdx.x & 63;
+  const int ib = bid * PPB + il;
+  const bool integrates = (int)(threadIdx.x >> 6) == int_wave && il < PPB && ib < n;
+  R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
+  V4 x0{}, vv{}, r0{};
+  if (integrates) {
+    x0 = in[ib];
+    vv = vel[ib];
+    if (do_step && K.skin_half_sq > R(0)) r0 = ref_pos[ib];
+    if (do_step) normals6(seed, (uint32_t)ib, step, 0u, z);
+    mm_pin(z[0]), mm_pin(z[1]), mm_pin(z[2]);
+    mm_pin(x0.x), mm_pin(x0.y), mm_pin(x0.z), mm_pin(vv.x), mm_pin(vv.y), mm_pin(vv.z), mm_pin(vv.w);
+  }
   if (threadIdx.x == 0) s_halt = halt_word;
   __syncthreads();
   if (s_halt != 0) return;  // halted: the state stays at the last valid step
   if (bid == 0 && threadIdx.x == 0) flags[2] = k_index + 1;
   // ---- one wavefront integrates the 32 beads of the workgroup, one per lane
-  const int int_wave = (bid >> 2) & 3;
-  const int il = threadIdx.x & 63;
-  const int ib = bid * PPB + il;
-  if ((int)(threadIdx.x >> 6) == int_wave && il < PPB && ib < n) {
-    const V4 x0 = in[ib];
-    V4 vv = vel[ib];
+  if (integrates) {
     const R im = vv.w;  // inverse mass
     const R F[3] = {-s_f[il][0], -s_f[il][1], -s_f[il][2]};
     R x[3] = {x0.x, x0.y, x0.z}, v[3] = {vv.x, vv.y, vv.z};
@@ -234,8 +252,6 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       if (traj) traj[3 * (size_t)ib] = x[0], traj[3 * (size_t)ib + 1] = x[1], traj[3 * (size_t)ib + 2] = x[2];
     }
     if (do_step) {
-      R z[6];
-      normals6(seed, (uint32_t)ib, step, 0u, z);
       const R hk = K.half_dt * im;
       const R c2 = m_sqrt(K.kT * im * (R(1) - K.c1 * K.c1));
 #pragma unroll
@@ -246,7 +262,6 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
         x[k] += K.half_dt * v[k];
       }
       if (K.skin_half_sq > R(0)) {
-        const V4 r0 = ref_pos[ib];
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags + 1, 1);  // stale for the NEXT forces: halt before them
       }
