@@ -138,7 +138,7 @@ int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
 int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 
 /* timing hook for bench.py, HIP events on the launch stream of the last run:
- *   kernel_ms            mean duration of the step kernel over up to 64 launches spread evenly over the
+ *   kernel_ms            mean duration of the step kernel over up to 16 launches spread evenly over the
  *                        run, each timed by its own event pair attached to the dispatch
  *                        (hipExtLaunchKernelGGL start/stop events = the dispatch's begin/end stamps)
  *   loop_ms_per_launch   (last event - first event) / launches: includes neighbour rebuilds and

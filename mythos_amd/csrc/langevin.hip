@@ -926,7 +926,7 @@ struct mythos_sim {
   int epart_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // sampled per-launch timing: every kSampleStride-th step launch is bracketed by its own event pair
-  static constexpr int kMaxSamples = 64;
+  static constexpr int kMaxSamples = 16;
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_avg_ms = 0;     // (ev1 - ev0) / launches: includes rebuilds and inter-kernel gaps
   double last_kernel_ms = 0;  // mean over the sampled single-launch intervals

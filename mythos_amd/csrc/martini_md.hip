@@ -532,7 +532,7 @@ struct mythos_martini_sim {
   int row_stride = 256;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  static constexpr int kMaxSamples = 64;
+  static constexpr int kMaxSamples = 16;
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_kernel_ms = 0, last_avg_ms = 0;
   int last_launches = 0, last_samples = 0, last_max_row = 0, last_recoveries = 0;
