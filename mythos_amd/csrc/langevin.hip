@@ -920,6 +920,7 @@ struct mythos_sim {
   static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN, 4 angular items), [1] halt, [2] progress
   int* d_flags = nullptr;
   int last_recoveries = 0;       // halts of the last run that were rebuilt and resumed
+  bool list_fitted = false;      // a synchronising, growing build has sized rows and buckets for this integrator
   int* d_chunk_order = nullptr;  // [blocks] spatial order of the 32-nucleotide chunks (null: index order)
   int chunk_order_age = 0;       // runs since it was computed
   double* d_epart = nullptr;
@@ -1027,11 +1028,18 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     return rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, fr[buf].p1, true, st);
   };
   if (dynamic_list) {
-    // first build of the run: grow the rows until they hold the longest one with a quarter of headroom for the
-    // builds that follow inside the run (those cannot stop to grow: a row overflow there is sticky in d_overflow and
-    // ends the run with an error), and the cell buckets until none is more than half full
-    if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
-      return rc;
+    // first build of the run.  The first run of this integrator sizes rows (a quarter of headroom) and cell buckets
+    // (none more than half full) with a synchronising build; later runs just rebuild - should that overflow, the
+    // first step kernel halts and the recovery below grows what is needed (a synchronisation saved per run: ~70 us,
+    // which is 4 % of a 100-step run of the 12 kbp duplex)
+    if (!sim->list_fitted) {
+      if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
+        return rc;
+      sim->list_fitted = true;
+    } else {
+      MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, kOverflowWords * sizeof(int), st));
+      if (int rc = rebuild(cur)) return rc;
+    }
   }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0;
@@ -1234,6 +1242,7 @@ int mythos_langevin_set_neighbor_policy(mythos_sim_t* s, double r_cut, double sk
   s->r_cut = r_cut;
   s->skin = skin;
   s->rebuild_every = every;
+  s->list_fitted = false;  // another list range: size rows and buckets again at the next run
   return MYTHOS_OK;
 }
 

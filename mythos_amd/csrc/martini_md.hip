@@ -536,6 +536,7 @@ struct mythos_martini_sim {
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_kernel_ms = 0, last_avg_ms = 0;
   int last_launches = 0, last_samples = 0, last_max_row = 0, last_recoveries = 0;
+  bool list_fitted = false;  // a synchronising, growing build has sized rows and buckets for this integrator
 };
 
 namespace mythos {
@@ -652,7 +653,15 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       if (demand > 0) sim->cell_bucket_cap = ((2 * demand + 15) / 16) * 16;
     }
   };
-  if (int rc = build_until_fit(cur)) return rc;
+  // the first run of this integrator sizes rows and buckets with the synchronising build; later runs just rebuild
+  // (an overflow there halts the first step kernel and is recovered below)
+  if (!sim->list_fitted) {
+    if (int rc = build_until_fit(cur)) return rc;
+    sim->list_fitted = true;
+  } else {
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
+    if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+  }
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0;
@@ -823,6 +832,7 @@ int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* s, double 
   }
   s->skin = skin;
   s->rebuild_every = rebuild_every;
+  s->list_fitted = false;  // another list range: size rows and buckets again at the next run
   return MYTHOS_OK;
 }
 
