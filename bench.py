@@ -209,6 +209,7 @@ def martini_main(args):
     integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
     skin, every = (0.4 if args.skin is None else args.skin), (8 if args.rebuild_every is None else args.rebuild_every)
     integ.set_neighbor_policy(skin, every)
+    integ.set_timing(16)  # HIP event pairs on 16 dispatches of the timed run (roofline.kernel_ms)
     pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
     vel = integ.init_velocities()
     integ.run(pos, vel, bt, args.warmup)
@@ -279,6 +280,7 @@ def main():
         mass=sim["nucleotide_mass"], inertia=sim["moment_of_inertia"], seed=rank,
     )
     integ.set_neighbor_policy(R_CUT, args.skin, args.rebuild_every)
+    integ.set_timing(16)  # HIP event pairs on 16 dispatches of the timed run (roofline.kernel_ms)
     c = torch.as_tensor(c0, dtype=dtype, device=dev).contiguous()
     q = torch.as_tensor(q0, dtype=dtype, device=dev).contiguous()
     p, L = integ.init_momenta()

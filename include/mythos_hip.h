@@ -143,6 +143,9 @@ int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
  *                        (hipExtLaunchKernelGGL start/stop events = the dispatch's begin/end stamps)
  *   loop_ms_per_launch   (last event - first event) / launches: includes neighbour rebuilds and
  *                        inter-kernel gaps */
+/* samples: how many dispatches of a run get their own event pair (0 = none, the default; at most 16).  A bracketed
+ * dispatch costs ~8 us of queue time, so timing is something the caller switches on (bench.py does). */
+int mythos_langevin_set_timing(mythos_sim_t* sim, int samples);
 int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, double* loop_ms_per_launch,
                                    int* launches, int* samples);
 
@@ -216,6 +219,7 @@ int mythos_martini_langevin_run(mythos_martini_sim_t* sim, void* pos, void* vel,
                                 int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream);
 int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* sim, double* kernel_ms,
                                            double* loop_ms_per_launch, int* launches, int* samples);
+int mythos_martini_langevin_set_timing(mythos_martini_sim_t* sim, int samples); /* as mythos_langevin_set_timing */
 /* out-of-turn rebuilds of the last run (same protocol as mythos_langevin_last_recoveries) */
 int mythos_martini_langevin_last_recoveries(const mythos_martini_sim_t* sim, int* recoveries);
 int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* sim, int* max_row, double* mean_row);

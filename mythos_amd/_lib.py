@@ -63,6 +63,8 @@ def load() -> C.CDLL:
         "mythos_langevin_get_step": (C.c_int64, [V]),
         "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
         "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mythos_langevin_set_timing": (C.c_int, [V, C.c_int]),
+        "mythos_martini_langevin_set_timing": (C.c_int, [V, C.c_int]),
         "mythos_langevin_last_recoveries": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_oxdna_read_trajectory": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
         "mythos_oxdna_write_trajectory": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
@@ -113,6 +115,8 @@ DECLARED_SYMBOLS = (
     "mythos_langevin_set_step",
     "mythos_langevin_last_kernel_ms",
     "mythos_langevin_last_recoveries",
+    "mythos_langevin_set_timing",
+    "mythos_martini_langevin_set_timing",
     "mythos_oxdna_read_trajectory",
     "mythos_oxdna_write_trajectory",
     "mythos_martini_create",

@@ -928,6 +928,7 @@ struct mythos_sim {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // sampled per-launch timing: every kSampleStride-th step launch is bracketed by its own event pair
   static constexpr int kMaxSamples = 16;
+  int timing_samples = 0;  // dispatches per run timed with their own event pair (set_timing; ~8 us each)
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_avg_ms = 0;     // (ev1 - ev0) / launches: includes rebuilds and inter-kernel gaps
   double last_kernel_ms = 0;  // mean over the sampled single-launch intervals
@@ -1043,7 +1044,8 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   }
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0;
-  const int sample_stride = std::max(1, (n_steps + 1) / mythos_sim::kMaxSamples);
+  const int max_samples = std::min(sim->timing_samples, (int)mythos_sim::kMaxSamples);  // 0: no dispatch is bracketed
+  const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
   const int* halt_words = dynamic_list ? sys->d_overflow : nullptr;
   // The kernels of a run are queued in segments of kSegment; after each the host looks at the halt word.  A step that
   // moves a site out of its skin, or a rebuild that overflows its rows or spill list, halts the launches behind it
@@ -1067,7 +1069,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       const V4* ref = (const V4*)sys->d_ref_pos;
       const V4* ref_off = (const V4*)sys->d_ref_off;
       const V4* ref_a1 = (const V4*)sys->d_ref_a1;
-      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_sim::kMaxSamples;
+      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
       if (save) {
         hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
                            fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
@@ -1325,6 +1327,15 @@ int mythos_langevin_last_recoveries(const mythos_sim_t* s, int* recoveries) {
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   *recoveries = s->last_recoveries;
+  return MYTHOS_OK;
+}
+
+int mythos_langevin_set_timing(mythos_sim_t* s, int samples) {
+  if (!s || samples < 0) {
+    set_error("mythos_langevin_set_timing: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->timing_samples = std::min(samples, (int)mythos_sim::kMaxSamples);
   return MYTHOS_OK;
 }
 

@@ -533,6 +533,7 @@ struct mythos_martini_sim {
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   static constexpr int kMaxSamples = 16;
+  int timing_samples = 0;  // dispatches per run timed with their own event pair (set_timing; ~8 us each)
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
   double last_kernel_ms = 0, last_avg_ms = 0;
   int last_launches = 0, last_samples = 0, last_max_row = 0, last_recoveries = 0;
@@ -665,7 +666,8 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
   MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0;
-  const int sample_stride = std::max(1, (n_steps + 1) / mythos_martini_sim::kMaxSamples);
+  const int max_samples = std::min(sim->timing_samples, (int)mythos_martini_sim::kMaxSamples);  // 0: no dispatch is bracketed
+  const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
   // Segments of kSegment launches; a halted segment (a bead left its skin before the scheduled rebuild, or a rebuild
   // overflowed: the launches behind it return at once) is followed by a growing rebuild at the last valid state and
   // a resume there - the protocol of mythos_langevin_run (langevin.hip).
@@ -682,7 +684,7 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       const R kick_close = (k == 0) ? R(0) : R(0.5);
       const int do_step = last ? 0 : 1;
       R* tp = (save && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
-      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < mythos_martini_sim::kMaxSamples;
+      const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
 #define MM_ARGS                                                                                                    \
   n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, sim->d_rows, sim->d_row_len, sim->row_stride, (const R*)m->d_sigma,    \
       (const R*)m->d_eps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
@@ -906,6 +908,15 @@ int mythos_martini_langevin_last_recoveries(const mythos_martini_sim_t* s, int* 
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   *recoveries = s->last_recoveries;
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_set_timing(mythos_martini_sim_t* s, int samples) {
+  if (!s || samples < 0) {
+    set_error("mythos_martini_langevin_set_timing: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->timing_samples = std::min(samples, (int)mythos_martini_sim::kMaxSamples);
   return MYTHOS_OK;
 }
 

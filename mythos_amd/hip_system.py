@@ -225,6 +225,10 @@ class LangevinIntegrator:
     def step(self, value: int) -> None:
         _lib.check(self._lib.mythos_langevin_set_step(self._h, int(value)), "set_step")
 
+    def set_timing(self, samples: int) -> None:
+        """Bracket ``samples`` dispatches per run with HIP event pairs (0 = off, the default; see last_kernel_ms)."""
+        _lib.check(self._lib.mythos_langevin_set_timing(self._h, int(samples)), "set_timing")
+
     def last_recoveries(self) -> int:
         """Out-of-turn list rebuilds of the last run (a site left its skin early, or rows / buckets had to grow)."""
         r = C.c_int(0)
@@ -392,6 +396,10 @@ class MartiniLangevinIntegrator:
             "martini_langevin_run",
         )
         return traj, et
+
+    def set_timing(self, samples: int) -> None:
+        """Bracket ``samples`` dispatches per run with HIP event pairs (0 = off, the default; see last_kernel_ms)."""
+        _lib.check(self._lib.mythos_martini_langevin_set_timing(self._h, int(samples)), "set_timing")
 
     def last_recoveries(self) -> int:
         """Out-of-turn list rebuilds of the last run (a bead left its skin early, or rows / buckets had to grow)."""
