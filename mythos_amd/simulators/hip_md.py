@@ -80,6 +80,11 @@ class HipMDSimulator(Simulator):
     init_state: Any = None
     n_steps: int | None = None
     key: int = 0
+    # Independent replicas of the system advanced by ONE launch per step (free space only): the copies are laid out
+    # on a grid far apart and integrated as one system, so 64 replicas of a 64-nt duplex cost a step of a 4 096-nt
+    # system, not 64 steps.  Every nucleotide has its own Philox stream, so replicas are statistically independent.
+    # The reference runs replicas as separate simulator instances (mythos/simulators/base.py MultiSimulator, Ray).
+    n_replicas: int = 1
 
     def run(self, opt_params: dict, init_state: RigidBody | None = None, n_steps: int | None = None, key: int | None = None,
             **_) -> SimulatorOutput:
@@ -120,8 +125,17 @@ class HipMDSimulator(Simulator):
         if dev.type != "cuda":
             dev = torch.device("cuda", torch.cuda.current_device())
         box = getattr(first.displacement_fn, "box", None)
-        system = OxdnaSystem(model, _np(first.seq), None if first.is_end is None else _np(first.is_end),
-                             _np(first.bonded_neighbors), box=box, dtype=self.dtype, device=dev)
+        n_rep = int(self.n_replicas)
+        n_one = int(_np(first.seq).shape[0])
+        seq_a, end_a, bonded_a = _np(first.seq), None if first.is_end is None else _np(first.is_end), _np(first.bonded_neighbors)
+        if n_rep > 1:
+            if box is not None:
+                raise ValueError("HipMDSimulator: replicas are batched in free space; the energy function has a periodic box")
+            bonded_2 = np.asarray(bonded_a).reshape(-1, 2)
+            seq_a = np.tile(np.asarray(seq_a), n_rep)
+            end_a = None if end_a is None else np.tile(np.asarray(end_a), n_rep)
+            bonded_a = np.concatenate([bonded_2 + r * n_one for r in range(n_rep)], axis=0)
+        system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev)
         system.set_params(flat.detach())
         mass, inertia = _pair(sp.mass)
         gamma_t, gamma_r = _pair(sp.gamma)
@@ -135,11 +149,40 @@ class HipMDSimulator(Simulator):
             pairs = nb.idx if nb is not None else first.unbonded_neighbors
             from mythos_amd.energy.base import _pairs_2xP
 
-            system.set_neighbors(_pairs_2xP(pairs, system.n))
+            p2 = _pairs_2xP(pairs, n_one)
+            if n_rep > 1:
+                p2 = np.concatenate([np.asarray(p2).reshape(-1, 2) + r * n_one for r in range(n_rep)], axis=0)
+            system.set_neighbors(p2)
         c = init_state.center.to(device=dev, dtype=self.dtype).contiguous().clone()
         q = init_state.orientation.vec.to(device=dev, dtype=self.dtype).contiguous().clone()
+        offsets = None
+        if n_rep > 1:
+            # (n, 3) initial state: every replica starts from it; (R, n, 3): one start per replica
+            c = (c if c.dim() == 3 else c[None].expand(n_rep, -1, -1)).reshape(n_rep, n_one, 3).clone()
+            q = (q if q.dim() == 3 else q[None].expand(n_rep, -1, -1)).reshape(n_rep, n_one, 4).clone()
+            extent = float((c - c.mean(dim=1, keepdim=True)).norm(dim=-1).max())
+            r_list = (nb.r_cutoff + nb.dr_threshold) if isinstance(nb, VerletNeighborList) else 4.0
+            spacing = 2.0 * extent + 8.0 * r_list + 16.0  # replicas stay out of each other's list range while they diffuse
+            side = int(np.ceil(n_rep ** (1.0 / 3.0)))
+            grid = torch.as_tensor([[r % side, (r // side) % side, r // (side * side)] for r in range(n_rep)], dtype=self.dtype, device=dev)
+            offsets = (grid * spacing)[:, None, :]
+            c = (c + offsets).reshape(n_rep * n_one, 3).contiguous()
+            q = q.reshape(n_rep * n_one, 4).contiguous()
         p, ang = integ.init_momenta()
         tc, tq, et = integ.run(c, q, p, ang, int(n_steps), save_every=self.save_every)
+        if n_rep > 1:
+            # states of all replicas, replica-major: (R * S, n, .); the offsets of the grid come off again
+            def unbatch(t, width, off):
+                t = t.reshape(t.shape[0], n_rep, n_one, width)
+                if off is not None:
+                    t = t - off[None]
+                return t.transpose(0, 1).reshape(-1, n_one, width)
+
+            tc = None if tc is None else unbatch(tc, 3, offsets)
+            tq = None if tq is None else unbatch(tq, 4, None)
+            et = None  # the fused trace sums over the whole launch; per-replica energies come from energy_fn
+            c = c.reshape(n_rep, n_one, 3) - offsets
+            q = q.reshape(n_rep, n_one, 4)
         n_saved = 0 if tc is None else tc.shape[0]
         traj = SimulatorTrajectory(
             center=tc if tc is not None else c[None][:0],

@@ -191,3 +191,50 @@ def test_simulator_run_surface():
         # the stored frames are consistent with the energy function (same parameters)
         e_traj = ef.with_params(eps_hb=1.05).map(RigidBody(tr.center, tr.orientation))
         torch.testing.assert_close(e_traj.cpu(), tr.metadata["energy_terms"].sum(1).cpu(), rtol=2e-4, atol=1e-3)
+
+
+def test_simulator_batches_independent_replicas_in_one_launch():
+    """n_replicas copies of the system advance as one launch per step, far apart in free space.  Cold and frictionless
+    (kT -> 0, gamma = 0) the copies follow the same deterministic trajectory as a single run; thermal, they stay where
+    they were put relative to their own origin, decorrelate from each other, and hand back (R, n, .) states."""
+    import dataclasses as dc
+
+    from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList, VerletNeighborList
+
+    top, traj, _, _, mod, _, _, _ = _setup(2, "simple-helix")
+    disp, shift = space.free()
+    ef = mod.create_default_energy_fn(top, disp)
+    init = _states(traj, torch.float32)[0]
+    cold = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(0.0, 0.0),
+                                 bonded_neighbors=top.bonded_neighbors, checkpoint_every=0, dt=5e-3, kT=1e-14)
+    for nb in (NoNeighborList(unbonded_nbrs=top.unbonded_neighbors), VerletNeighborList(3.25, 0.6, 20)):
+        one = HipMDSimulator(energy_fn=ef, simulator_params=cold, space=(disp, shift), simulator_init=nvt_langevin, neighbors=nb,
+                             save_every=10)
+        ref = one.run({}, init, 60, key=5).observables[0].center  # (6, 16, 3)
+        many = dc.replace(one, n_replicas=5)
+        out = many.run({}, init, 60, key=5)
+        got = out.observables[0].center
+        assert got.shape == (5 * 6, 16, 3) and out.observables[0].orientation.vec.shape == (5 * 6, 16, 4)
+        for r in range(5):
+            torch.testing.assert_close(got[6 * r:6 * (r + 1)], ref, rtol=0, atol=2e-4)
+        assert out.state["final_state"].center.shape == (5, 16, 3)
+    warm = dc.replace(cold, kT=KT, gamma=(KT / 2.5, KT / 7.5))
+    sim = HipMDSimulator(energy_fn=ef, simulator_params=warm, space=(disp, shift), simulator_init=nvt_langevin,
+                         neighbors=VerletNeighborList(3.25, 0.6, 20), save_every=50, n_replicas=8)
+    out = sim.run({}, init, 400, key=9)
+    c = out.observables[0].center.reshape(8, 8, 16, 3)
+    assert torch.isfinite(c).all()
+    com = c.mean(dim=2)                                      # replicas sit at their own origin again
+    assert (com - init.center.mean(0).to(com)).norm(dim=-1).max() < 3.0
+    last = c[:, -1]
+    assert (last[0] - last[1]).abs().max() > 1e-3            # different noise per replica
+    e = ef.map(RigidBody(out.observables[0].center, out.observables[0].orientation))
+    assert torch.isfinite(e).all() and e.shape == (64,)
+    # the next run continues all replicas from where they are
+    again = sim.run({}, **{k: out.state[k] for k in ("init_state", "key")}, n_steps=50)
+    assert again.observables[0].center.shape == (8, 16, 3)
+    # replicas need free space
+    box_disp, box_shift = space.periodic(traj.box_size)
+    with pytest.raises(ValueError, match="free space"):
+        dc.replace(sim, energy_fn=mod.create_default_energy_fn(top, box_disp), space=(box_disp, box_shift)).run({}, init, 5, key=1)
