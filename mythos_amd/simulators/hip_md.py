@@ -160,12 +160,15 @@ class HipMDSimulator(Simulator):
             # (n, 3) initial state: every replica starts from it; (R, n, 3): one start per replica
             c = (c if c.dim() == 3 else c[None].expand(n_rep, -1, -1)).reshape(n_rep, n_one, 3).clone()
             q = (q if q.dim() == 3 else q[None].expand(n_rep, -1, -1)).reshape(n_rep, n_one, 4).clone()
-            extent = float((c - c.mean(dim=1, keepdim=True)).norm(dim=-1).max())
+            # every replica is centred on its grid node for the run (free space: a translation changes nothing) and gets
+            # its own centre of mass back afterwards, so drift accumulated over earlier runs never eats into the spacing
+            com = c.mean(dim=1, keepdim=True)
+            extent = float((c - com).norm(dim=-1).max())
             r_list = (nb.r_cutoff + nb.dr_threshold) if isinstance(nb, VerletNeighborList) else 4.0
-            spacing = 2.0 * extent + 8.0 * r_list + 16.0  # replicas stay out of each other's list range while they diffuse
+            spacing = 2.0 * extent + 8.0 * r_list + 64.0  # out of each other's list range for as long as a run diffuses
             side = int(np.ceil(n_rep ** (1.0 / 3.0)))
             grid = torch.as_tensor([[r % side, (r // side) % side, r // (side * side)] for r in range(n_rep)], dtype=self.dtype, device=dev)
-            offsets = (grid * spacing)[:, None, :]
+            offsets = (grid * spacing)[:, None, :] - com
             c = (c + offsets).reshape(n_rep * n_one, 3).contiguous()
             q = q.reshape(n_rep * n_one, 4).contiguous()
         p, ang = integ.init_momenta()
