@@ -220,3 +220,19 @@ def test_full_cell_buckets_spill_without_losing_neighbours():
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout
+
+
+def test_row_builder_equals_a_kd_tree_on_random_clouds():
+    """scripts/stress_rows.py: 24 random systems (600-6 000 particles, blobs in free space and periodic boxes with
+    wrapped and unwrapped coordinates, fp32 and fp64, 8-45 neighbours per particle): the device-built rows hold exactly
+    the pairs of scipy's k-d tree and the same longest row - with managed buckets and with buckets of five places."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for seed, extra in ((11, {}), (12, {"MYTHOS_CELL_BUCKET_CAP": "5"})):
+        r = subprocess.run([sys.executable, str(root / "scripts" / "stress_rows.py"), str(seed)], cwd=root,
+                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
