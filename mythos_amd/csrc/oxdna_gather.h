@@ -79,26 +79,60 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // Walk row i with the G lanes of a group.  On return every lane holds its PARTIAL sums;
 // call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
 // parameter partials, inside the sink) carry weight 1/2.
+// Two passes over the row.  The first evaluates the bonded slots and the radial part of every unbonded entry and
+// collects the entries whose angular terms can act (ballot compaction into the group's LDS list, in row order); the
+// second evaluates the angular terms of that list, dense over the G lanes.  With the reference's all-pairs list
+// (63 entries per nucleotide in a 32-bp duplex, ~5 of them in range) one fused loop ran the ~1 000-instruction angular
+// code in every iteration for a lane or two; compacted, it runs once per ~16 in-range entries.
+// items: this group's LDS list, one int per row slot (row_stride of them), so every flagged entry fits.
+
 template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
-                                           PG& pg) {
+                                           PG& pg, int* __restrict__ items) {
+  static_assert(G <= 32, "group masks below are 32-bit");
   const int* __restrict__ row = rows + (size_t)i * row_stride;
-  for (int s = lane; s < len; s += G) {
-    const int entry = row[s];
-    if (entry < 0) continue;
+  const int gshift = (threadIdx.x & 63) & ~(G - 1);
+  constexpr unsigned int kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
+  const unsigned int below = (1u << lane) - 1u;
+  int n_items = 0;
+  for (int s0 = 0; s0 < len; s0 += G) {
+    const int s = s0 + lane;
+    const int entry = (s < len) ? row[s] : -1;
+    bool flag = false;
+    Nuc<R> other;
+    V3<R> dco{R(0), R(0), R(0)};
+    bool role_p = false;
+    if (entry >= 0) {
+      const int j = entry & ROW_INDEX_MASK;
+      const bool bonded = s < ROW_BONDED_SLOTS;
+      role_p = bonded ? ((s & 1) == 1) : ((entry & ROW_ROLE_Q) == 0);
+      R q4[4];
+      ld.load(j, other, q4);
+      dco = min_image(other.c - self.c, box);
+      if (bonded)
+        bonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+      else
+        flag = unbonded_radial<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+    }
+    const unsigned int m = (unsigned int)(__ballot(flag) >> gshift) & kGroupMask;
+    if (flag) {
+      items[n_items + __popc(m & below)] = entry;
+    }
+    n_items += __popc(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int k = lane; k < n_items; k += G) {
+    const int entry = items[k];
     const int j = entry & ROW_INDEX_MASK;
-    const bool bonded = s < ROW_BONDED_SLOTS;
-    const bool role_p = bonded ? ((s & 1) == 1) : ((entry & ROW_ROLE_Q) == 0);
+    const bool role_p = (entry & ROW_ROLE_Q) == 0;
     Nuc<R> other;
     R q4[4];
     ld.load(j, other, q4);
     const V3<R> dco = min_image(other.c - self.c, box);
-    if (bonded)
-      bonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
-    else
-      unbonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+    unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
   }
 }
 

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
+  extern __shared__ int item_lds[];  // [PPB][row_stride]: per group, the row entries whose angular terms can act (gather_row)
   __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
@@ -78,10 +79,10 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
       LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
-      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
+      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * row_stride);
     } else {
       NoPG pg;
-      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg);
+      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * row_stride);
     }
   }
   group_reduce<G, R, GRAD>(e, sg);
@@ -173,15 +174,15 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
     R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
     if (mode == 0)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
                          sys->d_pgpart);
     else if (mode == 1)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
                          sys->d_pgpart);
     else
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), 0, stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
                          sys->d_pgpart);
     MYTHOS_HIP_TRY(hipGetLastError());
