@@ -196,3 +196,22 @@ def _whole(x, b):
         d = x[j] - x[i]
         x[j] = x[i] + d - b * np.round(d / b)
     return x
+
+
+def test_rows_longer_than_the_default_stride_grow_at_the_first_build():
+    """A list range of 1.1 + 1.0 nm holds ~300 beads, more than the 256 slots rows start with: the first build of the
+    run must enlarge them (and the trajectory still equals the one on a comfortable list, fp64)."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(torch.float64)
+    outs = []
+    for skin, every in ((0.3, 5), (1.0, 5)):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=8)
+        integ.set_neighbor_policy(skin, every)
+        pos = torch.as_tensor(x0, dtype=torch.float64, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        integ.run(pos, vel, b0, 20)
+        outs.append(pos.clone())
+        mx, _ = integ.neighbor_stats()
+        assert (mx > 256) == (skin == 1.0), mx
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-9, atol=1e-9)
