@@ -31,6 +31,7 @@ struct PackedLoader {
   const R* __restrict__ center;
   const R* __restrict__ quat;
   const int* __restrict__ meta;
+  __device__ __forceinline__ V3<R> centre(int j) const { return V3<R>{center[3 * j + 0], center[3 * j + 1], center[3 * j + 2]}; }
   __device__ __forceinline__ void load(int j, Nuc<R>& o, R* q4) const {
     o.c = {center[3 * j + 0], center[3 * j + 1], center[3 * j + 2]};
     q4[0] = quat[4 * j + 0];
@@ -51,6 +52,10 @@ struct Vec4Loader {
   const V4* __restrict__ pos;
   const V4* __restrict__ quat;
   const int* __restrict__ meta;
+  __device__ __forceinline__ V3<R> centre(int j) const {
+    const V4 c = pos[j];
+    return V3<R>{c.x, c.y, c.z};
+  }
   __device__ __forceinline__ void load(int j, Nuc<R>& o, R* q4) const {
     const V4 c = pos[j];
     const V4 q = quat[j];
@@ -79,60 +84,83 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // Walk row i with the G lanes of a group.  On return every lane holds its PARTIAL sums;
 // call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
 // parameter partials, inside the sink) carry weight 1/2.
-// Two passes over the row.  The first evaluates the bonded slots and the radial part of every unbonded entry and
-// collects the entries whose angular terms can act (ballot compaction into the group's LDS list, in row order); the
-// second evaluates the angular terms of that list, dense over the G lanes.  With the reference's all-pairs list
-// (63 entries per nucleotide in a 32-bp duplex, ~5 of them in range) one fused loop ran the ~1 000-instruction angular
-// code in every iteration for a lane or two; compacted, it runs once per ~16 in-range entries.
-// items: this group's LDS list, one int per row slot (row_stride of them), so every flagged entry fits.
-
+// A row is walked in stages, each dense over the G lanes of the group:
+//   1. bonded slots (one lane each);
+//   2. every unbonded entry: centre distance only (12 bytes, no quaternion algebra) against rnear2, beyond which no
+//      site pair of the two nucleotides can be inside any cut-off; the near entries are compacted into an LDS list;
+//   3. the near list: full neighbour state, the radial terms, and a second compaction of the entries whose angular
+//      terms can act;
+//   4. that list: the angular terms.
+// With the reference's all-pairs list (63 entries per nucleotide in a 32-bp duplex, ~8 near, ~5 with angular
+// support) a single fused loop ran ~200 instructions of radial terms for every entry and the ~1 000-instruction
+// angular code in every iteration for a lane or two; the kernel is VALU-bound, so instructions are its time.
+// items: this group's LDS, two lists of row_stride ints (near entries, angular entries).
 template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
-                                           PG& pg, int* __restrict__ items) {
+                                           PG& pg, int* __restrict__ items, R rnear2) {
   static_assert(G <= 32, "group masks below are 32-bit");
   const int* __restrict__ row = rows + (size_t)i * row_stride;
   const int gshift = (threadIdx.x & 63) & ~(G - 1);
   constexpr unsigned int kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
   const unsigned int below = (1u << lane) - 1u;
-  int n_items = 0;
-  for (int s0 = 0; s0 < len; s0 += G) {
+  int* __restrict__ near_list = items;
+  int* __restrict__ ang_list = items + row_stride;
+  // 1. bonded slots
+  if (lane < ROW_BONDED_SLOTS && lane < len) {
+    const int entry = row[lane];
+    if (entry >= 0) {
+      Nuc<R> other;
+      R q4[4];
+      ld.load(entry & ROW_INDEX_MASK, other, q4);
+      bonded_pair<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (lane & 1) == 1, R(0.5), e, sg, pg);
+    }
+  }
+  // 2. centre-distance filter
+  int n_near = 0;
+  for (int s0 = ROW_BONDED_SLOTS; s0 < len; s0 += G) {
     const int s = s0 + lane;
     const int entry = (s < len) ? row[s] : -1;
-    bool flag = false;
-    Nuc<R> other;
-    V3<R> dco{R(0), R(0), R(0)};
-    bool role_p = false;
+    bool near = false;
     if (entry >= 0) {
-      const int j = entry & ROW_INDEX_MASK;
-      const bool bonded = s < ROW_BONDED_SLOTS;
-      role_p = bonded ? ((s & 1) == 1) : ((entry & ROW_ROLE_Q) == 0);
-      R q4[4];
-      ld.load(j, other, q4);
-      dco = min_image(other.c - self.c, box);
-      if (bonded)
-        bonded_pair<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
-      else
-        flag = unbonded_radial<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+      const V3<R> d = min_image(ld.centre(entry & ROW_INDEX_MASK) - self.c, box);
+      near = dot(d, d) < rnear2;
     }
-    const unsigned int m = (unsigned int)(__ballot(flag) >> gshift) & kGroupMask;
-    if (flag) {
-      items[n_items + __popc(m & below)] = entry;
-    }
-    n_items += __popc(m);
+    const unsigned int m = (unsigned int)(__ballot(near) >> gshift) & kGroupMask;
+    if (near) near_list[n_near + __popc(m & below)] = entry;
+    n_near += __popc(m);
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  for (int k = lane; k < n_items; k += G) {
-    const int entry = items[k];
-    const int j = entry & ROW_INDEX_MASK;
-    const bool role_p = (entry & ROW_ROLE_Q) == 0;
+  // 3. radial terms of the near entries
+  int n_ang = 0;
+  for (int k0 = 0; k0 < n_near; k0 += G) {
+    const int k = k0 + lane;
+    bool flag = false;
+    int entry = -1;
+    if (k < n_near) {
+      entry = near_list[k];
+      Nuc<R> other;
+      R q4[4];
+      ld.load(entry & ROW_INDEX_MASK, other, q4);
+      flag = unbonded_radial<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5),
+                                                 e, sg, pg);
+    }
+    const unsigned int m = (unsigned int)(__ballot(flag) >> gshift) & kGroupMask;
+    if (flag) ang_list[n_ang + __popc(m & below)] = entry;
+    n_ang += __popc(m);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // 4. angular terms
+  for (int k = lane; k < n_ang; k += G) {
+    const int entry = ang_list[k];
     Nuc<R> other;
     R q4[4];
-    ld.load(j, other, q4);
-    const V3<R> dco = min_image(other.c - self.c, box);
-    unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, dco, role_p, R(0.5), e, sg, pg);
+    ld.load(entry & ROW_INDEX_MASK, other, q4);
+    unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5), e, sg,
+                                         pg);
   }
 }
 

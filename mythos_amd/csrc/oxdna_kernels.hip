@@ -45,11 +45,11 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
-    double* __restrict__ pg_part) {
+    double* __restrict__ pg_part, R rnear2) {
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
-  extern __shared__ int item_lds[];  // [PPB][row_stride]: per group, the row entries whose angular terms can act (gather_row)
+  extern __shared__ int item_lds[];  // [PPB][2][row_stride]: per group, the near and the angular entries of its row (gather_row)
   __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
       LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
-      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * row_stride);
+      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
     } else {
       NoPG pg;
-      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * row_stride);
+      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
     }
   }
   group_reduce<G, R, GRAD>(e, sg);
@@ -166,6 +166,16 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * OXP_COUNT)) return rc;
   const R* P = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
+  // centre distance beyond which no site pair of two nucleotides is inside any cut-off: the longest range of a term
+  // plus twice the farthest site from the centre (with a margin for the rounding of the comparison)
+  const OxParams<double>& Pd = sys->pd;
+  double range = std::max({(double)Pd[NEXC_BACKBONE_RC], (double)Pd[NEXC_BASE_RC], (double)Pd[NEXC_BACK_BASE_RC],
+                           (double)Pd[NEXC_BASE_BACK_RC], (double)Pd[HYDR_RCHIGH], (double)Pd[CRST_RCHIGH], (double)Pd[CXST_RCHIGH]});
+  if (MODEL == 2) range = std::max(range, (double)Pd[DH_RCUT]);
+  const double reach = std::max({std::hypot((double)Pd[GEO_BACK_A1], MODEL == 2 ? (double)Pd[GEO_BACK_A2] : 0.0),
+                                 std::fabs((double)Pd[GEO_BASE]), std::fabs((double)Pd[GEO_STACK])});
+  const double rnear = (range + 2.0 * reach) * (1.0 + 1e-4) + 1e-4;
+  const R rnear2 = R(rnear * rnear);
   for (int f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = std::min(chunk, n_frames - f0);
     dim3 grid(blocks, nf);
@@ -174,17 +184,17 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
     R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
     if (mode == 0)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart);
+                         sys->d_pgpart, rnear2);
     else if (mode == 1)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart);
+                         sys->d_pgpart, rnear2);
     else
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart);
+                         sys->d_pgpart, rnear2);
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
                        e_terms + (size_t)f0 * T_COUNT);
