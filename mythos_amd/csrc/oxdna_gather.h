@@ -85,7 +85,8 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
 // parameter partials, inside the sink) carry weight 1/2.
 // A row is walked in stages, each dense over the G lanes of the group:
-//   1. bonded slots (one lane each);
+//   1. bonded slots (one lane each) - unless the caller evaluates the bonded pairs elsewhere (BONDED = false: the
+//      energy kernel gathers the 64 bonded slots of its workgroup in one wavefront);
 //   2. every unbonded entry: centre distance only (12 bytes, no quaternion algebra) against rnear2, beyond which no
 //      site pair of the two nucleotides can be inside any cut-off; the near entries are compacted into an LDS list;
 //   3. the near list: full neighbour state, the radial terms, and a second compaction of the entries whose angular
@@ -95,7 +96,7 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // support) a single fused loop ran ~200 instructions of radial terms for every entry and the ~1 000-instruction
 // angular code in every iteration for a lane or two; the kernel is VALU-bound, so instructions are its time.
 // items: this group's LDS, two lists of row_stride ints (near entries, angular entries).
-template <typename R, int MODEL, bool GRAD, class PG, int G, class Loader, class PT>
+template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
@@ -108,7 +109,7 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
   int* __restrict__ near_list = items;
   int* __restrict__ ang_list = items + row_stride;
   // 1. bonded slots
-  if (lane < ROW_BONDED_SLOTS && lane < len) {
+  if (BONDED && lane < ROW_BONDED_SLOTS && lane < len) {
     const int entry = row[lane];
     if (entry >= 0) {
       Nuc<R> other;

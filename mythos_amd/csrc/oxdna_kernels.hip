@@ -72,17 +72,70 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
   R qs[4] = {R(1), R(0), R(0), R(0)};
+  const PackedLoader<R> ld{center + fo * 3, quat + fo * 4, meta};
+
+  // ---- bonded pairs: the 16 x 4 bonded slots of the workgroup are the 64 lanes of ONE wavefront (which one rotates
+  //      with the workgroup), results handed to the owners through LDS.  Left inside the row walk, every wavefront ran
+  //      the ~600 bonded instructions for the 4 of 16 lanes of its groups that hold a bonded slot: a quarter of the
+  //      kernel's instructions, and the kernel is VALU-bound.
+  static_assert(PPB * ROW_BONDED_SLOTS == 64, "one wavefront covers the bonded slots of the workgroup");
+  constexpr int kBondedWidth = T_COUNT + 12;
+  __shared__ R bonded_lds[PPB][ROW_BONDED_SLOTS][kBondedWidth];
+  if ((int)(threadIdx.x >> 6) == (int)(blockIdx.x & 3)) {
+    const int wl = threadIdx.x & 63, p = wl / ROW_BONDED_SLOTS, slot = wl % ROW_BONDED_SLOTS;
+    const int ip = blockIdx.x * PPB + p;
+    R eb[T_COUNT];
+#pragma unroll
+    for (int k = 0; k < T_COUNT; ++k) eb[k] = R(0);
+    SelfGrad<R> sb;
+    sb.dc = sb.g1 = sb.g2 = sb.g3 = V3<R>{R(0), R(0), R(0)};
+    if (ip < n && slot < row_len[ip]) {
+      const int entry = rows[(size_t)ip * row_stride + slot];
+      if (entry >= 0) {
+        Nuc<R> sp, other;
+        R qp[4], q4[4];
+        ld.load(ip, sp, qp);
+        ld.load(entry & ROW_INDEX_MASK, other, q4);
+        const V3<R> dco = min_image(other.c - sp.c, box);
+        if constexpr (MODE == 2) {
+          LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
+          bonded_pair<R, MODEL, GRAD, LdsPG>(P, sp, other, dco, (slot & 1) == 1, R(0.5), eb, sb, pg);
+        } else {
+          NoPG pg;
+          bonded_pair<R, MODEL, GRAD, NoPG>(P, sp, other, dco, (slot & 1) == 1, R(0.5), eb, sb, pg);
+        }
+      }
+    }
+    R* br = bonded_lds[p][slot];
+#pragma unroll
+    for (int k = 0; k < T_COUNT; ++k) br[k] = eb[k];
+    br[T_COUNT + 0] = sb.dc.x, br[T_COUNT + 1] = sb.dc.y, br[T_COUNT + 2] = sb.dc.z;
+    br[T_COUNT + 3] = sb.g1.x, br[T_COUNT + 4] = sb.g1.y, br[T_COUNT + 5] = sb.g1.z;
+    br[T_COUNT + 6] = sb.g2.x, br[T_COUNT + 7] = sb.g2.y, br[T_COUNT + 8] = sb.g2.z;
+    br[T_COUNT + 9] = sb.g3.x, br[T_COUNT + 10] = sb.g3.y, br[T_COUNT + 11] = sb.g3.z;
+  }
 
   if (i < n) {
-    PackedLoader<R> ld{center + fo * 3, quat + fo * 4, meta};
     Nuc<R> self;
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
       LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
-      gather_row<R, MODEL, GRAD, LdsPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
+      gather_row<R, MODEL, GRAD, LdsPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
     } else {
       NoPG pg;
-      gather_row<R, MODEL, GRAD, NoPG, G>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
+      gather_row<R, MODEL, GRAD, NoPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
+    }
+  }
+  __syncthreads();  // the bonded results are in LDS
+  if (i < n && lane < ROW_BONDED_SLOTS) {
+    const R* br = bonded_lds[grp][lane];
+#pragma unroll
+    for (int k = 0; k < T_COUNT; ++k) e[k] += br[k];
+    if constexpr (GRAD) {
+      sg.dc = sg.dc + V3<R>{br[T_COUNT + 0], br[T_COUNT + 1], br[T_COUNT + 2]};
+      sg.g1 = sg.g1 + V3<R>{br[T_COUNT + 3], br[T_COUNT + 4], br[T_COUNT + 5]};
+      sg.g2 = sg.g2 + V3<R>{br[T_COUNT + 6], br[T_COUNT + 7], br[T_COUNT + 8]};
+      sg.g3 = sg.g3 + V3<R>{br[T_COUNT + 9], br[T_COUNT + 10], br[T_COUNT + 11]};
     }
   }
   group_reduce<G, R, GRAD>(e, sg);
