@@ -78,18 +78,21 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   //      with the workgroup), results handed to the owners through LDS.  Left inside the row walk, every wavefront ran
   //      the ~600 bonded instructions for the 4 of 16 lanes of its groups that hold a bonded slot: a quarter of the
   //      kernel's instructions, and the kernel is VALU-bound.
-  static_assert(PPB * ROW_BONDED_SLOTS == 64, "one wavefront covers the bonded slots of the workgroup");
+  constexpr int kBondedWaves = (PPB * ROW_BONDED_SLOTS + 63) / 64;
+  static_assert(kBondedWaves <= kBlock / 64, "the bonded slots of a workgroup fit its wavefronts");
   constexpr int kBondedWidth = T_COUNT + 12;
   __shared__ R bonded_lds[PPB][ROW_BONDED_SLOTS][kBondedWidth];
-  if ((int)(threadIdx.x >> 6) == (int)(blockIdx.x & 3)) {
-    const int wl = threadIdx.x & 63, p = wl / ROW_BONDED_SLOTS, slot = wl % ROW_BONDED_SLOTS;
+  const int bonded_wave = ((int)(threadIdx.x >> 6) - (int)(blockIdx.x & 3)) & 3;  // 0 .. kBondedWaves-1: a bonded wavefront
+  if (bonded_wave < kBondedWaves) {
+    const int wl = bonded_wave * 64 + (threadIdx.x & 63), p = wl / ROW_BONDED_SLOTS, slot = wl % ROW_BONDED_SLOTS;
+    const bool slot_ok = wl < PPB * ROW_BONDED_SLOTS;
     const int ip = blockIdx.x * PPB + p;
     R eb[T_COUNT];
 #pragma unroll
     for (int k = 0; k < T_COUNT; ++k) eb[k] = R(0);
     SelfGrad<R> sb;
     sb.dc = sb.g1 = sb.g2 = sb.g3 = V3<R>{R(0), R(0), R(0)};
-    if (ip < n && slot < row_len[ip]) {
+    if (slot_ok && ip < n && slot < row_len[ip]) {
       const int entry = rows[(size_t)ip * row_stride + slot];
       if (entry >= 0) {
         Nuc<R> sp, other;
@@ -106,13 +109,15 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
         }
       }
     }
-    R* br = bonded_lds[p][slot];
+    R* br = bonded_lds[slot_ok ? p : 0][slot_ok ? slot : 0];
+    if (slot_ok) {
 #pragma unroll
     for (int k = 0; k < T_COUNT; ++k) br[k] = eb[k];
     br[T_COUNT + 0] = sb.dc.x, br[T_COUNT + 1] = sb.dc.y, br[T_COUNT + 2] = sb.dc.z;
     br[T_COUNT + 3] = sb.g1.x, br[T_COUNT + 4] = sb.g1.y, br[T_COUNT + 5] = sb.g1.z;
     br[T_COUNT + 6] = sb.g2.x, br[T_COUNT + 7] = sb.g2.y, br[T_COUNT + 8] = sb.g2.z;
     br[T_COUNT + 9] = sb.g3.x, br[T_COUNT + 10] = sb.g3.y, br[T_COUNT + 11] = sb.g3.z;
+    }
   }
 
   if (i < n) {
@@ -261,19 +266,30 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
 
 int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream) {
-  constexpr int G = 16;
-  if (sys->dtype == MYTHOS_F32) {
-    if (sys->model == 1)
-      return launch_typed<float, 1, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+  // Lanes per nucleotide by what the row walk's LDS lists (two of row_stride ints per nucleotide) leave room for:
+  // 8 lanes = 32 nucleotides per workgroup is the fastest (half the wavefronts of 16 lanes for the same rows, and the
+  // short angular lists fill 8 lanes better than 16), up to rows of 192 slots; longer rows take wider groups.
+  auto run = [&](auto g_tag) -> int {
+    constexpr int G = decltype(g_tag)::value;
+    if (sys->dtype == MYTHOS_F32) {
+      if (sys->model == 1)
+        return launch_typed<float, 1, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                         (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
+      return launch_typed<float, 2, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
                                        (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
-    return launch_typed<float, 2, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
-                                     (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
-  }
-  if (sys->model == 1)
-    return launch_typed<double, 1, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+    }
+    if (sys->model == 1)
+      return launch_typed<double, 1, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                        (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+    return launch_typed<double, 2, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
                                       (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
-  return launch_typed<double, 2, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
-                                    (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+  };
+  const size_t list_bytes = (size_t)2 * sys->row_stride * sizeof(int);  // per nucleotide
+  if ((kBlock / 8) * list_bytes <= (size_t)48 << 10) return run(std::integral_constant<int, 8>{});
+  if ((kBlock / 16) * list_bytes <= (size_t)60 << 10) return run(std::integral_constant<int, 16>{});
+  if ((kBlock / 32) * list_bytes <= (size_t)60 << 10) return run(std::integral_constant<int, 32>{});
+  set_error("mythos_oxdna_energy: neighbour rows of " + std::to_string(sys->row_stride) + " slots are longer than the energy kernel's lists allow");
+  return MYTHOS_ERR_OVERFLOW;
 }
 
 }  // namespace mythos
