@@ -41,7 +41,8 @@ enum mythos_status {
   MYTHOS_ERR_HIP = -2,
   MYTHOS_ERR_NO_DEVICE = -3,
   MYTHOS_ERR_NOT_READY = -4,   /* parameters or neighbours not set */
-  MYTHOS_ERR_OVERFLOW = -5,    /* neighbour row capacity exceeded / skin violated */
+  MYTHOS_ERR_OVERFLOW = -5,    /* a static neighbour list too short, or more out-of-turn rebuilds in one run than a
+                                  sane skin / rebuild interval produces (see mythos_langevin_last_recoveries) */
   MYTHOS_ERR_NUMERIC = -6      /* NaN / Inf detected */
 };
 
@@ -129,7 +130,9 @@ int mythos_langevin_init_momenta(mythos_sim_t* sim, void* p_lin, void* p_ang, my
  *   save_every > 0: traj_center dev real[n_steps/save_every][n][3], traj_quat [..][n][4] receive the
  *   state after steps save_every, 2*save_every, ...; e_trace dev double[n_steps/save_every][10] receives
  *   the 8 term energies + translational + rotational kinetic energy (any of the three may be NULL).
- * Returns MYTHOS_ERR_OVERFLOW if a nucleotide outran the Verlet skin between rebuilds. */
+ * A site that outruns the Verlet skin before the scheduled rebuild, or rows / cell buckets that outgrow their
+ * allocation, halt the queued launches; the run rebuilds at the last valid state and resumes (not an error; counted
+ * by mythos_langevin_last_recoveries).  MYTHOS_ERR_OVERFLOW only after 64 such rebuilds in one run. */
 int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin, void* p_ang, int n_steps,
                         int save_every, void* traj_center, void* traj_quat, double* e_trace,
                         mythos_stream_t stream);
@@ -209,7 +212,7 @@ int mythos_martini_param_grads(mythos_martini_t* m, const void* pos, const void*
  *   gamma    friction rate 1/ps (GROMACS sd integrator: 1 / tau_t);  mass host double[n] or NULL (72 amu)
  *   pos, vel dev real[n][3], updated in place;  box host double[3] (orthorhombic, fixed during the run)
  *   traj_pos dev real[n_steps/save_every][n][3] or NULL;  e_trace dev double[.][4] = lj, bond, angle, kinetic
- * Errors as mythos_langevin_run (OVERFLOW: row capacity or skin violated, NUMERIC: NaN). */
+ * Errors and the halt-and-resume protocol as mythos_langevin_run (NUMERIC: NaN). */
 mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, double dt, double kT, double gamma,
                                                      const double* mass, uint64_t seed);
 void mythos_martini_langevin_destroy(mythos_martini_sim_t* sim);
