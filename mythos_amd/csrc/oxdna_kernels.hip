@@ -18,9 +18,11 @@ constexpr int kBlock = 256;
 
 // Parameter-partial sink: fp64 LDS atomics into one of kPgCopies private copies of the accumulator (chosen by
 // lane), so the 64 lanes of a wave instruction that add to the SAME parameter - the common case: the index is a
-// compile-time constant at most call sites - hit 16 addresses in 16 different bank pairs instead of one.
-constexpr int kPgCopies = 16;
-constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: copy c of parameter k lands in bank pair (c + k) % 16
+// compile-time constant at most call sites - hit kPgCopies addresses in different bank pairs instead of one.
+// Eight copies, not sixteen: the LDS atomics are a few per cent of the kernel's time either way, but 35 KB of copies
+// left room for two workgroups per CU where the registers allow three (dU/dtheta call -30 % in fp32).
+constexpr int kPgCopies = 8;
+constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: the copies of one parameter land in different bank pairs
 struct LdsPG {
   static constexpr bool on = true;
   double* acc;  // this lane's copy
