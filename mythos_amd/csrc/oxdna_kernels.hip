@@ -39,7 +39,9 @@ struct LdsPG {
 #endif
 template <typename R, int MODE>
 constexpr int energy_blocks_per_cu() {
-  return sizeof(R) == 4 ? (MODE == 0 ? 4 : EN_LB) : 2;
+  // fp64: the energy-only mode runs faster at three workgroups per CU with 100 B of scratch than at two without
+  // (0.58 -> 0.49 ms on the DiffTRe shape); the gradient modes spill too much for that (0.72 -> 1.43 ms)
+  return sizeof(R) == 4 ? (MODE == 0 ? 4 : EN_LB) : (MODE == 0 ? 3 : 2);
 }
 
 template <typename R, int MODEL, int MODE, int G>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
