@@ -5,10 +5,13 @@ Langevin) per GPU, one independent replica per GPU (BASELINE.json metric / confi
     python bench.py --gpus 1 --steps 2000 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: starts the N ranks itself as child processes)
 
 A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin.hip).
-The timed region is one ``mythos_langevin_run`` call of K steps with the state resident in HBM,
-bracketed by barrier + synchronize; value = N_gpus * K / max-over-ranks time.  For N > 1 the
+The timed region is one ``mythos_langevin_advance`` call of K steps with the state resident in HBM
+(loaded into the integrator before the clock starts), bracketed by barrier + synchronize; value =
+N_gpus * K / max-over-ranks time.  Nothing else is inside it: the per-dispatch HIP events behind
+``roofline.kernel_ms`` are taken in a second, untimed pass of the same length.  For N > 1 the
 replicas' observables (energy trace) are all-gathered over RCCL inside the timed region.
 
 Rank 0 prints ONE JSON line with the fields of the driver contract plus
@@ -62,6 +65,7 @@ def parse_args():
     ap.add_argument("--workload", choices=["oxdna2-12kbp", "martini-bilayer"], default="oxdna2-12kbp",
                     help="oxdna2-12kbp is the headline (BASELINE.json metric); martini-bilayer is BASELINE configs[2] "
                          "(20 480-bead DMPC bilayer, LJ + bonds + angles, Langevin) and prints its own line")
+    ap.add_argument("--no-second-dtype", action="store_true", help="skip the measurement at the other precision (config.f64 / config.f32)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
                          "between ranks); the printed line is then marked as a rehearsal, not a measurement")
@@ -209,7 +213,6 @@ def martini_main(args):
     integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
     skin, every = (0.4 if args.skin is None else args.skin), (8 if args.rebuild_every is None else args.rebuild_every)
     integ.set_neighbor_policy(skin, every)
-    integ.set_timing(16)  # HIP event pairs on 16 dispatches of the timed run (roofline.kernel_ms)
     pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
     vel = integ.init_velocities()
     integ.run(pos, vel, bt, args.warmup)
@@ -218,6 +221,8 @@ def martini_main(args):
     integ.run(pos, vel, bt, args.steps)
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    integ.set_timing(16)  # untimed second pass: HIP event pairs on 16 dispatches (roofline.kernel_ms)
+    integ.run(pos, vel, bt, max(args.steps, 64))
     timing = integ.last_kernel_ms()
     mx, nbar = integ.neighbor_stats()
     n = system.n
@@ -240,62 +245,52 @@ def martini_main(args):
     }))
 
 
-def main():
-    args = parse_args()
-    if args.workload == "martini-bilayer":
-        return martini_main(args)
-    args.skin = 0.6 if args.skin is None else args.skin
-    args.rebuild_every = 25 if args.rebuild_every is None else args.rebuild_every
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as children of this process
+    (torch.distributed.run, rendezvous on 127.0.0.1) and relay their output.  Runs before anything in this
+    process has touched the GPU, and nothing is exec'ed: the parent only waits."""
+    import socket
+    import subprocess
 
-        from mythos_amd import distributed as md
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env, check=False).returncode
 
-        md.init("gloo" if args.rehearse_on_one_gpu else "nccl")  # "nccl" is RCCL on ROCm
 
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    word = 4 if args.dtype == "f32" else 8
-    sim, cfg = defaults.default_configs_for("dna2")
-    sim["dt"] = args.dt
+def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=None, md=None) -> dict:
+    """Warm up, time ``args.steps`` steps of the resident state (barrier + synchronize on both sides, MAX over
+    ranks), then - outside the timed region - the same number of steps with 16 dispatches bracketed by HIP events
+    on the launch stream (a bracketed dispatch costs ~8 us of queue time, so it is not part of the timed run)."""
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
     kT = sim["kT"]
-    top, c0, q0 = generators.ideal_duplex(args.bp, model=2, seed=1234)
-    n = top.n_nucleotides
-    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=sim["salt_conc"], half_charged_ends=True), _lib.param_names())
     system = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype, device=dev)
     system.set_params(flat)
     integ = LangevinIntegrator(
         system, dt=sim["dt"], kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"],
-        mass=sim["nucleotide_mass"], inertia=sim["moment_of_inertia"], seed=rank,
+        mass=sim["nucleotide_mass"], inertia=sim["moment_of_inertia"], seed=seed,
     )
     integ.set_neighbor_policy(R_CUT, args.skin, args.rebuild_every)
-    integ.set_timing(16)  # HIP event pairs on 16 dispatches of the timed run (roofline.kernel_ms)
     c = torch.as_tensor(c0, dtype=dtype, device=dev).contiguous()
     q = torch.as_tensor(q0, dtype=dtype, device=dev).contiguous()
     p, L = integ.init_momenta()
+    integ.load(c, q, p, L)  # inputs resident in HBM, in the integrator's layout, before the clock starts
 
     # ---- warm-up (untimed): also thermalises the ideal helix
-    integ.run(c, q, p, L, args.warmup)
+    integ.advance(args.warmup)
     torch.cuda.synchronize(dev)
 
-    # ---- timed region
+    # ---- timed region: exactly args.steps steps
+    world = 1 if dist is None else dist.get_world_size()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    _, _, et = integ.run(c, q, p, L, args.steps, save_every=args.save_every)
-    gathered = None
+    _, _, et = integ.advance(args.steps, save_every=args.save_every)
     if dist is not None:
         # per-replica observables (energy trace, or one row of zeros without --save-every), replica id =
         # rank: one all-gather over RCCL / xGMI - the only collective, the MD data path has none
@@ -307,30 +302,78 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
     if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        elapsed = float(t.item())
+    recoveries = integ.last_recoveries()
 
+    # ---- instrumented pass (untimed): duration of the step kernel from HIP events attached to sampled dispatches on
+    #      the launch stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
+    integ.set_timing(16)
+    integ.advance(max(args.steps, 64))
     timing = integ.last_kernel_ms()
+    integ.set_timing(0)
+    integ.store(c, q, p, L)
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(c).all() and torch.isfinite(q).all(), "state diverged"
     mx, nbar = system.neighbor_stats()
-    assert torch.isfinite(c).all(), "state diverged"
+    n = top.n_nucleotides
+    alg = algorithmic_bytes_per_step(n, nbar, 4 if dtype_name == "f32" else 8)
+    kms = timing["kernel_ms"]
+    achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+    return {"elapsed": elapsed, "steps_per_s": world * args.steps / elapsed, "kernel_ms": kms,
+            "loop_ms_per_launch": timing["loop_ms_per_launch"], "alg": alg, "achieved": achieved,
+            "mean_row": nbar, "max_row": mx, "recoveries": recoveries}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(args))  # no GPU call has been made in this process
+    if args.workload == "martini-bilayer":
+        return martini_main(args)
+    args.skin = 0.6 if args.skin is None else args.skin
+    args.rebuild_every = 25 if args.rebuild_every is None else args.rebuild_every
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    dev_index = 0 if args.rehearse_on_one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = md = None
+    if world > 1:
+        import torch.distributed as dist
+
+        from mythos_amd import distributed as md
+
+        md.init("gloo" if args.rehearse_on_one_gpu else "nccl")  # "nccl" is RCCL on ROCm
+
+    sim, cfg = defaults.default_configs_for("dna2")
+    sim["dt"] = args.dt
+    kT = sim["kT"]
+    top, c0, q0 = generators.ideal_duplex(args.bp, model=2, seed=1234)
+    n = top.n_nucleotides
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=sim["salt_conc"], half_charged_ends=True), _lib.param_names())
+
+    m = measure(args, args.dtype, top, c0, q0, sim, flat, dev, rank, dist, md)
+    # the reference computes in fp64 (jax_enable_x64): the same measurement at that precision goes into the same line
+    other = "f64" if args.dtype == "f32" else "f32"
+    m2 = measure(args, other, top, c0, q0, sim, flat, dev, rank, dist, md) if not args.no_second_dtype else None
 
     if rank == 0:
-        steps_per_s = world * args.steps / elapsed
-        alg = algorithmic_bytes_per_step(n, nbar, word)
-        # mean duration of the step kernel from HIP events attached to sampled dispatches on the launch
-        # stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
-        kms = timing["kernel_ms"]
-        achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
         out = {
             "metric": "MD steps/sec (and ns/day) per GPU, oxDNA2 12 kbp duplex",
-            "value": steps_per_s,
+            "value": m["steps_per_s"],
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -341,23 +384,30 @@ def main():
                 f"Langevin dt {sim['dt']}, kT {kT:.6f}, free space, 1 replica per GPU",
                 "replicas": world,
                 **({"rehearsal": "all ranks on cuda:0 over gloo - not a measurement"} if args.rehearse_on_one_gpu else {}),
-                "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": nbar, "max_row": mx,
-                                  "out_of_turn_rebuilds": integ.last_recoveries()},
-                "ns_per_day": steps_per_s / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
+                "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": m["mean_row"],
+                                  "max_row": m["max_row"], "out_of_turn_rebuilds": m["recoveries"]},
+                "ns_per_day": m["steps_per_s"] / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
+                "timed_region": f"one mythos_langevin_advance of {args.steps} steps on the resident state = {args.steps + 1} "
+                "step-kernel launches (the last closes the final half kick) + scheduled list rebuilds + one stream synchronisation",
             },
             "roofline": {
                 "bound": "hbm",
-                "achieved": achieved,
+                "achieved": m["achieved"],
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": m["achieved"] / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args, n),
                 "kernel": "md_step_kernel",
-                "kernel_ms": kms,
-                "loop_ms_per_launch": timing["loop_ms_per_launch"],
-                "algorithmic_bytes_per_launch": alg,
+                "kernel_ms": m["kernel_ms"],
+                "loop_ms_per_launch": m["loop_ms_per_launch"],
+                "algorithmic_bytes_per_launch": m["alg"],
             },
         }
+        if m2 is not None:
+            out["config"][other] = {"steps_per_s": m2["steps_per_s"], "ms_per_step": 1e3 * m2["elapsed"] / args.steps,
+                                    "kernel_ms": m2["kernel_ms"], "loop_ms_per_launch": m2["loop_ms_per_launch"],
+                                    "achieved_GBs": m2["achieved"], "frac": m2["achieved"] / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_launch": m2["alg"]}
         cpu_steps = args.cpu_steps
         if cpu_steps < 0:
             cpu_steps = 60 if n > 8000 else 400  # capped at about 20 s of host work

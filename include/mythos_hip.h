@@ -136,11 +136,27 @@ int mythos_langevin_init_momenta(mythos_sim_t* sim, void* p_lin, void* p_ang, my
 int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin, void* p_ang, int n_steps,
                         int save_every, void* traj_center, void* traj_quat, double* e_trace,
                         mythos_stream_t stream);
+/* Resident form of the same loop: the state stays in the integrator's own layout on the device between calls, as
+ * the carry of the reference's jax.lax.scan stays on its device (mythos/simulators/jax_md/jaxmd.py:87-94).
+ *   load     caller's arrays -> resident state (asynchronous); the neighbour list is rebuilt at the next advance
+ *   advance  n_steps on the resident state; the list and its rebuild schedule carry over from the previous advance;
+ *            outputs as mythos_langevin_run.  One stream synchronisation per call (the halt-and-resume protocol
+ *            needs the host to see the control words before the steps count as taken), nothing else between calls
+ *   store    resident state -> caller's arrays (asynchronous on the stream); the state stays resident
+ * mythos_langevin_run(...) == load; advance; store.  advance after advance continues bit for bit like one advance
+ * of the summed length.  An advance that ends in MYTHOS_ERR_NUMERIC drops the resident state. */
+int mythos_langevin_load(mythos_sim_t* sim, const void* center, const void* quat, const void* p_lin, const void* p_ang,
+                         mythos_stream_t stream);
+int mythos_langevin_advance(mythos_sim_t* sim, int n_steps, int save_every, void* traj_center, void* traj_quat,
+                            double* e_trace, mythos_stream_t stream);
+int mythos_langevin_store(mythos_sim_t* sim, void* center, void* quat, void* p_lin, void* p_ang, mythos_stream_t stream);
+
 /* absolute step counter (RNG stream position); settable for checkpoint/resume */
 int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
 int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 
-/* timing hook for bench.py, HIP events on the launch stream of the last run:
+/* timing hook for bench.py, HIP events on the launch stream of the last run / advance (all zero unless
+ * mythos_langevin_set_timing asked for samples: an untimed run records no events at all):
  *   kernel_ms            mean duration of the step kernel over up to 16 launches spread evenly over the
  *                        run, each timed by its own event pair attached to the dispatch
  *                        (hipExtLaunchKernelGGL start/stop events = the dispatch's begin/end stamps)

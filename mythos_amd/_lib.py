@@ -60,6 +60,9 @@ def load() -> C.CDLL:
         "mythos_langevin_set_neighbor_policy": (C.c_int, [V, C.c_double, C.c_double, C.c_int]),
         "mythos_langevin_init_momenta": (C.c_int, [V, V, V, V]),
         "mythos_langevin_run": (C.c_int, [V, V, V, V, V, C.c_int, C.c_int, V, V, V, V]),
+        "mythos_langevin_load": (C.c_int, [V, V, V, V, V, V]),
+        "mythos_langevin_advance": (C.c_int, [V, C.c_int, C.c_int, V, V, V, V]),
+        "mythos_langevin_store": (C.c_int, [V, V, V, V, V, V]),
         "mythos_langevin_get_step": (C.c_int64, [V]),
         "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
         "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -111,6 +114,9 @@ DECLARED_SYMBOLS = (
     "mythos_langevin_set_neighbor_policy",
     "mythos_langevin_init_momenta",
     "mythos_langevin_run",
+    "mythos_langevin_load",
+    "mythos_langevin_advance",
+    "mythos_langevin_store",
     "mythos_langevin_get_step",
     "mythos_langevin_set_step",
     "mythos_langevin_last_kernel_ms",

@@ -165,6 +165,7 @@ int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params
   MYTHOS_HIP_TRY(hipMemcpy(s->d_pf, s->pf.v, OXP_COUNT * sizeof(float), hipMemcpyHostToDevice));
   MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd.v, OXP_COUNT * sizeof(double), hipMemcpyHostToDevice));
   s->params_set = true;
+  ++s->list_epoch;  // cut-offs may have moved: integrators rebuild their list
   return MYTHOS_OK;
 }
 
@@ -174,6 +175,7 @@ int mythos_oxdna_set_neighbors(mythos_system_t* s, const int32_t* pairs, int n_p
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  ++s->list_epoch;
   return rows_from_pairs(s, pairs, n_pairs);
 }
 
@@ -185,6 +187,7 @@ int mythos_oxdna_build_neighbors(mythos_system_t* s, const void* center, double 
   }
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
   hipStream_t st = (hipStream_t)stream;
+  ++s->list_epoch;
   return rows_build_until_fit(s, center, false, r_cut, skin, nullptr, nullptr, false, false, st);
 }
 

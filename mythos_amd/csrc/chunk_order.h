@@ -1,4 +1,4 @@
-// Spatial order of the MD kernels' workgroup chunks (host side).
+// Spatial order of the MD kernels' workgroup chunks, computed on the device (no host round trip, no synchronisation).
 //
 // The step kernels give XCD x the x-th contiguous eighth of a list of chunks (32 particles each), so that the
 // neighbours a workgroup reads are mostly in its own XCD's L2.  In index order that holds only when index
@@ -7,53 +7,71 @@
 // code of their position makes the eighths contiguous in space whatever the storage order (12 kbp duplex: +2.6 %).
 // Not used by the MARTINI kernel: the tiled bilayer is stored tile by tile, molecule by molecule, already compact,
 // and ordering its 32-bead chunks by their first bead made it 9 % slower.
+//
+// Two small kernels on the caller's stream: a Morton key per chunk (from the position of its first particle, cells
+// of the list range, origin shifted by 2^20 cells so that negative coordinates order correctly), then a rank sort -
+// chunk c goes to place #{c' : (key, c') < (key, c)}.  The rank sort is O(chunks^2) key comparisons: 0.6 M for a
+// 12 kbp duplex, 39 M for 100 kbp (a few tens of microseconds, once per load and every few dozen list rebuilds).
 #ifndef MYTHOS_CHUNK_ORDER_H
 #define MYTHOS_CHUNK_ORDER_H
 
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <cstdint>
-#include <utility>
-#include <vector>
 
 namespace mythos {
 
-// pos: device array of V4 (x, y, z, *), one per particle; chunk c is represented by particle c * per_chunk.
-// *d_order is allocated on first use ([blocks] ints).  Synchronises the stream.  Returns a hipError_t.
+__device__ __forceinline__ unsigned long long morton_spread21(unsigned long long x) {  // 21 bits -> every third bit
+  x &= 0x1fffffull;
+  x = (x | x << 32) & 0x1f00000000ffffull;
+  x = (x | x << 16) & 0x1f0000ff0000ffull;
+  x = (x | x << 8) & 0x100f00f00f00f00full;
+  x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+  x = (x | x << 2) & 0x1249249249249249ull;
+  return x;
+}
+
 template <typename V4>
-static inline hipError_t chunk_order_update(const V4* pos, int blocks, int per_chunk, double cell, int** d_order,
-                                            hipStream_t st) {
-  std::vector<V4> rep((size_t)blocks);
-  hipError_t e = hipMemcpy2DAsync(rep.data(), sizeof(V4), pos, (size_t)per_chunk * sizeof(V4), sizeof(V4), (size_t)blocks,
-                                  hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess) return e;
-  if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
-  double lo[3] = {1e300, 1e300, 1e300};
-  for (const V4& v : rep)
-    lo[0] = std::min(lo[0], (double)v.x), lo[1] = std::min(lo[1], (double)v.y), lo[2] = std::min(lo[2], (double)v.z);
-  auto spread = [](uint64_t x) {  // 21 bits -> every third bit
-    x &= 0x1fffff;
-    x = (x | x << 32) & 0x1f00000000ffffull;
-    x = (x | x << 16) & 0x1f0000ff0000ffull;
-    x = (x | x << 8) & 0x100f00f00f00f00full;
-    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
-    x = (x | x << 2) & 0x1249249249249249ull;
-    return x;
+__global__ void chunk_keys_kernel(const V4* __restrict__ pos, int blocks, int per_chunk, double inv_cell,
+                                  unsigned long long* __restrict__ keys) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= blocks) return;
+  const V4 v = pos[(size_t)c * per_chunk];
+  auto cell = [&](double x) {
+    const double f = floor(x * inv_cell) + 1048576.0;
+    return (unsigned long long)(f < 0.0 ? 0.0 : (f > 2097151.0 ? 2097151.0 : f));
   };
-  std::vector<std::pair<uint64_t, int>> key((size_t)blocks);
-  for (int c = 0; c < blocks; ++c) {
-    const V4& v = rep[(size_t)c];
-    const uint64_t ix = (uint64_t)(((double)v.x - lo[0]) / cell), iy = (uint64_t)(((double)v.y - lo[1]) / cell),
-                   iz = (uint64_t)(((double)v.z - lo[2]) / cell);
-    key[(size_t)c] = {spread(ix) | spread(iy) << 1 | spread(iz) << 2, c};
+  keys[c] = morton_spread21(cell((double)v.x)) | morton_spread21(cell((double)v.y)) << 1 | morton_spread21(cell((double)v.z)) << 2;
+}
+
+__global__ void chunk_rank_kernel(const unsigned long long* __restrict__ keys, int blocks, int* __restrict__ order) {
+  __shared__ unsigned long long tile[256];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long mine = c < blocks ? keys[c] : 0ull;
+  int rank = 0;
+  for (int base = 0; base < blocks; base += 256) {
+    const int t = base + (int)threadIdx.x;
+    tile[threadIdx.x] = t < blocks ? keys[t] : ~0ull;
+    __syncthreads();
+    const int lim = min(256, blocks - base);
+    for (int k = 0; k < lim; ++k) {
+      const unsigned long long o = tile[k];
+      rank += (o < mine || (o == mine && base + k < c)) ? 1 : 0;
+    }
+    __syncthreads();
   }
-  std::sort(key.begin(), key.end());
-  std::vector<int> order((size_t)blocks);
-  for (int c = 0; c < blocks; ++c) order[(size_t)c] = key[(size_t)c].second;
-  if (!*d_order && (e = hipMalloc((void**)d_order, (size_t)blocks * sizeof(int))) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(*d_order, order.data(), (size_t)blocks * sizeof(int), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-  return hipStreamSynchronize(st);  // order[] leaves scope
+  if (c < blocks) order[rank] = c;
+}
+
+// pos: device array of V4 (x, y, z, *), one per particle; chunk c is represented by particle c * per_chunk.
+// d_keys [blocks] and d_order [blocks] are the caller's device buffers.  Asynchronous on st.
+template <typename V4>
+static inline hipError_t chunk_order_device(const V4* pos, int blocks, int per_chunk, double cell,
+                                            unsigned long long* d_keys, int* d_order, hipStream_t st) {
+  const int g = (blocks + 255) / 256;
+  hipLaunchKernelGGL((chunk_keys_kernel<V4>), dim3(g), dim3(256), 0, st, pos, blocks, per_chunk, 1.0 / cell, d_keys);
+  hipLaunchKernelGGL(chunk_rank_kernel, dim3(g), dim3(256), 0, st, (const unsigned long long*)d_keys, blocks, d_order);
+  return hipGetLastError();
 }
 
 }  // namespace mythos

@@ -258,7 +258,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // kernel writes nothing to global memory.  (Every thread loading and testing them up front cost 1.7 % of the step.)
   __shared__ int s_halt;
   int halt_word = 0;  // requested now, parked in LDS just before the barrier: nobody waits for it on the way
-  if (threadIdx.x == 0) halt_word = flags[1] | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
+  // The halt word carries the index of the first launch that must not run (set by launch k: k + 1): a workgroup of
+  // the SAME launch that starts after the word was set keeps going - on a grid larger than what is resident at once
+  // the late workgroups of launch k would otherwise skip a step the early ones took.
+  if (threadIdx.x == 0) {
+    const int hw = flags[1];
+    halt_word = ((hw != 0 && hw <= k_index) ? 1 : 0) | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
+  }
   // chunk_order (host, from the positions at the start of a run): the chunks of 32 nucleotides in spatial order, so
   // the contiguous eighth an XCD works on is also contiguous in space - in a duplex the two complementary
   // stretches of the strands, which are far apart in index, land on the same XCD and share its L2
@@ -777,7 +783,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const R sx = dx + gb * (n1.x - a0.x), sy = dy + gb * (n1.y - a0.y), sz = dz + gb * (n1.z - a0.z);
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq || bx * bx + by * by + bz * bz > K.skin_half_sq ||
             sx * sx + sy * sy + sz * sz > K.skin_half_sq)
-          atomicOr(flags + 1, 1);  // the list is stale for the NEXT force evaluation: halt before it
+          atomicMax(flags + 1, k_index + 1);  // the list is stale for the NEXT force evaluation: launch k + 1 halts
       }
     }
     out.p0[i] = V4{x[0], x[1], x[2], self_lds[il][9]};
@@ -913,16 +919,27 @@ struct mythos_sim {
   int rebuild_every = 0;
   // device state: two ping-pong frames of 6 vec4 arrays each (p0, p1, p2, p3, q, pl) + momenta
   void* frame[2][6] = {};
+  int cur = 0;             // the frame that holds the current state
+  bool resident = false;   // the frames hold a state (mythos_langevin_load, or the last run)
+  bool list_valid = false; // the rows were built from this state's history and the rebuild schedule continues
+  int since_build = 0;     // steps taken since the rows were built
+  int builds = 0;          // scheduled rebuilds so far (the chunk order is refreshed every 64th)
+  int list_epoch = 0;      // sys->list_epoch the rows in use belong to
   // centres as the last run handed them out (hi) and the low parts that went with them (fp32 systems)
   void *keep_hi = nullptr, *keep_lo = nullptr;
   bool keep_valid = false;
   void *mom = nullptr, *ang = nullptr;
   static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN, 4 angular items), [1] halt, [2] progress
   int* d_flags = nullptr;
+  // control words as the device published them at the end of a segment: [0..3] d_flags, [4..6] the list builder's
+  // overflow words.  Pinned host memory the publishing kernel writes directly: one stream synchronisation per
+  // segment and no copy commands.
+  int* h_ctl = nullptr;
+  int* d_ctl = nullptr;          // device address of h_ctl
   int last_recoveries = 0;       // halts of the last run that were rebuilt and resumed
   bool list_fitted = false;      // a synchronising, growing build has sized rows and buckets for this integrator
   int* d_chunk_order = nullptr;  // [blocks] spatial order of the 32-nucleotide chunks (null: index order)
-  int chunk_order_age = 0;       // runs since it was computed
+  unsigned long long* d_chunk_keys = nullptr;
   double* d_epart = nullptr;
   int epart_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -937,6 +954,15 @@ struct mythos_sim {
 };
 
 namespace mythos {
+
+// End of a segment: hand the control words to the host (pinned memory) and clear the ones a later segment starts
+// from, so that neither a copy command nor a memset sits between two runs.
+__global__ void publish_ctl_kernel(int* __restrict__ flags, int* __restrict__ overflow, int* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = flags[0], out[1] = flags[1], out[2] = flags[2], out[3] = flags[3];
+  out[4] = overflow ? overflow[0] : 0, out[5] = overflow ? overflow[1] : 0, out[6] = overflow ? overflow[2] : 0;
+  flags[0] = 0, flags[2] = 0;  // the halt word stays until the host has recovered (later launches must see it)
+}
 
 template <typename R>
 static LangevinConst<R> make_const(const mythos_sim* s) {
@@ -982,28 +1008,64 @@ static Frame<R> frame_of(const mythos_sim* sim, int k) {
                   (V4*)sim->frame[k][4], (V4*)sim->frame[k][5]};
 }
 
-// Spatial order of the workgroups' chunks (chunk_order.h): one strided copy of a position per chunk to the host, a
-// sort, one small upload; redone every 16th run (molecules drift slowly, and a stale order costs speed, not
-// correctness).  Systems under 64 chunks do not bother.
+// Spatial order of the workgroups' chunks (chunk_order.h): two small kernels on the run's stream, at every load and
+// every 64th scheduled list rebuild (molecules drift slowly, and a stale order costs speed, not correctness).
+// Systems under 64 chunks do not bother.
 template <typename R>
 static int update_chunk_order(mythos_sim* sim, const typename Vec4T<R>::type* p0, int blocks, hipStream_t st) {
   if (blocks < 64) return 0;
-  if (sim->d_chunk_order && (++sim->chunk_order_age & 15) != 0) return 0;
-  MYTHOS_HIP_TRY(chunk_order_update(p0, blocks, kMdPPB, std::max(1.0, sim->r_cut > 0 ? sim->r_cut : 4.0), &sim->d_chunk_order, st));
-  sim->chunk_order_age = 0;
+  if (!sim->d_chunk_keys) MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_chunk_keys, (size_t)blocks * sizeof(unsigned long long)));
+  if (!sim->d_chunk_order) MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_chunk_order, (size_t)blocks * sizeof(int)));
+  MYTHOS_HIP_TRY(chunk_order_device(p0, blocks, kMdPPB, std::max(1.0, sim->r_cut > 0 ? sim->r_cut : 4.0), sim->d_chunk_keys,
+                                    sim->d_chunk_order, st));
   return 0;
 }
 
+// Caller's (N,3)/(N,4) arrays -> the resident frames.  The list of a previous state does not carry over.
 template <typename R, int MODEL>
-static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, int n_steps, int save_every,
-                     R* traj_center, R* traj_quat, double* e_trace, hipStream_t st) {
+static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* p_lin, const R* p_ang, hipStream_t st) {
+  using V4 = typename Vec4T<R>::type;
+  mythos_system* sys = sim->sys;
+  const int n = sys->n;
+  const int tb = (n + 255) / 256;
+  const OxParams<R>& P = params_of<R>(sys);
+  const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  sim->cur = 0;
+  const Frame<R> f0 = frame_of<R>(sim, 0);
+  hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
+                     sys->d_meta, f0, (V4*)sim->mom, (V4*)sim->ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
+                     (const R*)sim->keep_lo);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  sim->resident = true;
+  sim->list_valid = false;
+  sim->since_build = 0;
+  return update_chunk_order<R>(sim, f0.p0, (n + kMdPPB - 1) / kMdPPB, st);
+}
+
+// The resident frames -> caller's arrays (asynchronous on st; the state stays resident).
+template <typename R>
+static int store_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, hipStream_t st) {
+  using V4 = typename Vec4T<R>::type;
+  const int n = sim->sys->n;
+  hipLaunchKernelGGL(unpack_state_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, frame_of<R>(sim, sim->cur),
+                     (const V4*)sim->mom, (const V4*)sim->ang, center, quat, p_lin, p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  sim->keep_valid = true;
+  return 0;
+}
+
+// n_steps on the resident state: n_steps + 1 launches (the last one closes the final half kick) and ONE stream
+// synchronisation per segment of kSegment launches - the host has to see the halt word before it can say the steps
+// were taken.  Nothing else is between two calls: the list and its rebuild schedule carry over, the control words
+// are published and cleared by a one-thread kernel, events are recorded only when timing was asked for.
+template <typename R, int MODEL>
+static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_center, R* traj_quat, double* e_trace,
+                         hipStream_t st) {
   using V4 = typename Vec4T<R>::type;
   mythos_system* sys = sim->sys;
   const int n = sys->n;
   const int blocks = (n + kMdPPB - 1) / kMdPPB;
   const int grid = 8 * ((blocks + 7) / 8);  // padded for the kernel's XCD-aware workgroup order
-  const int tb = (n + 255) / 256;
-  const OxParams<R>& P = params_of<R>(sys);
   const R* Pdev = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
   const LangevinConst<R> K = make_const<R>(sim);
@@ -1011,12 +1073,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   const Frame<R> fr[2] = {frame_of<R>(sim, 0), frame_of<R>(sim, 1)};
   V4* mom = (V4*)sim->mom;
   V4* ang = (V4*)sim->ang;
-  const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
-  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, mythos_sim::kCtlWords * sizeof(int), st));
-  hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
-                     sys->d_meta, fr[0], mom, ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
-                     (const R*)sim->keep_lo);
-  int cur = 0;
+  int cur = sim->cur;
 #ifdef MYTHOS_MD_DIAG
   const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
   const int ablate = abl ? atoi(abl) : 0;
@@ -1024,29 +1081,34 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   const int ablate = 0;
 #endif
   const bool dynamic_list = sim->rebuild_every > 0;
-  if (int rc = update_chunk_order<R>(sim, fr[cur].p0, blocks, st)) return rc;
+  const bool timing = sim->timing_samples > 0;
   auto rebuild = [&](int buf) -> int {
+    if ((++sim->builds & 63) == 0)
+      if (int rc = update_chunk_order<R>(sim, fr[buf].p0, blocks, st)) return rc;
     return rows_build_device(sys, fr[buf].p0, true, sim->r_cut, sim->skin, fr[buf].p3, fr[buf].p1, true, st);
   };
+  // k index at which the rows in use were built (negative: so many steps before this call)
+  int built_at = 0;
   if (dynamic_list) {
-    // first build of the run.  The first run of this integrator sizes rows (a quarter of headroom) and cell buckets
-    // (none more than half full) with a synchronising build; later runs just rebuild - should that overflow, the
-    // first step kernel halts and the recovery below grows what is needed (a synchronisation saved per run: ~70 us,
-    // which is 4 % of a 100-step run of the 12 kbp duplex)
     if (!sim->list_fitted) {
+      // the first build of this integrator sizes rows (a quarter of headroom) and cell buckets (none more than half
+      // full) with a synchronising build; later ones just rebuild - should that overflow, the next step kernel
+      // halts and the recovery below grows what is needed
       if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
         return rc;
       sim->list_fitted = true;
-    } else {
-      MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_overflow, 0, kOverflowWords * sizeof(int), st));
+    } else if (!sim->list_valid) {
       if (int rc = rebuild(cur)) return rc;
+    } else {
+      built_at = -sim->since_build;
     }
+    sim->list_valid = true;
   }
-  MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
+  if (timing) MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0;
   const int max_samples = std::min(sim->timing_samples, (int)mythos_sim::kMaxSamples);  // 0: no dispatch is bracketed
   const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
-  const int* halt_words = dynamic_list ? sys->d_overflow : nullptr;
+  int* halt_words = dynamic_list ? sys->d_overflow : nullptr;
   // The kernels of a run are queued in segments of kSegment; after each the host looks at the halt word.  A step that
   // moves a site out of its skin, or a rebuild that overflows its rows or spill list, halts the launches behind it
   // (they return at once); the host then rebuilds at the last valid state - growing what overflowed - and resumes
@@ -1054,14 +1116,17 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
   // it costs is the empty launches behind the halt (at most a segment) and a synchronisation.
   constexpr int kSegment = 8192, kMaxRecoveries = 64;
   int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
+  int err_bits = 0, ovw[kOverflowWords] = {0, 0, 0};
   while (k <= n_steps) {
     const int seg_end = std::min(n_steps, k + seg_len - 1);
     for (; k <= seg_end; ++k) {
       const bool last = (k == n_steps);
       const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
       const int sidx = save ? (k / save_every - 1) : 0;
-      if (dynamic_list && k > 0 && !last && (k % sim->rebuild_every == 0))
+      if (dynamic_list && !last && k - built_at >= sim->rebuild_every) {
         if (int rc = rebuild(cur)) return rc;
+        built_at = k;
+      }
       const R kick_close = (k == 0) ? R(0) : R(0.5);
       const int do_step = last ? 0 : 1;
       R* tc = (save && traj_center) ? traj_center + (size_t)sidx * n * 3 : nullptr;
@@ -1092,49 +1157,53 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
       ++launches;
       cur ^= 1;
     }
-    if (!dynamic_list) continue;
-    int ctl[mythos_sim::kCtlWords] = {0, 0, 0, 0}, ovs[kOverflowWords] = {0, 0, 0};
-    MYTHOS_HIP_TRY(hipMemcpyAsync(ctl, sim->d_flags, sizeof(ctl), hipMemcpyDeviceToHost, st));
-    MYTHOS_HIP_TRY(hipMemcpyAsync(ovs, sys->d_overflow, sizeof(ovs), hipMemcpyDeviceToHost, st));
+    if (timing && k > n_steps) MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
+    hipLaunchKernelGGL(publish_ctl_kernel, dim3(1), dim3(1), 0, st, sim->d_flags, halt_words, sim->d_ctl);
+    MYTHOS_HIP_TRY(hipGetLastError());
     MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-    if ((ctl[0] & (2 | 4)) != 0) break;                          // NaN / angular items: reported below
-    if (ctl[1] == 0 && ovs[0] == 0 && ovs[1] == 0) continue;     // nothing halted
+    const int* ctl = sim->h_ctl;
+    err_bits |= ctl[0];
+    for (int w = 0; w < kOverflowWords; ++w) ovw[w] = ctl[4 + w];
+    if ((err_bits & (2 | 4)) != 0) break;                        // NaN / angular items: reported below
+    if (ctl[1] == 0 && ovw[0] == 0 && ovw[1] == 0) continue;     // nothing halted
+    if (!dynamic_list) break;                                    // (a static list cannot halt; defensive)
     if (++recoveries > kMaxRecoveries) {
       sim->step += ctl[2];
+      sim->resident = false;
       set_error("mythos_langevin_run: the neighbour list had to be rebuilt out of turn more than " + std::to_string(kMaxRecoveries) +
                 " times in one run: the skin (" + std::to_string(sim->skin) + ") is too small for a rebuild every " +
                 std::to_string(sim->rebuild_every) + " steps");
       return MYTHOS_ERR_OVERFLOW;
     }
-    k = ctl[2];   // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
-    cur = k & 1;
+    // kernels 0 .. k-1 ran; the state they left is in the frame kernel k would have read
+    const int ran = ctl[2];
+    cur = sim->cur ^ (ran & 1);
+    k = ran;
     seg_len = std::max(256, seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
     if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
       return rc;
+    built_at = k;
+    ovw[0] = ovw[1] = 0;
   }
   sim->last_recoveries = recoveries;
-  MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
-  MYTHOS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(unpack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, fr[cur], mom, ang, center, quat, p_lin,
-                     p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
-  sim->keep_valid = true;
-  int flags = 0, ovw[kOverflowWords] = {0, 0, 0};
-  MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipMemcpyAsync(ovw, sys->d_overflow, sizeof(ovw), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-  const int ov = dynamic_list ? ovw[0] : 0;
-  float ms = 0;
-  MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
-  sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
-  sim->last_launches = launches;
-  double acc = 0;
-  for (int k = 0; k < samples; ++k) {
-    float t = 0;
-    MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[k], sim->sb[k]));
-    acc += t;
+  sim->cur = cur;
+  sim->since_build = n_steps - built_at;
+  if (timing) {
+    float ms = 0;
+    MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
+    sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
+    double acc = 0;
+    for (int s = 0; s < samples; ++s) {
+      float t = 0;
+      MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[s], sim->sb[s]));
+      acc += t;
+    }
+    sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  } else {
+    sim->last_avg_ms = sim->last_kernel_ms = 0.0;
   }
-  sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  sim->last_launches = launches;
   sim->last_samples = samples;
   if (ablate & 128) {  // diagnostic: dump the cycle stamps of the last launch
     if (const char* path = getenv("MYTHOS_MD_STAMPS")) {
@@ -1147,12 +1216,13 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
     }
   }
   sim->step += n_steps;
-  if (flags & 2) {
+  if (err_bits & 2) {
+    sim->resident = false;
     set_error("mythos_langevin_run: NaN in the state (time step too large or overlapping start configuration)");
     return MYTHOS_ERR_NUMERIC;
   }
-  if (ov != 0) {
-    set_error("mythos_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
+  if (dynamic_list && ovw[0] != 0) {
+    set_error("mythos_langevin_run: neighbour row capacity exceeded (" + std::to_string(ovw[0]) + " > " +
               std::to_string(sys->row_stride) + "); rebuild with mythos_oxdna_build_neighbors first");
     return MYTHOS_ERR_OVERFLOW;
   }
@@ -1161,7 +1231,7 @@ static int run_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, in
               ") did not fit the buckets of their cells during a neighbour rebuild");
     return MYTHOS_ERR_OVERFLOW;
   }
-  if (flags & 4) {
+  if (err_bits & 4) {
     set_error("mythos_langevin_run: more than " + std::to_string(kMdMaxItems) +
               " neighbours of one nucleotide are inside the range of an angular term");
     return MYTHOS_ERR_OVERFLOW;
@@ -1201,7 +1271,11 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
   ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
        hipMalloc((void**)&s->d_flags, mythos_sim::kCtlWords * sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 64 * sizeof(double)) == hipSuccess &&
-       hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
+       hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess &&
+       hipHostMalloc((void**)&s->h_ctl, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&s->d_ctl, s->h_ctl, 0) == hipSuccess &&
+       hipMemset(s->d_flags, 0, mythos_sim::kCtlWords * sizeof(int)) == hipSuccess;
+  if (ok) std::fill(s->h_ctl, s->h_ctl + 8, 0);
   for (int k = 0; ok && k < mythos_sim::kMaxSamples; ++k)
     ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;
   if (ok && !sys->d_ref_pos) ok = hipMalloc(&sys->d_ref_pos, v4) == hipSuccess;
@@ -1226,6 +1300,8 @@ void mythos_langevin_destroy(mythos_sim_t* s) {
   if (s->ang) (void)hipFree(s->ang);
   if (s->d_flags) (void)hipFree(s->d_flags);
   if (s->d_chunk_order) (void)hipFree(s->d_chunk_order);
+  if (s->d_chunk_keys) (void)hipFree(s->d_chunk_keys);
+  if (s->h_ctl) (void)hipHostFree(s->h_ctl);
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1245,6 +1321,7 @@ int mythos_langevin_set_neighbor_policy(mythos_sim_t* s, double r_cut, double sk
   s->skin = skin;
   s->rebuild_every = every;
   s->list_fitted = false;  // another list range: size rows and buckets again at the next run
+  s->list_valid = false;
   return MYTHOS_OK;
 }
 
@@ -1267,6 +1344,50 @@ int mythos_langevin_init_momenta(mythos_sim_t* s, void* p_lin, void* p_ang, myth
   return MYTHOS_OK;
 }
 
+namespace {
+
+// what every entry that launches step kernels checks first
+int md_ready(mythos_sim_t* s, const char* who) {
+  mythos_system* sys = s->sys;
+  if (!sys->params_set || (!sys->nbrs_set && s->rebuild_every <= 0)) {
+    set_error(std::string(who) + ": parameters and neighbours (or a neighbour policy) must be set first");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(sys->device));
+  if (s->rebuild_every > 0 && sys->row_stride == 0)
+    if (int rc = rows_reserve(sys, 64)) return rc;
+  if (s->list_epoch != sys->list_epoch) {  // parameters or rows were replaced behind the integrator's back
+    s->list_valid = false;
+    s->list_epoch = sys->list_epoch;
+  }
+  return MYTHOS_OK;
+}
+
+int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
+  mythos_system* sys = s->sys;
+  if (sys->dtype == MYTHOS_F32)
+    return sys->model == 1 ? load_typed<float, 1>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+                           : load_typed<float, 2>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
+  return sys->model == 1 ? load_typed<double, 1>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
+                         : load_typed<double, 2>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
+}
+
+int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
+  mythos_system* sys = s->sys;
+  if (sys->dtype == MYTHOS_F32)
+    return sys->model == 1 ? advance_typed<float, 1>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
+                           : advance_typed<float, 2>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st);
+  return sys->model == 1 ? advance_typed<double, 1>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
+                         : advance_typed<double, 2>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
+}
+
+int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
+  if (s->sys->dtype == MYTHOS_F32) return store_typed<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
+  return store_typed<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
+}
+
+}  // namespace
+
 int mythos_langevin_run(mythos_sim_t* s, void* center, void* quat, void* p_lin, void* p_ang, int n_steps,
                         int save_every, void* traj_center, void* traj_quat, double* e_trace,
                         mythos_stream_t stream) {
@@ -1274,27 +1395,55 @@ int mythos_langevin_run(mythos_sim_t* s, void* center, void* quat, void* p_lin, 
     set_error("mythos_langevin_run: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  mythos_system* sys = s->sys;
-  if (!sys->params_set || (!sys->nbrs_set && s->rebuild_every <= 0)) {
-    set_error("mythos_langevin_run: parameters and neighbours (or a neighbour policy) must be set first");
+  if (int rc = md_ready(s, "mythos_langevin_run")) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = md_load(s, center, quat, p_lin, p_ang, st)) return rc;
+  const int rc = md_advance(s, n_steps, save_every, traj_center, traj_quat, e_trace, st);
+  // the state of the last valid step goes back to the caller whatever the run reported
+  if (int rs = md_store(s, center, quat, p_lin, p_ang, st)) return rc ? rc : rs;
+  return rc;
+}
+
+int mythos_langevin_load(mythos_sim_t* s, const void* center, const void* quat, const void* p_lin, const void* p_ang,
+                         mythos_stream_t stream) {
+  if (!s || !center || !quat || !p_lin || !p_ang) {
+    set_error("mythos_langevin_load: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->sys->params_set) {
+    set_error("mythos_langevin_load: parameters must be set first");
     return MYTHOS_ERR_NOT_READY;
   }
-  MYTHOS_HIP_TRY(hipSetDevice(sys->device));
-  if (s->rebuild_every > 0 && sys->row_stride == 0)
-    if (int rc = rows_reserve(sys, 64)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  if (sys->dtype == MYTHOS_F32) {
-    if (sys->model == 1)
-      return run_typed<float, 1>(s, (float*)center, (float*)quat, (float*)p_lin, (float*)p_ang, n_steps, save_every,
-                                 (float*)traj_center, (float*)traj_quat, e_trace, st);
-    return run_typed<float, 2>(s, (float*)center, (float*)quat, (float*)p_lin, (float*)p_ang, n_steps, save_every,
-                               (float*)traj_center, (float*)traj_quat, e_trace, st);
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  return md_load(s, (void*)center, (void*)quat, (void*)p_lin, (void*)p_ang, (hipStream_t)stream);
+}
+
+int mythos_langevin_advance(mythos_sim_t* s, int n_steps, int save_every, void* traj_center, void* traj_quat,
+                            double* e_trace, mythos_stream_t stream) {
+  if (!s || n_steps < 0 || save_every < 0) {
+    set_error("mythos_langevin_advance: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (sys->model == 1)
-    return run_typed<double, 1>(s, (double*)center, (double*)quat, (double*)p_lin, (double*)p_ang, n_steps,
-                                save_every, (double*)traj_center, (double*)traj_quat, e_trace, st);
-  return run_typed<double, 2>(s, (double*)center, (double*)quat, (double*)p_lin, (double*)p_ang, n_steps, save_every,
-                              (double*)traj_center, (double*)traj_quat, e_trace, st);
+  if (!s->resident) {
+    set_error("mythos_langevin_advance: no resident state (call mythos_langevin_load first; a run that ended in a numeric "
+              "error drops its state)");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  if (int rc = md_ready(s, "mythos_langevin_advance")) return rc;
+  return md_advance(s, n_steps, save_every, traj_center, traj_quat, e_trace, (hipStream_t)stream);
+}
+
+int mythos_langevin_store(mythos_sim_t* s, void* center, void* quat, void* p_lin, void* p_ang, mythos_stream_t stream) {
+  if (!s || !center || !quat || !p_lin || !p_ang) {
+    set_error("mythos_langevin_store: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->resident) {
+    set_error("mythos_langevin_store: no resident state");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  return md_store(s, center, quat, p_lin, p_ang, (hipStream_t)stream);
 }
 
 int64_t mythos_langevin_get_step(const mythos_sim_t* s) { return s ? s->step : -1; }

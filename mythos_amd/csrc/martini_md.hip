@@ -89,7 +89,11 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   // integration, before which nothing is written to global memory.
   __shared__ int s_halt;
   int halt_word = 0;
-  if (threadIdx.x == 0) halt_word = flags[1] | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
+  // the word holds the index of the first launch that must not run: late workgroups of the launch that set it go on
+  if (threadIdx.x == 0) {
+    const int hw = flags[1];
+    halt_word = ((hw != 0 && hw <= k_index) ? 1 : 0) | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
+  }
 
   const int tt = K.n_types * K.n_types;
   for (int k = threadIdx.x; k < tt; k += kMmBlock) {
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       }
       if (K.skin_half_sq > R(0)) {
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
-        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicOr(flags + 1, 1);  // stale for the NEXT forces: halt before them
+        if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicMax(flags + 1, k_index + 1);  // stale for the NEXT forces: launch k + 1 halts
       }
       if (!(x[0] == x[0]) || !(v[0] == v[0])) atomicOr(flags, 2);
     }

@@ -60,6 +60,7 @@ struct mythos_system {
   int row_stride = 0;
   size_t rows_cap = 0;  // allocated ints in d_rows
   bool nbrs_set = false;
+  int list_epoch = 0;  // bumped when parameters or rows are replaced through the ABI (integrators re-validate their list)
   // host copy of the bonded partners, [n][2]
   std::vector<int> h_partners;
   bool extra_bonds = false;  // some nucleotide uses slot 2 or 3 (circular strands)

@@ -217,6 +217,36 @@ class LangevinIntegrator:
         )
         return tc, tq, et
 
+    # ---- resident form: the state stays in the integrator's layout on the device between calls ----------
+    def _state_ptrs(self, center, quat, p_lin, p_ang):
+        s = self.system
+        for t, tail, name in ((center, (s.n, 3), "center"), (quat, (s.n, 4), "quat"), (p_lin, (s.n, 3), "p_lin"), (p_ang, (s.n, 3), "p_ang")):
+            if s._check(t, tail, name).data_ptr() != t.data_ptr():
+                raise ValueError(f"{name} must be contiguous")
+        return _lib.ptr(center), _lib.ptr(quat), _lib.ptr(p_lin), _lib.ptr(p_ang)
+
+    def load(self, center, quat, p_lin, p_ang) -> None:
+        """Copy a state into the integrator (mythos_langevin_load); ``advance`` then steps it in place."""
+        _lib.check(self._lib.mythos_langevin_load(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device)), "langevin_load")
+
+    def advance(self, n_steps: int, save_every: int = 0, want_energy: bool = True):
+        """``n_steps`` on the resident state; the neighbour list and its rebuild schedule carry over between calls.
+        Returns (traj_center, traj_quat, e_trace) or Nones when save_every == 0."""
+        s = self.system
+        n_save = n_steps // save_every if save_every > 0 else 0
+        tc = torch.empty((n_save, s.n, 3), dtype=s.dtype, device=s.device) if n_save else None
+        tq = torch.empty((n_save, s.n, 4), dtype=s.dtype, device=s.device) if n_save else None
+        et = torch.zeros((n_save, TRACE_WIDTH), dtype=torch.float64, device=s.device) if (n_save and want_energy) else None
+        _lib.check(
+            self._lib.mythos_langevin_advance(self._h, int(n_steps), int(save_every), _lib.ptr(tc), _lib.ptr(tq), _lib.ptr(et), _stream(s.device)),
+            "langevin_advance",
+        )
+        return tc, tq, et
+
+    def store(self, center, quat, p_lin, p_ang) -> None:
+        """Copy the resident state out (mythos_langevin_store, asynchronous on the current stream)."""
+        _lib.check(self._lib.mythos_langevin_store(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device)), "langevin_store")
+
     @property
     def step(self) -> int:
         return int(self._lib.mythos_langevin_get_step(self._h))
