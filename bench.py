@@ -20,8 +20,9 @@ Rank 0 prints ONE JSON line with the fields of the driver contract plus
                 measured with HIP events on the launch stream inside the timed region.  ``traffic`` is the
                 PMC-measured HBM-side byte count per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)
                 of the SAME command, read from profiles/traffic.json when that file matches the workload.
-  cpu_baseline  the CPU oracle (torch fp64 restatement over the same Verlet list, all host cores) timed on a
-                bounded sample of the same system (N=1, rank 0 only)
+  cpu_baseline  the C++/OpenMP port of the same kernels (oracle/cpu_port, fp64, all host cores; median of 5 x 1 000
+                steps) and, under ``torch_restatement``, the vectorised torch-fp64 oracle that stands in for JAX-CPU,
+                both on a bounded sample of the same system (N=1, rank 0 only)
 """
 
 from __future__ import annotations
@@ -184,6 +185,39 @@ def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray, budget_s: fl
         "sample": f"{n_steps} Langevin steps of the same {top.n_nucleotides}-nt system, torch-fp64 oracle over the "
         f"same Verlet pair list ({len(pairs)} pairs), {dt:.1f} s",
     }
+
+
+def cpu_baseline_openmp(top, c0, q0, sim, flat, n_steps: int = 1000, repeats: int = 5, warmup: int = 100) -> dict:
+    """The C++/OpenMP port (oracle/cpu_port: the same pair-physics templates as the HIP kernels compiled for the host,
+    fp64, Verlet list rebuilt on the bench's schedule): ``warmup`` steps, then the median of ``repeats`` timings of
+    ``n_steps`` steps each (at least 1 000 steps, median of 5), continuing one trajectory."""
+    from oracle import cpu_port
+
+    cores = host_cores()
+    cpu_port.set_threads(cores)
+    port = cpu_port.CpuPort(2, top.seq, top.is_end, top.bonded_neighbors, flat.detach().numpy())
+    kT = sim["kT"]
+    kw = dict(dt=sim["dt"], kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"], mass=sim["nucleotide_mass"],
+              inertia=sim["moment_of_inertia"], seed=0, r_cut=R_CUT, skin=0.6, rebuild_every=25)
+    x, q = c0.copy(), q0.copy()
+    p, L = np.zeros_like(x), np.zeros_like(x)
+    t0 = time.perf_counter()
+    port.run(x, q, p, L, warmup, step0=0, **kw)
+    est = (time.perf_counter() - t0) / warmup
+    n_steps = int(max(50, min(n_steps, 6.0 / max(est, 1e-9))))  # about 30 s for the five repeats at most
+    print(f"[bench] cpu baseline (C++/OpenMP port): {repeats} x {n_steps} steps, about {est * n_steps * repeats:.0f} s on {cores} threads",
+          file=sys.stderr, flush=True)
+    rates, done = [], warmup
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        port.run(x, q, p, L, n_steps, step0=done, **kw)
+        rates.append(n_steps / (time.perf_counter() - t0))
+        done += n_steps
+    assert np.isfinite(x).all()
+    return {"value": float(np.median(rates)), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"C++/OpenMP port of the same kernels (oracle/cpu_port), fp64, median of {repeats} x {n_steps} Langevin steps after "
+                      f"{warmup} warm-up steps of the same {top.n_nucleotides}-nt system, Verlet list r_cut {R_CUT} + skin 0.6 rebuilt "
+                      f"every 25 steps; all {repeats} rates: " + ", ".join(f"{r:.1f}" for r in rates)}
 
 
 def martini_main(args):
@@ -414,8 +448,11 @@ def main():
         if cpu_steps > 0 and world == 1:
             from mythos_amd.simulators.neighbors import verlet_pairs_numpy
 
+            # two CPU numbers: the C++/OpenMP port (the value: the faster, fairer baseline) and, as in round 1, the
+            # vectorised torch-fp64 restatement that stands in for JAX-CPU (JAX is not installable offline)
+            out["cpu_baseline"] = cpu_baseline_openmp(top, c0, q0, sim, flat)
             pairs = verlet_pairs_numpy(c0, top.bonded_neighbors, R_CUT + 0.1)
-            out["cpu_baseline"] = cpu_baseline(top, c0, q0, sim, cpu_steps, pairs)
+            out["cpu_baseline"]["torch_restatement"] = cpu_baseline(top, c0, q0, sim, min(cpu_steps, 30), pairs, budget_s=8.0)
             out["config"]["dU_dtheta_vs_cpu"] = param_gradient_error(dev)
         else:
             out["cpu_baseline"] = None

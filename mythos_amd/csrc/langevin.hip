@@ -790,7 +790,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     if constexpr (kHiLo<R>) out.pl[i] = V4{xl[0], xl[1], xl[2], R(0)};
     out.p1[i] = V4{n1.x, n1.y, n1.z, R(0)};
     out.p2[i] = V4{n3.x, n3.y, n3.z, R(0)};
-    out.p3[i] = V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)};
+    // (a closing-only launch hands the frame on unchanged, bit for bit: the offset is copied, not re-derived from
+    // axes whose cross product may round differently - advance(a); advance(b) then equals advance(a + b) exactly)
+    out.p3[i] = do_step ? V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)} : in.p3[i];
     out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
     mom[i] = V4{p[0], p[1], p[2], R(0)};
     ang[i] = V4{L[0], L[1], L[2], R(0)};

@@ -16,6 +16,8 @@ the host applies d(flat)/d(theta), see flat_params.py).  There is no CPU fallbac
 
 from __future__ import annotations
 
+import hashlib
+
 import dataclasses as dc
 from abc import ABC, abstractmethod
 from typing import Any, Callable
@@ -144,7 +146,8 @@ def _get_system(model, seq, is_end, bonded, unbonded, box, dtype, device):
             _SYSTEMS.pop(next(iter(_SYSTEMS)))
     if unbonded is not None:
         pairs = _pairs_2xP(unbonded, seq.shape[0])
-        tag = (pairs.shape, pairs.tobytes() if pairs.size < 4_000_000 else id(unbonded))
+        # content, never identity: ids are reused after garbage collection and arrays are mutated in place
+        tag = (pairs.shape, pairs.tobytes() if pairs.size < 65_536 else hashlib.blake2b(pairs.data, digest_size=16).digest())
         if entry["pairs"] != tag:
             entry["sys"].set_neighbors(pairs)
             entry["pairs"] = tag

@@ -58,33 +58,46 @@ def compute_loss_and_grad(opt_params: dict, energy_fn, beta, loss_fn, ref_states
 # ------------------------------------------------------------------------------------------------
 # replica-sharded reweighting: every rank holds the frames of its own replicas
 # ------------------------------------------------------------------------------------------------
+def _reduce(t, op, group):
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def distributed_weights_and_neff(beta, new_energies, ref_energies, group=None):
     """Globally normalised weights of THIS rank's frames and the global n_eff.
 
     Two collectives: all-reduce(MAX) of the exponent for a stable softmax, then
     all-reduce(SUM) of [sum exp, sum exp * x, count] from which Z and the entropy follow.
+
+    The weights come back DETACHED: their normaliser was all-reduced, so autograd through them would see the
+    numerator only and silently drop the -<O><g> term of the DiffTRe gradient.  Gradients of reweighted means across
+    ranks come from ``distributed_reweighted_mean_and_grad`` / ``distributed_compute_loss_and_grad`` (closed form,
+    every sum all-reduced before the means are combined).
     """
     import torch.distributed as dist
 
-    x = -torch.as_tensor(beta, dtype=torch.float64, device=new_energies.device) * (
-        new_energies.to(torch.float64) - torch.as_tensor(ref_energies, dtype=torch.float64, device=new_energies.device)
-    )
-    m = x.max().detach().reshape(1) if x.numel() else torch.full((1,), -float("inf"), dtype=torch.float64, device=x.device)
-    if dist.is_initialized():
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=group)
-    ex = torch.exp(x - m)
-    sums = torch.stack([ex.sum().detach(), (ex * (x - m)).sum().detach(), torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
-    if dist.is_initialized():
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
-    z, sx, n = sums[0], sums[1], sums[2]
-    weights = ex / z
-    entropy = torch.log(z) - sx / z  # -sum w ln w over ALL frames
-    return weights, torch.exp(entropy) / n
+    with torch.no_grad():
+        x = -torch.as_tensor(beta, dtype=torch.float64, device=new_energies.device) * (
+            new_energies.to(torch.float64) - torch.as_tensor(ref_energies, dtype=torch.float64, device=new_energies.device)
+        )
+        m = x.max().reshape(1) if x.numel() else torch.full((1,), -float("inf"), dtype=torch.float64, device=x.device)
+        _reduce(m, dist.ReduceOp.MAX, group)
+        ex = torch.exp(x - m)
+        sums = torch.stack([ex.sum(), (ex * (x - m)).sum(), torch.tensor(float(x.numel()), dtype=torch.float64, device=x.device)])
+        _reduce(sums, dist.ReduceOp.SUM, group)
+        z, sx, n = sums[0], sums[1], sums[2]
+        weights = ex / z
+        entropy = torch.log(z) - sx / z  # -sum w ln w over ALL frames
+        return weights, torch.exp(entropy) / n
 
 
 def reweighted_mean_and_grad(observable, energies_grad, weights, beta):
     """<O>_w and d<O>_w/dtheta = -beta ( <O g>_w - <O>_w <g>_w ) for per-frame dU/dtheta rows g (S, K)
-    (closed form of the DiffTRe gradient, SURVEY.md section 8a last row)."""
+    (closed form of the DiffTRe gradient, SURVEY.md section 8a last row).  ``weights`` must be normalised over the
+    frames passed in: this is the single-process form (see ``distributed_reweighted_mean_and_grad`` across ranks)."""
     w = weights.to(torch.float64)
     o = observable.to(torch.float64)
     g = energies_grad.to(torch.float64)
@@ -93,6 +106,71 @@ def reweighted_mean_and_grad(observable, energies_grad, weights, beta):
     mean_og = ((w * o)[:, None] * g).sum(0)
     b = torch.as_tensor(beta, dtype=torch.float64, device=w.device)
     return mean_o, -b * (mean_og - mean_o * mean_g)
+
+
+def distributed_reweighted_mean_and_grad(observable, weighted_grad_fn, beta, new_energies, ref_energies, group=None):
+    """<O>_w, d<O>_w/dtheta and n_eff over the frames of ALL ranks.
+
+    ``observable`` (S_local,), ``new_energies`` / ``ref_energies`` (S_local,), ``beta`` scalar or (S_local,);
+    ``weighted_grad_fn(c)`` returns sum_s c_s dU(x_s)/dtheta as a (K,) tensor for per-frame coefficients c (one
+    vector-Jacobian product over this rank's frames: the HIP kernel's dU/dtheta rows times c).
+    Collectives: all-reduce(MAX) of the softmax exponent, then ONE all-reduce(SUM) of
+    [sum w~, sum w~ O, sum w~ ln w~, count, sum w~ beta g (K), sum w~ O beta g (K)]  (SURVEY.md 8e), w~ = exp(x - max).
+    Means are formed only after the reduction:  d<O>/dtheta = -( <O beta g> - <O> <beta g> ).
+    """
+    import torch.distributed as dist
+
+    with torch.no_grad():
+        dev = new_energies.device
+        b = torch.as_tensor(beta, dtype=torch.float64, device=dev).expand(new_energies.shape)
+        x = -b * (new_energies.to(torch.float64) - torch.as_tensor(ref_energies, dtype=torch.float64, device=dev))
+        m = x.max().reshape(1) if x.numel() else torch.full((1,), -float("inf"), dtype=torch.float64, device=dev)
+        _reduce(m, dist.ReduceOp.MAX, group)
+        wt = torch.exp(x - m)
+        o = observable.to(torch.float64).to(dev)
+    g1 = weighted_grad_fn(wt * b).detach().to(torch.float64).reshape(-1)
+    g2 = weighted_grad_fn(wt * b * o).detach().to(torch.float64).reshape(-1)
+    with torch.no_grad():
+        k = g1.numel()
+        head = torch.stack([wt.sum(), (wt * o).sum(), (wt * (x - m)).sum(), torch.tensor(float(x.numel()), dtype=torch.float64, device=dev)])
+        buf = torch.cat([head, g1.to(dev), g2.to(dev)])
+        _reduce(buf, dist.ReduceOp.SUM, group)
+        z, so, sx, n = buf[0], buf[1], buf[2], buf[3]
+        mean_o = so / z
+        mean_g = buf[4 : 4 + k] / z
+        mean_og = buf[4 + k : 4 + 2 * k] / z
+        neff = torch.exp(torch.log(z) - sx / z) / n
+        return mean_o, -(mean_og - mean_o * mean_g), neff
+
+
+def distributed_compute_loss_and_grad(opt_params: dict, energy_fn, beta, observable_fn: Callable, loss_of_mean: Callable,
+                                      ref_states, ref_energies, group=None):
+    """The multi-rank counterpart of ``compute_loss_and_grad`` for losses of ONE reweighted mean, L(<O>_w): every rank
+    passes the stored frames of its own replicas (replica r lives on rank r mod world, mythos_amd.distributed), the
+    result - loss, gradients, n_eff, <O>_w - is identical on all ranks and equal to the single-process value on the
+    concatenated frames.  Replaces the gather of whole trajectories into one objective task that the reference does
+    through Ray's object store (mythos/optimization/optimization.py:151-169, 225-247, objective.py:277-389).
+
+    ``observable_fn(ref_states) -> (S_local,)``; ``loss_of_mean(mean) -> scalar`` differentiable torch function.
+    Returns ((loss, (neff, mean_o, new_energies_local)), grads) like ``compute_loss_and_grad``.
+    """
+    names = list(opt_params)
+    leaves = {k: torch.as_tensor(opt_params[k], dtype=torch.float64).detach().clone().requires_grad_(True) for k in names}
+    new_energies = energy_fn.with_params(leaves).map(ref_states)
+
+    def weighted_grad(c):
+        gs = torch.autograd.grad(new_energies, [leaves[k] for k in names], grad_outputs=c.to(new_energies), retain_graph=True,
+                                 allow_unused=True)
+        return torch.stack([torch.zeros((), dtype=torch.float64, device=new_energies.device) if g is None else g.to(new_energies.device).reshape(())
+                            for g in gs])
+
+    obs = observable_fn(ref_states).detach()
+    mean_o, dmean, neff = distributed_reweighted_mean_and_grad(obs, weighted_grad, beta, new_energies.detach(), ref_energies, group)
+    mean_leaf = mean_o.detach().clone().requires_grad_(True)
+    loss = loss_of_mean(mean_leaf)
+    (dl,) = torch.autograd.grad(loss, [mean_leaf])
+    grads = {k: (dl * dmean[i]).detach() for i, k in enumerate(names)}
+    return (loss.detach(), (neff, mean_o, new_energies.detach())), grads
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,0 +1,397 @@
+// C++/OpenMP port of the oxDNA force evaluation + rigid-body Langevin step  --  TEST INFRASTRUCTURE ONLY.
+//
+// What it is for:
+//   * bench.py's cpu_baseline leg: the second, faster CPU number next to the torch-fp64 oracle ("kind": "port");
+//   * a host build of the SAME pair-physics templates the HIP kernels instantiate (mythos_amd/csrc/oxdna_math.h,
+//     oxdna_pair.h, philox.h) that AddressSanitizer / UBSan can run (the GPU pool has no sanitizer runs);
+//   * a third implementation of the stepping loop for the parity tests (tests/test_cpu_port.py holds it to
+//     oracle/oxdna_oracle.py and oracle/langevin_oracle.py, which are pinned to the reference's golden files).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may load it; nothing under mythos_amd/ does.
+//
+// Algorithm (the reference's, restated): energy terms as mythos/energy/dna1/*.py, dna2/*.py evaluate them over the
+// bonded pairs (nn_i, nn_j) and the unbonded pairs (op_i < op_j); BAOAB Langevin step on rigid bodies as
+// jax_md.simulate.nvt_langevin is driven by mythos/simulators/jax_md/jaxmd.py:73-94 (see oracle/langevin_oracle.py
+// for the restatement this follows line by line).  Arithmetic: fp64, as the reference (jax_enable_x64).
+// Decomposition: one nucleotide per loop iteration gathers its own row (every pair is visited from both ends with
+// weight 1/2, as on the GPU: no scatter, no atomics, results independent of the thread count); OpenMP over nucleotides.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include <omp.h>
+
+#include "oxdna_pair.h"
+#include "philox.h"
+
+using namespace mythos;
+
+namespace {
+
+constexpr int kRoleQ = 1 << 30;
+constexpr int kIndexMask = kRoleQ - 1;
+
+struct Sys {
+  int model = 2, n = 0;
+  bool has_box = false;
+  double box[3] = {0, 0, 0};
+  OxParams<double> P;
+  std::vector<int> meta;      // seq | is_end << 2
+  std::vector<int> partners;  // [n][4], slot parity = role (odd: self is nn_i)
+  std::vector<int> row_ptr, row;  // CSR of unbonded neighbours, entry = j | kRoleQ if self is op_j
+  std::vector<double> ref;    // centres the list was built from
+  std::vector<int> bonded_key;  // sorted (min * n + max) of bonded pairs, for exclusion
+};
+
+inline V3<double> min_image(V3<double> d, const Sys& s) {
+  if (s.has_box) {
+    d.x -= s.box[0] * std::rint(d.x / s.box[0]);
+    d.y -= s.box[1] * std::rint(d.y / s.box[1]);
+    d.z -= s.box[2] * std::rint(d.z / s.box[2]);
+  }
+  return d;
+}
+
+inline Nuc<double> load(const Sys& s, const double* c, const double* q, int j) {
+  Nuc<double> o;
+  o.c = {c[3 * j], c[3 * j + 1], c[3 * j + 2]};
+  quat_axes(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3], o.a1, o.a2, o.a3);
+  o.seq = s.meta[j] & 3;
+  o.is_end = (s.meta[j] >> 2) & 1;
+  return o;
+}
+
+// energy terms (8, summed over threads in a fixed order), and per nucleotide dU/dcentre + axis gradients
+template <int MODEL>
+void forces(const Sys& s, const double* c, const double* q, double* e_terms, double* dc, double* g_axes) {
+  const int n = s.n;
+  const int nt = omp_get_max_threads();
+  std::vector<double> e_thr((size_t)nt * T_COUNT, 0.0);
+  std::vector<Nuc<double>> nuc((size_t)n);  // axes once per evaluation, not once per neighbour visit
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) nuc[i] = load(s, c, q, i);
+#pragma omp parallel
+  {
+    double* et = e_thr.data() + (size_t)omp_get_thread_num() * T_COUNT;
+    NoPG pg;
+#pragma omp for schedule(static)
+    for (int i = 0; i < n; ++i) {
+      const Nuc<double>& self = nuc[i];
+      SelfGrad<double> sg;
+      sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<double>{0, 0, 0};
+      double e[T_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < 4; ++k) {
+        const int j = s.partners[4 * i + k];
+        if (j < 0) continue;
+        const Nuc<double>& o = nuc[j];
+        bonded_pair<double, MODEL, true, NoPG>(s.P, self, o, min_image(o.c - self.c, s), (k & 1) == 1, 0.5, e, sg, pg);
+      }
+      for (int t = s.row_ptr[i]; t < s.row_ptr[i + 1]; ++t) {
+        const int entry = s.row[t];
+        const Nuc<double>& o = nuc[entry & kIndexMask];
+        unbonded_pair<double, MODEL, true, NoPG>(s.P, self, o, min_image(o.c - self.c, s), (entry & kRoleQ) == 0, 0.5, e, sg, pg);
+      }
+      for (int k = 0; k < T_COUNT; ++k) et[k] += e[k];
+      dc[3 * i] = sg.dc.x, dc[3 * i + 1] = sg.dc.y, dc[3 * i + 2] = sg.dc.z;
+      double* g = g_axes + 9 * (size_t)i;
+      g[0] = sg.g1.x, g[1] = sg.g1.y, g[2] = sg.g1.z, g[3] = sg.g2.x, g[4] = sg.g2.y, g[5] = sg.g2.z;
+      g[6] = sg.g3.x, g[7] = sg.g3.y, g[8] = sg.g3.z;
+    }
+  }
+  for (int k = 0; k < T_COUNT; ++k) {
+    double t = 0;
+    for (int r = 0; r < nt; ++r) t += e_thr[(size_t)r * T_COUNT + k];
+    e_terms[k] = t;
+  }
+}
+
+void forces(const Sys& s, const double* c, const double* q, double* e, double* dc, double* g) {
+  if (s.model == 1) forces<1>(s, c, q, e, dc, g); else forces<2>(s, c, q, e, dc, g);
+}
+
+// body-frame torque from the axis gradients: lab torque -sum_k a_k x dU/da_k, projected on the axes
+inline void body_torque(const double* q4, const double* g, double* tb) {
+  V3<double> a1, a2, a3;
+  quat_axes(q4[0], q4[1], q4[2], q4[3], a1, a2, a3);
+  const V3<double> g1{g[0], g[1], g[2]}, g2{g[3], g[4], g[5]}, g3{g[6], g[7], g[8]};
+  const V3<double> t = -(cross(a1, g1) + cross(a2, g2) + cross(a3, g3));
+  tb[0] = dot(a1, t), tb[1] = dot(a2, t), tb[2] = dot(a3, t);
+}
+
+// dU/dq (4) from the axis gradients; a_k(q) as in mythos/energy/utils.py:18-36
+inline void quat_grad(const double* q, const double* g, double* dq) {
+  const double q0 = 2 * q[0], q1 = 2 * q[1], q2 = 2 * q[2], q3 = 2 * q[3];
+  dq[0] = (q0 * g[0] + q3 * g[1] - q2 * g[2]) + (-q3 * g[3] + q0 * g[4] + q1 * g[5]) + (q2 * g[6] - q1 * g[7] + q0 * g[8]);
+  dq[1] = (q1 * g[0] + q2 * g[1] + q3 * g[2]) + (q2 * g[3] - q1 * g[4] + q0 * g[5]) + (q3 * g[6] - q0 * g[7] - q1 * g[8]);
+  dq[2] = (-q2 * g[0] + q1 * g[1] - q0 * g[2]) + (q1 * g[3] + q2 * g[4] + q3 * g[5]) + (q0 * g[6] + q3 * g[7] - q2 * g[8]);
+  dq[3] = (-q3 * g[0] + q0 * g[1] + q1 * g[2]) + (-q0 * g[3] - q3 * g[4] + q2 * g[5]) + (q1 * g[6] + q2 * g[7] + q3 * g[8]);
+}
+
+// Verlet list from a cell grid (free space: cells hashed by their integer coordinates; periodic: direct grid).
+// Rows are sorted by neighbour index so that the result does not depend on the thread count.
+void build_rows(Sys& s, const double* c, double r_list) {
+  const int n = s.n;
+  const double inv = 1.0 / r_list;
+  int nc[3] = {0, 0, 0};
+  bool direct = s.has_box;
+  if (direct)
+    for (int k = 0; k < 3; ++k) {
+      nc[k] = (int)std::floor(s.box[k] / r_list);
+      if (nc[k] < 3) direct = false;
+    }
+  const bool brute = s.has_box && !direct;  // box under three cells: all pairs with the minimum image
+  const int H = 1 << (int)std::ceil(std::log2(std::max(2 * n, 16)));
+  auto cell_of = [&](const double* x, int* ic) {
+    for (int k = 0; k < 3; ++k) {
+      if (direct) {
+        double f = x[k] / s.box[k];
+        f -= std::floor(f);
+        ic[k] = std::min(nc[k] - 1, (int)(f * nc[k]));
+      } else {
+        ic[k] = (int)std::floor(x[k] * inv);
+      }
+    }
+  };
+  auto slot = [&](const int* ic) -> int {
+    if (direct) return (ic[0] * nc[1] + ic[1]) * nc[2] + ic[2];
+    const uint32_t h = (uint32_t)ic[0] * 73856093u ^ (uint32_t)ic[1] * 19349663u ^ (uint32_t)ic[2] * 83492791u;
+    return (int)(h & (uint32_t)(H - 1));
+  };
+  const int n_slots = direct ? nc[0] * nc[1] * nc[2] : H;
+  std::vector<int> head((size_t)n_slots + 1, 0), order(n), cell(3 * (size_t)n);
+  if (!brute) {
+    for (int i = 0; i < n; ++i) {
+      cell_of(c + 3 * i, &cell[3 * (size_t)i]);
+      ++head[slot(&cell[3 * (size_t)i]) + 1];
+    }
+    for (int h = 0; h < n_slots; ++h) head[h + 1] += head[h];
+    std::vector<int> fill(head.begin(), head.end() - 1);
+    for (int i = 0; i < n; ++i) order[fill[slot(&cell[3 * (size_t)i])]++] = i;
+  }
+  const double r2 = r_list * r_list;
+  std::vector<std::vector<int>> rows(n);
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < n; ++i) {
+    std::vector<int>& out = rows[i];
+    const V3<double> ci{c[3 * i], c[3 * i + 1], c[3 * i + 2]};
+    auto consider = [&](int j) {
+      if (j == i) return;
+      const V3<double> d = min_image(V3<double>{c[3 * j] - ci.x, c[3 * j + 1] - ci.y, c[3 * j + 2] - ci.z}, s);
+      if (dot(d, d) >= r2) return;
+      for (int k = 0; k < 4; ++k)
+        if (s.partners[4 * i + k] == j) return;
+      out.push_back(j < i ? (j | kRoleQ) : j);
+    };
+    if (brute) {
+      for (int j = 0; j < n; ++j) consider(j);
+    } else {
+      int seen[27], n_seen = 0;
+      for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dz = -1; dz <= 1; ++dz) {
+            int ic[3] = {cell[3 * (size_t)i] + dx, cell[3 * (size_t)i + 1] + dy, cell[3 * (size_t)i + 2] + dz};
+            if (direct)
+              for (int k = 0; k < 3; ++k) ic[k] = (ic[k] + nc[k]) % nc[k];
+            const int h = slot(ic);
+            bool dup = false;
+            for (int t = 0; t < n_seen; ++t) dup = dup || seen[t] == h;
+            if (dup) continue;  // hash collision between two of the 27 cells (or a wrapped grid of three)
+            seen[n_seen++] = h;
+            for (int t = head[h]; t < head[h + 1]; ++t) {
+              const int j = order[t];
+              if (!direct) {  // a hashed slot holds other cells too: keep only candidates of a cell in the 27
+                const int* jc = &cell[3 * (size_t)j];
+                if (std::abs(jc[0] - cell[3 * (size_t)i]) > 1 || std::abs(jc[1] - cell[3 * (size_t)i + 1]) > 1 ||
+                    std::abs(jc[2] - cell[3 * (size_t)i + 2]) > 1)
+                  continue;
+              }
+              consider(j);
+            }
+          }
+    }
+    std::sort(out.begin(), out.end(), [](int a, int b) { return (a & kIndexMask) < (b & kIndexMask); });
+  }
+  s.row_ptr.assign((size_t)n + 1, 0);
+  for (int i = 0; i < n; ++i) s.row_ptr[i + 1] = s.row_ptr[i] + (int)rows[i].size();
+  s.row.resize((size_t)s.row_ptr[n]);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) std::copy(rows[i].begin(), rows[i].end(), s.row.begin() + s.row_ptr[i]);
+  s.ref.assign(c, c + 3 * (size_t)n);
+}
+
+// one NO_SQUISH factor: rotation about body axis K by phi = h L_K / I_K (oracle/langevin_oracle.py free_rotor)
+template <int K>
+inline void free_rotor(double* q, double* L, double h, const double* inertia) {
+  const double phi = h * L[K] / inertia[K];
+  const double s = std::sin(0.5 * phi), c = std::cos(0.5 * phi);
+  const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+  if (K == 0) {
+    q[0] = c * q0 - s * q1, q[1] = c * q1 + s * q0, q[2] = c * q2 + s * q3, q[3] = c * q3 - s * q2;
+  } else if (K == 1) {
+    q[0] = c * q0 - s * q2, q[1] = c * q1 - s * q3, q[2] = c * q2 + s * q0, q[3] = c * q3 + s * q1;
+  } else {
+    q[0] = c * q0 - s * q3, q[1] = c * q1 + s * q2, q[2] = c * q2 - s * q1, q[3] = c * q3 + s * q0;
+  }
+  const double cf = std::cos(phi), sf = std::sin(phi);
+  constexpr int A = (K + 1) % 3, B = (K + 2) % 3;
+  const double la = L[A], lb = L[B];
+  L[A] = cf * la + sf * lb;
+  L[B] = -sf * la + cf * lb;
+}
+
+inline void drift(double* x, double* q, const double* p, double* L, double h, double mass, const double* inertia) {
+  for (int k = 0; k < 3; ++k) x[k] += h * p[k] / mass;
+  free_rotor<2>(q, L, 0.5 * h, inertia);
+  free_rotor<1>(q, L, 0.5 * h, inertia);
+  free_rotor<0>(q, L, h, inertia);
+  free_rotor<1>(q, L, 0.5 * h, inertia);
+  free_rotor<2>(q, L, 0.5 * h, inertia);
+}
+
+}  // namespace
+
+extern "C" {
+
+void* mythos_cpu_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded, const int32_t* bonded,
+                        const double* box, const double* flat, int n_params) {
+  if (n_params != OXP_COUNT || (model != 1 && model != 2) || n <= 0) return nullptr;
+  Sys* s = new Sys();
+  s->model = model, s->n = n;
+  if (box) s->has_box = true, s->box[0] = box[0], s->box[1] = box[1], s->box[2] = box[2];
+  for (int k = 0; k < OXP_COUNT; ++k) s->P.v[k] = flat[k];
+  s->meta.resize(n);
+  for (int i = 0; i < n; ++i) s->meta[i] = (seq[i] & 3) | ((is_end && is_end[i]) ? 4 : 0);
+  s->partners.assign(4 * (size_t)n, -1);
+  for (int b = 0; b < n_bonded; ++b) {
+    const int i = bonded[2 * b], j = bonded[2 * b + 1];  // (nn_i, nn_j)
+    int* pi = &s->partners[4 * (size_t)i];
+    int* pj = &s->partners[4 * (size_t)j];
+    (pi[1] < 0 ? pi[1] : pi[3]) = j;  // odd slots: self is nn_i
+    (pj[0] < 0 ? pj[0] : pj[2]) = i;  // even slots: self is nn_j
+  }
+  s->row_ptr.assign((size_t)n + 1, 0);
+  return s;
+}
+
+void mythos_cpu_destroy(void* h) { delete (Sys*)h; }
+
+int mythos_cpu_threads(void) { return omp_get_max_threads(); }
+void mythos_cpu_set_threads(int t) { omp_set_num_threads(t > 0 ? t : 1); }
+
+// reference-style pair list: int32[n_pairs][2], rows (op_i, op_j)
+int mythos_cpu_set_pairs(void* h, const int32_t* pairs, int n_pairs) {
+  Sys& s = *(Sys*)h;
+  std::vector<int> cnt((size_t)s.n + 1, 0);
+  for (int k = 0; k < n_pairs; ++k) {
+    const int i = pairs[2 * k], j = pairs[2 * k + 1];
+    if (i < 0 || j < 0 || i >= s.n || j >= s.n) continue;  // padding entries (index n) as the reference's lists carry
+    ++cnt[i + 1], ++cnt[j + 1];
+  }
+  for (int i = 0; i < s.n; ++i) cnt[i + 1] += cnt[i];
+  s.row_ptr = cnt;
+  s.row.assign((size_t)cnt[s.n], 0);
+  std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+  for (int k = 0; k < n_pairs; ++k) {
+    const int i = pairs[2 * k], j = pairs[2 * k + 1];
+    if (i < 0 || j < 0 || i >= s.n || j >= s.n) continue;
+    s.row[fill[i]++] = j;
+    s.row[fill[j]++] = i | kRoleQ;
+  }
+  return 0;
+}
+
+int mythos_cpu_build_pairs(void* h, const double* center, double r_list) {
+  build_rows(*(Sys*)h, center, r_list);
+  return 0;
+}
+
+double mythos_cpu_mean_row(void* h) {
+  const Sys& s = *(Sys*)h;
+  return double(s.row_ptr[s.n]) / s.n;
+}
+
+// e_terms[8]; dU_dcenter[n][3], dU_dquat[n][4], torque_body[n][3] optional
+int mythos_cpu_energy(void* h, const double* center, const double* quat, double* e_terms, double* dU_dcenter,
+                      double* dU_dquat, double* torque_body) {
+  const Sys& s = *(Sys*)h;
+  std::vector<double> dc(3 * (size_t)s.n), g(9 * (size_t)s.n);
+  forces(s, center, quat, e_terms, dc.data(), g.data());
+  if (dU_dcenter) std::copy(dc.begin(), dc.end(), dU_dcenter);
+  for (int i = 0; i < s.n; ++i) {
+    if (dU_dquat) quat_grad(quat + 4 * i, &g[9 * (size_t)i], dU_dquat + 4 * i);
+    if (torque_body) body_torque(quat + 4 * i, &g[9 * (size_t)i], torque_body + 3 * i);
+  }
+  return 0;
+}
+
+// n_steps of BAOAB (oracle/langevin_oracle.py LangevinOracle.run: one force evaluation per step) in place.
+// rebuild_every > 0: Verlet list of range r_cut + skin rebuilt on that schedule and whenever a centre has moved more
+// than skin / 2 since the last build; otherwise the list given by mythos_cpu_set_pairs / _build_pairs is kept.
+// e_last[10]: term energies + kinetic energies of the final state (optional).  Returns the number of list builds.
+int mythos_cpu_langevin_run(void* h, double* c, double* q, double* p, double* L, int n_steps, double dt, double kT,
+                            double gamma_t, double gamma_r, double mass, const double* inertia, uint64_t seed,
+                            int64_t step0, double r_cut, double skin, int rebuild_every, double* e_last) {
+  Sys& s = *(Sys*)h;
+  const int n = s.n;
+  const double hh = 0.5 * dt;
+  const double c1t = std::exp(-gamma_t * dt), c2t = std::sqrt(kT * (1 - c1t * c1t) * mass);
+  const double c1r = std::exp(-gamma_r * dt);
+  const double c2r[3] = {std::sqrt(kT * (1 - c1r * c1r) * inertia[0]), std::sqrt(kT * (1 - c1r * c1r) * inertia[1]),
+                         std::sqrt(kT * (1 - c1r * c1r) * inertia[2])};
+  std::vector<double> dc(3 * (size_t)n), g(9 * (size_t)n);
+  double e[T_COUNT];
+  int builds = 0, since = 0;
+  const bool dynamic = rebuild_every > 0;
+  for (int i = 0; i < n; ++i) {  // unit quaternions on entry, as the device integrator
+    double* qi = q + 4 * i;
+    const double inv = 1.0 / std::sqrt(qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3]);
+    for (int k = 0; k < 4; ++k) qi[k] *= inv;
+  }
+  if (dynamic) build_rows(s, c, r_cut + skin), ++builds;
+  forces(s, c, q, e, dc.data(), g.data());
+  for (int step = 0; step < n_steps; ++step) {
+    int moved = 0;
+#pragma omp parallel for schedule(static) reduction(| : moved)
+    for (int i = 0; i < n; ++i) {
+      double tb[3], z[6];
+      body_torque(q + 4 * i, &g[9 * (size_t)i], tb);
+      double* pi = p + 3 * i;
+      double* Li = L + 3 * i;
+      for (int k = 0; k < 3; ++k) pi[k] -= hh * dc[3 * (size_t)i + k], Li[k] += hh * tb[k];
+      drift(c + 3 * i, q + 4 * i, pi, Li, hh, mass, inertia);
+      normals6<double>(seed, (uint32_t)i, (uint64_t)(step0 + step), 0u, z);
+      for (int k = 0; k < 3; ++k) pi[k] = c1t * pi[k] + c2t * z[k], Li[k] = c1r * Li[k] + c2r[k] * z[3 + k];
+      drift(c + 3 * i, q + 4 * i, pi, Li, hh, mass, inertia);
+      double* qi = q + 4 * i;
+      const double inv = 1.0 / std::sqrt(qi[0] * qi[0] + qi[1] * qi[1] + qi[2] * qi[2] + qi[3] * qi[3]);
+      for (int k = 0; k < 4; ++k) qi[k] *= inv;
+      if (dynamic) {
+        const double dx = c[3 * i] - s.ref[3 * (size_t)i], dy = c[3 * i + 1] - s.ref[3 * (size_t)i + 1], dz = c[3 * i + 2] - s.ref[3 * (size_t)i + 2];
+        moved |= (dx * dx + dy * dy + dz * dz > 0.25 * skin * skin) ? 1 : 0;
+      }
+    }
+    ++since;
+    if (dynamic && (moved || since >= rebuild_every)) build_rows(s, c, r_cut + skin), ++builds, since = 0;
+    forces(s, c, q, e, dc.data(), g.data());
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+      double tb[3];
+      body_torque(q + 4 * i, &g[9 * (size_t)i], tb);
+      for (int k = 0; k < 3; ++k) p[3 * i + k] -= hh * dc[3 * (size_t)i + k], L[3 * i + k] += hh * tb[k];
+    }
+  }
+  if (e_last) {
+    for (int k = 0; k < T_COUNT; ++k) e_last[k] = e[k];
+    double kt = 0, kr = 0;
+    for (int i = 0; i < n; ++i) {
+      kt += 0.5 * (p[3 * i] * p[3 * i] + p[3 * i + 1] * p[3 * i + 1] + p[3 * i + 2] * p[3 * i + 2]) / mass;
+      kr += 0.5 * (L[3 * i] * L[3 * i] / inertia[0] + L[3 * i + 1] * L[3 * i + 1] / inertia[1] + L[3 * i + 2] * L[3 * i + 2] / inertia[2]);
+    }
+    e_last[T_COUNT] = kt, e_last[T_COUNT + 1] = kr;
+  }
+  return builds;
+}
+
+}  // extern "C"

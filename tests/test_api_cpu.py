@@ -111,6 +111,50 @@ assert torch.allclose(w, w_all[mine], rtol=1e-12), (w, w_all[mine])
 assert abs(float(neff) - float(neff_all)) < 1e-12
 s = md.all_reduce_sum(torch.tensor([float(rank + 1)]))
 assert float(s) == 3.0
+assert not w.requires_grad  # the all-reduced normaliser is not in any graph: weights come back detached
+
+# ---- DiffTRe across ranks: the gradient of a loss of a reweighted mean, frames sharded r mod world, equals the
+#      single-process autograd value on all frames (a toy energy stands in for the HIP energy function: the host
+#      logic under test only needs map() to be differentiable in the parameters)
+class ToyEnergy:
+    def __init__(self, f, h, p=None):
+        self.f, self.h, self.p = f, h, p or {}
+    def with_params(self, *ds, **kw):
+        p = dict(self.p)
+        for d in ds:
+            p.update(d)
+        p.update(kw)
+        return ToyEnergy(self.f, self.h, p)
+    def map(self, states):
+        a, b, c = (torch.as_tensor(self.p[k], dtype=torch.float64) for k in ("a", "b", "c"))
+        return a * self.f[states] + b * b * self.h[states] + torch.sin(c) * self.f[states] * self.h[states]
+
+S = 64 * 3  # 64 replicas x 3 stored frames
+g = torch.Generator().manual_seed(11)
+f = torch.randn(S, generator=g, dtype=torch.float64)
+h = torch.randn(S, generator=g, dtype=torch.float64)
+obs_all = torch.randn(S, generator=g, dtype=torch.float64) + 20.0
+temps = torch.where(torch.arange(S) % 2 == 0, 0.09, 0.11).to(torch.float64)  # two temperature segments
+beta_all = 1.0 / temps
+ref_p, new_p = {"a": 0.3, "b": -0.7, "c": 0.2}, {"a": 0.35, "b": -0.66, "c": 0.25}
+ef = ToyEnergy(f, h)
+every = torch.arange(S)
+ref_e_all = ef.with_params(ref_p).map(every)
+target = 20.3
+def loss_fn(ref_states, weights, energy_fn, opt_params, observables):
+    m = (weights * obs_all[ref_states]).sum()
+    return (m - target) ** 2, (("obs", m.detach()), {})
+(l_one, (neff_one, meas, _)), g_one = objective.compute_loss_and_grad(new_p, ef, beta_all, loss_fn, every, ref_e_all, [])
+replicas = md.shard_replicas(64, rank, world)
+mine = torch.cat([torch.arange(3 * r, 3 * r + 3) for r in replicas])
+(l_d, (neff_d, mean_d, e_loc)), g_d = objective.distributed_compute_loss_and_grad(
+    new_p, ef, beta_all[mine], lambda st: obs_all[st], lambda m: (m - target) ** 2, mine, ref_e_all[mine])
+assert abs(float(l_d) - float(l_one)) <= 1e-12 * max(1.0, abs(float(l_one))), (float(l_d), float(l_one))
+assert abs(float(neff_d) - float(neff_one)) <= 1e-12
+assert abs(float(mean_d) - float(meas[1])) <= 1e-12 * abs(float(meas[1]))
+for k in new_p:
+    assert abs(float(g_d[k]) - float(g_one[k])) <= 1e-12 * max(1.0, abs(float(g_one[k]))), (k, float(g_d[k]), float(g_one[k]))
+assert e_loc.shape == mine.shape
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

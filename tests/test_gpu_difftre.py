@@ -117,3 +117,43 @@ def test_simple_optimizer_moves_the_observable_towards_the_target():
     # the reweighted estimate on a fixed trajectory is deterministic: within one trajectory's validity window the
     # loss decreases monotonically under a small Adam step
     assert losses[1] < losses[0]
+
+
+def _run_ranks(extra, nproc=None):
+    """scripts/difftre_ranks.py as child processes (never exec'ed from this GPU-holding process)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    script = str(root / "scripts" / "difftre_ranks.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc is None:
+        cmd = [sys.executable, script, *extra]
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), script, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, check=False)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [json.loads(line) for line in r.stdout.splitlines() if line.startswith("{")]
+
+
+def test_rank_sharded_difftre_equals_the_single_process_gradient():
+    """BASELINE configs[4] through the multi-rank driver: 64 replicas of the 32 bp duplex; frames stay on their rank,
+    4 + 2K doubles are all-reduced, and the gradient equals single-process autograd on the gathered frames (1e-10).
+    One rank, then two ranks sharing this GPU over gloo (the driver's 8-GPU run uses RCCL on the same code path)."""
+    one = _run_ranks(["--replicas", "64", "--steps", "600", "--save-every", "100", "--equilibration-frames", "2",
+                      "--iterations", "2", "--check"])
+    assert len(one) == 2 and one[0]["frames_total"] == 64 * 4 and one[0]["check"]["frames"] == 256
+    assert one[0]["check"]["max_rel_grad_err"] <= 1e-10 and 0.0 < one[0]["neff"] <= 1.0
+    assert any(abs(v) > 0 for v in one[0]["grads"].values())
+    two = _run_ranks(["--replicas", "64", "--steps", "600", "--save-every", "100", "--equilibration-frames", "2",
+                      "--iterations", "2", "--check", "--rehearse-on-one-gpu"], nproc=2)
+    assert len(two) == 2 and two[0]["world"] == 2 and two[0]["replicas_this_rank"] == 32
+    assert two[1]["check"]["max_rel_grad_err"] <= 1e-10 and two[0]["check"]["frames"] == 256
