@@ -481,6 +481,55 @@ def pair_exc_vol_bonded(p, s: Sites, bonded, disp):
     )
 
 
+# base-pair types AT, TA, GC, CG as (nt of member 0, nt of member 1) (mythos/utils/constants.py:13-18)
+BP_IDXS = torch.tensor([[0, 3], [3, 0], [2, 1], [1, 2]], dtype=torch.long)
+
+
+def compute_seq_dep_weight(pseq, nt1, nt2, weights_table, sc):
+    """Expected sequence-dependent weight of the pairs (nt1[k], nt2[k]) under a probabilistic sequence:
+    mythos/energy/utils.py:45-132 case by case (the reference vmaps a scalar function over the pairs; here the pair
+    axis is the leading tensor axis).  ``pseq = (unpaired (n_unpaired, 4), base-pair types (n_bp, 4))``; ``sc`` carries
+    ``is_unpaired``, ``idx_to_unpaired_idx``, ``idx_to_bp_idx``.  Index -1 (a nucleotide that is not of the kind a case
+    assumes) reads the last row, as in jnp; that case is then discarded by the final selection."""
+    up, bp = (torch.as_tensor(a, dtype=torch.float64) for a in pseq)
+    if up.shape[0] == 0:
+        up = torch.zeros((1, 4), dtype=torch.float64)
+    if bp.shape[0] == 0:
+        bp = torch.zeros((1, 4), dtype=torch.float64)
+    table = torch.as_tensor(weights_table, dtype=torch.float64)
+    is_up = torch.as_tensor(sc.is_unpaired).bool()
+    iu = torch.as_tensor(sc.idx_to_unpaired_idx, dtype=torch.long)
+    ib = torch.as_tensor(sc.idx_to_bp_idx, dtype=torch.long)
+    u1, u2 = is_up[nt1], is_up[nt2]
+    p1, p2 = up[iu[nt1]], up[iu[nt2]]                      # (P, 4) nucleotide probabilities if unpaired
+    b1, w1 = bp[ib[nt1, 0]], ib[nt1, 1]                    # (P, 4) base-pair type probabilities, position inside the pair
+    b2, w2 = bp[ib[nt2, 0]], ib[nt2, 1]
+    n1_of_t = BP_IDXS[:, w1].T                             # (P, 4): nucleotide of nt1 for each base-pair type
+    n2_of_t = BP_IDXS[:, w2].T
+    # case 1: both unpaired - kron(p1, p2) . table
+    both_unpaired = torch.einsum("pa,pb,ab->p", p1, p2, table)
+    # case 2: nt1 unpaired, nt2 in a base pair
+    nt1_up = torch.einsum("pa,pt,pat->p", p1, b2, table[:, n2_of_t].permute(1, 0, 2))
+    # case 3: nt2 unpaired, nt1 in a base pair
+    nt2_up = torch.einsum("pb,pt,ptb->p", p2, b1, table[n1_of_t, :])
+    # case 4.I: the two members of one base pair
+    same_bp = (b1 * table[n1_of_t, n2_of_t]).sum(-1)
+    # case 4.II: members of different base pairs
+    diff_bps = torch.einsum("ps,pt,pst->p", b1, b2, table[n1_of_t[:, :, None], n2_of_t[:, None, :]])
+    both_paired = torch.where(ib[nt1, 0] == ib[nt2, 0], same_bp, diff_bps)
+    return torch.where(u1 & u2, both_unpaired, torch.where(u1, nt1_up, torch.where(u2, nt2_up, both_paired)))
+
+
+def _seq_weights(p, table_name, seq, i, j):
+    """Discrete lookup table[seq_i, seq_j], or the expectation under p["pseq"] (dna1/stacking.py:284-287,
+    dna1/hydrogen_bonding.py:330-333)."""
+    if p.get("pseq") is not None:
+        if p.get("pseq_constraints") is None:
+            raise ValueError("pseq_constraints must be provided when pseq is provided.")
+        return compute_seq_dep_weight(p["pseq"], i, j, p[table_name], p["pseq_constraints"])
+    return p[table_name][seq[i], seq[j]]
+
+
 def pair_stacking(p, s: Sites, seq, bonded, disp):
     """dna1/stacking.py:192-289; dna2/stacking.py:19-39 (cos(phi) on the dna1 backbone site)."""
     i, j = bonded[:, 0], bonded[:, 1]
@@ -513,7 +562,7 @@ def pair_stacking(p, s: Sites, seq, bonded, disp):
         * f5(-cosphi1, p["neg_cos_phi1_star_stack"], p["neg_cos_phi1_c_stack"], p["a_stack_1"], p["b_neg_cos_phi1_stack"])
         * f5(-cosphi2, p["neg_cos_phi2_star_stack"], p["neg_cos_phi2_c_stack"], p["a_stack_2"], p["b_neg_cos_phi2_stack"])
     )
-    return p["eps_stack"][seq[i], seq[j]] * v
+    return _seq_weights(p, "eps_stack", seq, i, j) * v
 
 
 def pair_exc_vol_unbonded(p, s: Sites, pairs, disp):
@@ -566,7 +615,7 @@ def pair_hydrogen_bonding(p, s: Sites, seq, pairs, disp):
     )
     for k, th in ((1, t1), (2, t2), (3, t3), (4, t4), (7, t7), (8, t8)):
         v = v * f4(th, p[f"theta0_hb_{k}"], p[f"delta_theta_star_hb_{k}"], p[f"delta_theta_hb_{k}_c"], p[f"a_hb_{k}"], p[f"b_hb_{k}"])
-    return p["eps_hb_weights"][seq[i], seq[j]] * v
+    return _seq_weights(p, "eps_hb_weights", seq, i, j) * v
 
 
 def pair_cross_stacking(p, s: Sites, pairs, disp):
