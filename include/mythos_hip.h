@@ -33,6 +33,7 @@ typedef struct mythos_system mythos_system_t;   /* one oxDNA system: topology + 
 typedef struct mythos_sim mythos_sim_t;         /* Langevin integrator state bound to a system */
 typedef struct mythos_martini mythos_martini_t; /* one MARTINI system */
 typedef struct mythos_martini_sim mythos_martini_sim_t; /* Langevin integrator state bound to a MARTINI system */
+typedef struct mythos_obs mythos_obs_t;         /* a set of per-frame structural observables (index lists on the device) */
 typedef void* mythos_stream_t;                  /* hipStream_t */
 
 enum mythos_status {
@@ -83,6 +84,20 @@ void mythos_oxdna_destroy(mythos_system_t* sys);
 /* host double[n_params] in mythos_oxdna_param_name() order; replaces with_params() at the boundary */
 int mythos_oxdna_set_params(mythos_system_t* sys, const double* flat_params, int n_params);
 
+/* Probabilistic sequence: replaces `pseq` / `pseq_constraints` of StackingConfiguration and
+ * HydrogenBondingConfiguration (mythos/energy/dna1/stacking.py:54-55, 261-287, dna1/hydrogen_bonding.py:94-95, 308-333)
+ * and compute_seq_dep_weight (mythos/energy/utils.py:45-132).  The sequence-dependent weight of a pair becomes its
+ * expectation; the energy entry point (energies, forces, dU/dparams incl. the 4x4 weight tables) honours it.
+ *   marginals  host double[n][4]   probability of A, C, G, T per nucleotide (for a base-paired nucleotide: the marginal
+ *              of its pair's type distribution)
+ *   unit       host int32[n]       2 * base_pair + position_in_pair for constrained base pairs, -1 for unpaired
+ *   bp_probs   host double[n_bp][4] probability of the types AT, TA, GC, CG (mythos/utils/constants.py:13) per base pair
+ *   terms      bit 0: stacking, bit 1: hydrogen bonding use the expectation; 0 switches back to the discrete sequence
+ * The Langevin integrator refuses a system with a probabilistic sequence (MYTHOS_ERR_NOT_READY): dynamics need a
+ * sequence, reweighting a distribution over them. */
+int mythos_oxdna_set_pseq(mythos_system_t* sys, const double* marginals, const int32_t* unit, int n_bp,
+                          const double* bp_probs, int terms);
+
 /* Unbonded pair list, reference semantics (NoNeighborList.idx, simulators/jax_md/utils.py:48-67):
  * host int32[n_pairs][2], rows (op_i, op_j) in that role order.  Converted to per-nucleotide rows. */
 int mythos_oxdna_set_neighbors(mythos_system_t* sys, const int32_t* pairs, int n_pairs);
@@ -106,6 +121,33 @@ int mythos_oxdna_neighbor_stats(mythos_system_t* sys, int* max_row, double* mean
  */
 int mythos_oxdna_energy(mythos_system_t* sys, const void* center, const void* quat, int n_frames, double* e_terms,
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_stream_t stream);
+
+/* ---- per-frame structural observables ------------------------------------------------------------
+ * Replaces mythos/observables/propeller.py:19-71, pitch.py:33-102, rise.py:21-80 and the per-state part of
+ * persistence_length.py:47-91, 168-185 (base.py:24-66 for the local helical axis and the quartets).
+ *   geometry    host double[3]: com_to_hb, backbone offset along a1, backbone offset along a2 (0 for oxDNA1)
+ *   box         host double[3] periodic box of the displacement function, or NULL (free space)
+ *   base_pairs  host int32[n_bp][2]       hydrogen-bonded pairs of the propeller twist
+ *   quartets    host int32[n_q][2][2]     adjacent base pairs ((a1, b1), (a2, b2)) of rise / pitch / persistence length
+ *   skip_ends   drop two quartets at either end in the persistence-length partials (persistence_length.py:84-87)
+ * Output row per frame, mythos_observables_width() = 4 + n_corr doubles (n_corr = n_q - 4 with skip_ends, else n_q):
+ *   [0] propeller twist (deg)  [1] rise (Angstrom)  [2] pitch angle (rad)  [3] mean base-pair spacing <l0>
+ *   [4 + d] autocorrelation C(d) of the local helical axes.   Entries whose list is empty are 0.
+ * mythos_observables_eval is the stand-alone launch; mythos_oxdna_energy_obs evaluates the same rows in the epilogue of
+ * the energy launch (one read of the trajectory for energies, dU/dparams and observables: the DiffTRe data path). */
+mythos_obs_t* mythos_observables_create(int model, int n, const double* geometry, const double* box, int n_bp,
+                                        const int32_t* base_pairs, int n_quartets, const int32_t* quartets, int skip_ends,
+                                        int dtype, int device);
+void mythos_observables_destroy(mythos_obs_t* obs);
+int mythos_observables_width(const mythos_obs_t* obs);
+/* center dev real[n_frames][n][3], quat dev real[n_frames][n][4], out dev double[n_frames][width] */
+int mythos_observables_eval(mythos_obs_t* obs, const void* center, const void* quat, int n_frames, double* out,
+                            mythos_stream_t stream);
+/* mythos_oxdna_energy with observables in the same launch: obs may be NULL (then identical to mythos_oxdna_energy);
+ * obs_out dev double[n_frames][width] */
+int mythos_oxdna_energy_obs(mythos_system_t* sys, const void* center, const void* quat, int n_frames, double* e_terms,
+                            void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_obs_t* obs, double* obs_out,
+                            mythos_stream_t stream);
 
 /* ---- Langevin integrator ----------------------------------------------------------------------
  * Replaces jax_md.simulate.nvt_langevin on RigidBody states as driven by

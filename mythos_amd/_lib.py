@@ -51,10 +51,16 @@ def load() -> C.CDLL:
         "mythos_oxdna_create": (V, [C.c_int, C.c_int, c_int_p, c_uint8_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
         "mythos_oxdna_destroy": (None, [V]),
         "mythos_oxdna_set_params": (C.c_int, [V, c_double_p, C.c_int]),
+        "mythos_oxdna_set_pseq": (C.c_int, [V, c_double_p, c_int_p, C.c_int, c_double_p, C.c_int]),
         "mythos_oxdna_set_neighbors": (C.c_int, [V, c_int_p, C.c_int]),
         "mythos_oxdna_build_neighbors": (C.c_int, [V, V, C.c_double, C.c_double, V]),
         "mythos_oxdna_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
         "mythos_oxdna_energy": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V]),
+        "mythos_oxdna_energy_obs": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V, V, V]),
+        "mythos_observables_create": (V, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, c_int_p, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int]),
+        "mythos_observables_destroy": (None, [V]),
+        "mythos_observables_width": (C.c_int, [V]),
+        "mythos_observables_eval": (C.c_int, [V, V, V, C.c_int, V, V]),
         "mythos_langevin_create": (V, [V, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p, C.c_uint64]),
         "mythos_langevin_destroy": (None, [V]),
         "mythos_langevin_set_neighbor_policy": (C.c_int, [V, C.c_double, C.c_double, C.c_int]),
@@ -105,10 +111,16 @@ DECLARED_SYMBOLS = (
     "mythos_oxdna_create",
     "mythos_oxdna_destroy",
     "mythos_oxdna_set_params",
+    "mythos_oxdna_set_pseq",
     "mythos_oxdna_set_neighbors",
     "mythos_oxdna_build_neighbors",
     "mythos_oxdna_neighbor_stats",
     "mythos_oxdna_energy",
+    "mythos_oxdna_energy_obs",
+    "mythos_observables_create",
+    "mythos_observables_destroy",
+    "mythos_observables_width",
+    "mythos_observables_eval",
     "mythos_langevin_create",
     "mythos_langevin_destroy",
     "mythos_langevin_set_neighbor_policy",

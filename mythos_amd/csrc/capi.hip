@@ -3,6 +3,7 @@
 #include <cstring>
 
 #include "mythos_internal.h"
+#include "observables.h"
 
 namespace mythos {
 
@@ -140,6 +141,9 @@ void mythos_oxdna_destroy(mythos_system_t* s) {
   if (s->d_pd) (void)hipFree(s->d_pd);
   if (s->d_epart) (void)hipFree(s->d_epart);
   if (s->d_pgpart) (void)hipFree(s->d_pgpart);
+  if (s->d_ps_marg) (void)hipFree(s->d_ps_marg);
+  if (s->d_ps_unit) (void)hipFree(s->d_ps_unit);
+  if (s->d_ps_bp) (void)hipFree(s->d_ps_bp);
   delete s;
 }
 
@@ -166,6 +170,57 @@ int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params
   MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd.v, OXP_COUNT * sizeof(double), hipMemcpyHostToDevice));
   s->params_set = true;
   ++s->list_epoch;  // cut-offs may have moved: integrators rebuild their list
+  return MYTHOS_OK;
+}
+
+int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int32_t* unit, int n_bp, const double* bp_probs,
+                          int terms) {
+  if (!s || terms < 0 || terms > 3 || n_bp < 0 || (terms != 0 && (!marginals || !unit || (n_bp > 0 && !bp_probs)))) {
+    set_error("mythos_oxdna_set_pseq: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  MYTHOS_HIP_TRY(hipDeviceSynchronize());  // no kernel in flight reads a half-written table
+  if (terms == 0) {
+    s->pseq_terms = 0;
+    return MYTHOS_OK;
+  }
+  const int n = s->n;
+  for (int i = 0; i < n; ++i) {
+    const int u = unit[i];
+    if (u < -1 || u >= 2 * n_bp) {
+      set_error("mythos_oxdna_set_pseq: unit of nucleotide " + std::to_string(i) + " is outside the " + std::to_string(n_bp) + " base pairs");
+      return MYTHOS_ERR_INVALID_ARGUMENT;
+    }
+  }
+  for (size_t k = 0; k < 4 * (size_t)n; ++k)
+    if (!std::isfinite(marginals[k])) {
+      set_error("mythos_oxdna_set_pseq: non-finite probability");
+      return MYTHOS_ERR_NUMERIC;
+    }
+  const size_t word = s->dtype == MYTHOS_F32 ? sizeof(float) : sizeof(double);
+  const int nb = std::max(n_bp, 1);
+  if (!s->d_ps_marg) MYTHOS_HIP_TRY(hipMalloc(&s->d_ps_marg, 4 * (size_t)n * word));
+  if (!s->d_ps_unit) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_ps_unit, (size_t)n * sizeof(int)));
+  if (nb > s->ps_bp_cap) {
+    if (s->d_ps_bp) (void)hipFree(s->d_ps_bp);
+    s->d_ps_bp = nullptr;
+    s->ps_bp_cap = 0;
+    MYTHOS_HIP_TRY(hipMalloc(&s->d_ps_bp, 4 * (size_t)nb * word));
+    s->ps_bp_cap = nb;
+  }
+  std::vector<double> bp(4 * (size_t)nb, 0.0);
+  if (n_bp > 0) std::copy(bp_probs, bp_probs + 4 * (size_t)n_bp, bp.begin());
+  if (s->dtype == MYTHOS_F32) {
+    std::vector<float> mf(marginals, marginals + 4 * (size_t)n), bf(bp.begin(), bp.end());
+    MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_marg, mf.data(), mf.size() * sizeof(float), hipMemcpyHostToDevice));
+    MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_bp, bf.data(), bf.size() * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_marg, marginals, 4 * (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_bp, bp.data(), bp.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_unit, unit, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+  s->pseq_terms = terms;
   return MYTHOS_OK;
 }
 
@@ -222,7 +277,28 @@ int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat
   }
   if (n_frames == 0) return MYTHOS_OK;  // an empty batch (its buffers may be null) is not an error
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
-  return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams,
+  return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams, nullptr, nullptr,
+                             (hipStream_t)stream);
+}
+
+int mythos_oxdna_energy_obs(mythos_system_t* s, const void* center, const void* quat, int n_frames, double* e_terms,
+                            void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_obs_t* obs, double* obs_out,
+                            mythos_stream_t stream) {
+  if (!s || n_frames < 0 || (n_frames > 0 && (!center || !quat || !e_terms)) || (obs && n_frames > 0 && !obs_out)) {
+    set_error("mythos_oxdna_energy_obs: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (obs && (obs->n != s->n || obs->dtype != s->dtype || obs->device != s->device)) {
+    set_error("mythos_oxdna_energy_obs: the observable set was made for another system size, precision or device");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->params_set || !s->nbrs_set) {
+    set_error("mythos_oxdna_energy_obs: parameters and neighbours must be set first");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  if (n_frames == 0) return MYTHOS_OK;
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams, obs, obs_out,
                              (hipStream_t)stream);
 }
 

@@ -9,7 +9,7 @@
 // and ordering its 32-bead chunks by their first bead made it 9 % slower.
 //
 // Two small kernels on the caller's stream: a Morton key per chunk (from the position of its first particle, cells
-// of the list range, origin shifted by 2^20 cells so that negative coordinates order correctly), then a rank sort -
+// of the list range counted from the lower corner of the bounding box), then a rank sort -
 // chunk c goes to place #{c' : (key, c') < (key, c)}.  The rank sort is O(chunks^2) key comparisons: 0.6 M for a
 // 12 kbp duplex, 39 M for 100 kbp (a few tens of microseconds, once per load and every few dozen list rebuilds).
 #ifndef MYTHOS_CHUNK_ORDER_H
@@ -31,17 +31,36 @@ __device__ __forceinline__ unsigned long long morton_spread21(unsigned long long
   return x;
 }
 
+// ONE workgroup: the lower corner of the representatives' bounding box first (cells are counted from it: counted
+// from a fixed origin, a molecule that straddles a coordinate plane - a duplex along z through the origin does, in
+// x and y - has its chunks on either side of the largest power-of-two boundary of the Morton curve, as far apart in
+// the order as two chunks can be), then the keys.
 template <typename V4>
-__global__ void chunk_keys_kernel(const V4* __restrict__ pos, int blocks, int per_chunk, double inv_cell,
-                                  unsigned long long* __restrict__ keys) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= blocks) return;
-  const V4 v = pos[(size_t)c * per_chunk];
-  auto cell = [&](double x) {
-    const double f = floor(x * inv_cell) + 1048576.0;
+__global__ __launch_bounds__(256) void chunk_keys_kernel(const V4* __restrict__ pos, int blocks, int per_chunk, double inv_cell,
+                                                         unsigned long long* __restrict__ keys) {
+  __shared__ double lo_s[3][256];
+  double lo[3] = {1e300, 1e300, 1e300};
+  for (int c = threadIdx.x; c < blocks; c += 256) {
+    const V4 v = pos[(size_t)c * per_chunk];
+    lo[0] = fmin(lo[0], (double)v.x), lo[1] = fmin(lo[1], (double)v.y), lo[2] = fmin(lo[2], (double)v.z);
+  }
+  for (int k = 0; k < 3; ++k) lo_s[k][threadIdx.x] = lo[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+      for (int k = 0; k < 3; ++k) lo_s[k][threadIdx.x] = fmin(lo_s[k][threadIdx.x], lo_s[k][threadIdx.x + o]);
+    __syncthreads();
+  }
+  const double l0 = lo_s[0][0], l1 = lo_s[1][0], l2 = lo_s[2][0];
+  auto cell = [&](double x, double l) {
+    const double f = floor((x - l) * inv_cell);
     return (unsigned long long)(f < 0.0 ? 0.0 : (f > 2097151.0 ? 2097151.0 : f));
   };
-  keys[c] = morton_spread21(cell((double)v.x)) | morton_spread21(cell((double)v.y)) << 1 | morton_spread21(cell((double)v.z)) << 2;
+  for (int c = threadIdx.x; c < blocks; c += 256) {
+    const V4 v = pos[(size_t)c * per_chunk];
+    keys[c] = morton_spread21(cell((double)v.x, l0)) | morton_spread21(cell((double)v.y, l1)) << 1 |
+              morton_spread21(cell((double)v.z, l2)) << 2;
+  }
 }
 
 __global__ void chunk_rank_kernel(const unsigned long long* __restrict__ keys, int blocks, int* __restrict__ order) {
@@ -69,7 +88,7 @@ template <typename V4>
 static inline hipError_t chunk_order_device(const V4* pos, int blocks, int per_chunk, double cell,
                                             unsigned long long* d_keys, int* d_order, hipStream_t st) {
   const int g = (blocks + 255) / 256;
-  hipLaunchKernelGGL((chunk_keys_kernel<V4>), dim3(g), dim3(256), 0, st, pos, blocks, per_chunk, 1.0 / cell, d_keys);
+  hipLaunchKernelGGL((chunk_keys_kernel<V4>), dim3(1), dim3(256), 0, st, pos, blocks, per_chunk, 1.0 / cell, d_keys);
   hipLaunchKernelGGL(chunk_rank_kernel, dim3(g), dim3(256), 0, st, (const unsigned long long*)d_keys, blocks, d_order);
   return hipGetLastError();
 }

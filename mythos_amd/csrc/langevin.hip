@@ -1355,6 +1355,10 @@ int md_ready(mythos_sim_t* s, const char* who) {
     set_error(std::string(who) + ": parameters and neighbours (or a neighbour policy) must be set first");
     return MYTHOS_ERR_NOT_READY;
   }
+  if (sys->pseq_terms != 0) {
+    set_error(std::string(who) + ": the system carries a probabilistic sequence (mythos_oxdna_set_pseq); dynamics need a discrete one");
+    return MYTHOS_ERR_NOT_READY;
+  }
   MYTHOS_HIP_TRY(hipSetDevice(sys->device));
   if (s->rebuild_every > 0 && sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;

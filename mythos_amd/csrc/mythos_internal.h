@@ -42,6 +42,8 @@ struct BoxT {
 
 }  // namespace mythos
 
+struct mythos_obs;
+
 struct mythos_system {
   int model = 0;
   int n = 0;
@@ -83,6 +85,13 @@ struct mythos_system {
   mythos::OxParams<double> pd;
   float* d_pf = nullptr;   // the same vectors in device memory (read by the MD kernel as scalar loads)
   double* d_pd = nullptr;
+
+  // probabilistic sequence (mythos_oxdna_set_pseq); pseq_terms == 0: discrete sequence
+  void* d_ps_marg = nullptr;  // [n][4] real: marginal base probabilities
+  int* d_ps_unit = nullptr;   // [n] 2 * base pair + member, or -1
+  void* d_ps_bp = nullptr;    // [max(n_bp, 1)][4] real: base-pair type probabilities
+  int ps_bp_cap = 0;
+  int pseq_terms = 0;         // bit 0 stacking, bit 1 hydrogen bonding
 
   // energy-pass scratch
   double* d_epart = nullptr;  // [frames_chunk][blocks][8]
@@ -140,7 +149,8 @@ inline double oxdna_close_range(const mythos_system* sys) {
 
 // oxdna_kernels.hip
 int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
-                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream);
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_obs* obs, double* obs_out,
+                        hipStream_t stream);
 // neighbors.hip
 int rows_from_pairs(mythos_system* sys, const int32_t* pairs, int n_pairs);
 // backbone_offsets, base_vectors: real4 per nucleotide (MD frames) to select the segments by site distances, or null

@@ -10,6 +10,7 @@
 // tiny kernel sums the partials in a fixed order, so e_terms are run-to-run reproducible.
 // Roofline: HBM; algorithmic bytes per frame = (7 s + 4) N + 4 (nbar + 2) N  read,
 // 7 s N + 8*8 + 8 K written (s = sizeof(real)).
+#include "observables.h"
 #include "oxdna_gather.h"
 
 namespace mythos {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
-    double* __restrict__ pg_part, R rnear2) {
+    double* __restrict__ pg_part, R rnear2, const PseqView<R> pseq, const ObsView obs, double* __restrict__ obs_out) {
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
-  const ConstParams<R> P(Pg);
+  // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
+  const ConstParams<R, true> P(Pg, pseq);
 
   const int frame = blockIdx.y;
   const int grp = threadIdx.x / G;
@@ -187,6 +189,13 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
       pg_part[bo * OXP_COUNT + k] = s;
     }
   }
+  // ---- epilogue: the frame's structural observables, by the first workgroup of the frame (observables.h).  The
+  //      frame was just read by this launch, so the second look at it comes out of L2, not HBM.
+  if (obs.width > 0 && blockIdx.x == 0) {
+    __shared__ double obs_red[kBlock / 64];
+    frame_observables<R>(obs, center + fo * 3, quat + fo * 4, obs_out + (size_t)frame * obs.width,
+                         obs.axis + (size_t)frame * obs.n_q * 3, obs_red);
+  }
 }
 
 // out[frame][k] = sum_b part[frame][b][k], fixed order
@@ -214,7 +223,7 @@ static int ensure(T*& ptr, size_t& cap, size_t need) {
 
 template <typename R, int MODEL, int G>
 static int launch_typed(mythos_system* sys, const R* center, const R* quat, int n_frames, double* e_terms,
-                        R* dU_dcenter, R* dU_dquat, double* dU_dparams, hipStream_t stream) {
+                        R* dU_dcenter, R* dU_dquat, double* dU_dparams, mythos_obs* oset, double* obs_out, hipStream_t stream) {
   constexpr int PPB = kBlock / G;
   const int n = sys->n;
   const int blocks = (n + PPB - 1) / PPB;
@@ -238,9 +247,18 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
                                  std::fabs((double)Pd[GEO_BASE]), std::fabs((double)Pd[GEO_STACK])});
   const double rnear = (range + 2.0 * reach) * (1.0 + 1e-4) + 1e-4;
   const R rnear2 = R(rnear * rnear);
+  PseqView<R> pseq;
+  if (sys->pseq_terms != 0) {
+    pseq.marg = (const R*)sys->d_ps_marg, pseq.unit = sys->d_ps_unit, pseq.bp = (const R*)sys->d_ps_bp, pseq.terms = sys->pseq_terms;
+  }
+  ObsView obs;  // width 0: no epilogue
+  if (oset && obs_out) {
+    if (int rc = obs_view_for(oset, n_frames, &obs)) return rc;
+  }
   for (int f0 = 0; f0 < n_frames; f0 += chunk) {
     const int nf = std::min(chunk, n_frames - f0);
     dim3 grid(blocks, nf);
+    if (obs.width > 0) obs.axis = oset->d_axis + (size_t)f0 * obs.n_q * 3;
     const R* c = center + (size_t)f0 * n * 3;
     const R* q = quat + (size_t)f0 * n * 4;
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
@@ -248,15 +266,15 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     if (mode == 0)
       hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
     else if (mode == 1)
       hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
     else
       hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
                        e_terms + (size_t)f0 * T_COUNT);
@@ -269,7 +287,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
 }
 
 int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
-                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, hipStream_t stream) {
+                        void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_obs* oset, double* obs_out, hipStream_t stream) {
   // Lanes per nucleotide by what the row walk's LDS lists (two of row_stride ints per nucleotide) leave room for:
   // 8 lanes = 32 nucleotides per workgroup is the fastest (half the wavefronts of 16 lanes for the same rows, and the
   // short angular lists fill 8 lanes better than 16), up to rows of 192 slots; longer rows take wider groups.
@@ -278,15 +296,15 @@ int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat
     if (sys->dtype == MYTHOS_F32) {
       if (sys->model == 1)
         return launch_typed<float, 1, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
-                                         (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
+                                         (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
       return launch_typed<float, 2, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
-                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, stream);
+                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
     }
     if (sys->model == 1)
       return launch_typed<double, 1, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
-                                        (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+                                        (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
     return launch_typed<double, 2, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
-                                      (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, stream);
+                                      (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
   };
   const size_t list_bytes = (size_t)2 * sys->row_stride * sizeof(int);  // per nucleotide
   if ((kBlock / 8) * list_bytes <= (size_t)48 << 10) return run(std::integral_constant<int, 8>{});

@@ -24,6 +24,7 @@ enum OxParamIndex : int {
 template <typename R>
 struct OxParams {
   static constexpr bool indexed = false;
+  static constexpr bool has_pseq = false;
   R v[OXP_COUNT];
   __host__ __device__ __forceinline__ R operator[](int i) const { return v[i]; }
 };
@@ -35,12 +36,26 @@ struct OxParams {
 // VGPR -> scratch, 0.5-1.4 KB per lane); staged in LDS the loads are hoisted and held in VGPRs (256 registers,
 // one wavefront per SIMD).  `indexed` = true would mean "lane-varying indices are cheap" (an LDS or global
 // gather); the role-dependent parameter blocks are instead chosen by per-value selects (the *_sel helpers).
+//
+// Probabilistic sequence as the energy kernel sees it (mythos/energy/utils.py:45-132, restated in terms of
+// per-nucleotide marginals by mythos_amd/input/sequence_constraints.py kernel_tables): two nucleotides of different
+// units are independent, the two members of one constrained base pair are tied through its type.
 template <typename R>
+struct PseqView {
+  const R* marg = nullptr;   // [n][4] probability of A, C, G, T per nucleotide; null: discrete sequence
+  const int* unit = nullptr; // [n] 2 * base pair + position inside it, or -1 for an unpaired nucleotide
+  const R* bp = nullptr;     // [n_bp][4] probability of the types AT, TA, GC, CG per constrained base pair
+  int terms = 0;             // bit 0: stacking weights are expectations, bit 1: hydrogen-bonding weights are
+};
+template <typename R, bool PSEQ = false>
 struct ConstParams {
   static constexpr bool indexed = false;
+  static constexpr bool has_pseq = PSEQ;  // the MD kernel compiles without the branch (and its registers)
   typedef const R __attribute__((address_space(4))) * cptr;
   cptr p;
+  PseqView<R> ps;
   __device__ __forceinline__ explicit ConstParams(const R* g) : p((cptr)g) {}
+  __device__ __forceinline__ ConstParams(const R* g, const PseqView<R>& v) : p((cptr)g), ps(v) {}
   __device__ __forceinline__ R operator[](int i) const { return p[i]; }
 };
 

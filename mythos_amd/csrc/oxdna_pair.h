@@ -40,6 +40,7 @@ struct Nuc {
   V3<R> c, a1, a2, a3;
   int seq;
   int is_end;
+  int idx;  // nucleotide index: read only where the parameter accessor carries a probabilistic sequence
 };
 
 // axes from an (un-normalised) quaternion, mythos/energy/utils.py:18-36
@@ -63,6 +64,63 @@ __device__ __forceinline__ auto weight_lookup(const PT& P, int base, int k) {
     for (int t = 1; t < 16; ++t) w = (k == t) ? P[base + t] : w;
     return w;
   }
+}
+
+// Weight of the ordered pair (p, q) of a sequence-dependent term: table[seq_p][seq_q] (dna1/stacking.py:287,
+// dna1/hydrogen_bonding.py:333), or - under a probabilistic sequence - its expectation (energy/utils.py:45-132):
+// sum_ab P(p = a, q = b) table[a][b] with P the product of the marginals for nucleotides of different units and
+// sum_t P(type t) [a, b = members of type t] for the two members of one constrained base pair.
+template <typename R, class PT>
+__device__ __forceinline__ R seq_weight(const PT& P, int base, int term_bit, const Nuc<R>& p, const Nuc<R>& q) {
+  if constexpr (PT::has_pseq) {
+    if (P.ps.marg != nullptr && (P.ps.terms & term_bit) != 0) {
+      const int up = P.ps.unit[p.idx], uq = P.ps.unit[q.idx];
+      if (up >= 0 && uq >= 0 && (up >> 1) == (uq >> 1)) {
+        // types AT, TA, GC, CG = (A,T), (T,A), (G,C), (C,G) for (member 0, member 1); A, C, G, T = 0 .. 3
+        const R* b = P.ps.bp + 4 * (up >> 1);
+        const bool fwd = (up & 1) == 0;  // p is member 0
+        return b[0] * (fwd ? P[base + 3] : P[base + 12]) + b[1] * (fwd ? P[base + 12] : P[base + 3]) +
+               b[2] * (fwd ? P[base + 9] : P[base + 6]) + b[3] * (fwd ? P[base + 6] : P[base + 9]);
+      }
+      const R* mp = P.ps.marg + 4 * p.idx;
+      const R* mq = P.ps.marg + 4 * q.idx;
+      const R q0 = mq[0], q1 = mq[1], q2 = mq[2], q3 = mq[3];
+      R w = R(0);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+        w += mp[a] * (q0 * P[base + 4 * a] + q1 * P[base + 4 * a + 1] + q2 * P[base + 4 * a + 2] + q3 * P[base + 4 * a + 3]);
+      return w;
+    }
+  }
+  return weight_lookup(P, base, p.seq * 4 + q.seq);
+}
+
+// dU/dtable[a][b] of the same weight: scale * P(p = a, q = b)
+template <typename R, class PG, class PT>
+__device__ __forceinline__ void seq_weight_pgrad(const PT& P, int base, int term_bit, const Nuc<R>& p, const Nuc<R>& q,
+                                                 R scale, PG& pg) {
+  if constexpr (PT::has_pseq) {
+    if (P.ps.marg != nullptr && (P.ps.terms & term_bit) != 0) {
+      const int up = P.ps.unit[p.idx], uq = P.ps.unit[q.idx];
+      if (up >= 0 && uq >= 0 && (up >> 1) == (uq >> 1)) {
+        const R* b = P.ps.bp + 4 * (up >> 1);
+        const bool fwd = (up & 1) == 0;
+        pg.add(base + (fwd ? 3 : 12), scale * b[0]);
+        pg.add(base + (fwd ? 12 : 3), scale * b[1]);
+        pg.add(base + (fwd ? 9 : 6), scale * b[2]);
+        pg.add(base + (fwd ? 6 : 9), scale * b[3]);
+        return;
+      }
+      const R* mp = P.ps.marg + 4 * p.idx;
+      const R* mq = P.ps.marg + 4 * q.idx;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) pg.add(base + 4 * a + b, scale * mp[a] * mq[b]);
+      return;
+    }
+  }
+  pg.add(base + p.seq * 4 + q.seq, scale);
 }
 
 template <typename R>
@@ -177,15 +235,14 @@ __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const 
     if (Bs.f == R(0)) return;
     const FD<R> Bo = f5_eval(xo, qo);
     if (Bo.f == R(0)) return;
-    const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
-    const R wseq = weight_lookup(P, STCK_EPS_00, wk);
+    const R wseq = seq_weight(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s);
     const R ang = A4.f * As.f * Ao.f;
     const R phi = Bs.f * Bo.f;
     const R v = F1.f * ang * phi;
     e[T_STCK] += wgt * wseq * v;
     const R w = wseq * P[TW_STCK];  // gradients carry the term weight
     if constexpr (PG::on) {
-      pg.add(STCK_EPS_00 + wk, P[TW_STCK] * v);
+      seq_weight_pgrad(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s, P[TW_STCK] * v, pg);
       f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
       f4_pgrad(t4.f, p4, w * F1.f * As.f * Ao.f * phi, pg);
       f4_pgrad(ts.f, ps, w * F1.f * A4.f * Ao.f * phi, pg);
@@ -308,8 +365,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
     const R r = m_sqrt(dot(d, d));
     V3<R> gd{R(0), R(0), R(0)};
     bool any = false;
-    const int wk = role_p ? (s.seq * 4 + o.seq) : (o.seq * 4 + s.seq);
-    const R whb = weight_lookup(P, HYDR_EPS_00, wk);
+    const R whb = seq_weight(P, HYDR_EPS_00, 2, role_p ? s : o, role_p ? o : s);
     const FD<R> F1 = ((TERMS & 1) && (whb != R(0) || PG::on)) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
     const FD<R> F2 = (TERMS & 2) ? f2_eval(r, P, CRST_RLOW) : FD<R>{R(0), R(0)};
     const bool hb_on = (F1.f != R(0) || F1.d != R(0));
@@ -353,7 +409,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
           const R whg = whb * P[TW_HB];
           const R wf = whg * F1.f;
           if constexpr (PG::on) {
-            pg.add(HYDR_EPS_00 + wk, P[TW_HB] * vhb);
+            seq_weight_pgrad(P, HYDR_EPS_00, 2, role_p ? s : o, role_p ? o : s, P[TW_HB] * vhb, pg);
             f1_pgrad(r, P, HYDR_RLOW, whg * ang, pg);
             f4_pgrad(t1.f, p1, wf * o1, pg);
             f4_pgrad(t4.f, p4, wf * o4, pg);

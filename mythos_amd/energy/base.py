@@ -140,7 +140,8 @@ def _get_system(model, seq, is_end, bonded, unbonded, box, dtype, device):
     )
     entry = _SYSTEMS.get(key)
     if entry is None:
-        entry = {"sys": OxdnaSystem(model, seq, is_end_b, bonded, box=box, dtype=dtype, device=device), "pairs": None, "flat": None}
+        entry = {"sys": OxdnaSystem(model, seq, is_end_b, bonded, box=box, dtype=dtype, device=device), "pairs": None, "flat": None,
+                 "pseq": None}
         _SYSTEMS[key] = entry
         if len(_SYSTEMS) > 16:
             _SYSTEMS.pop(next(iter(_SYSTEMS)))
@@ -152,6 +153,76 @@ def _get_system(model, seq, is_end, bonded, unbonded, box, dtype, device):
             entry["sys"].set_neighbors(pairs)
             entry["pairs"] = tag
     return entry
+
+
+def pseq_request(energy_fns):
+    """The probabilistic sequence a composed function asks for: (marginals, unit, bp_probs, terms) or None.
+    Stacking and hydrogen bonding each carry ``pseq`` / ``pseq_constraints`` (dna1/stacking.py:54-55,
+    dna1/hydrogen_bonding.py:94-95); a system has ONE sequence distribution, so if both carry one it must be the same."""
+    from mythos_amd.input.sequence_constraints import kernel_tables
+
+    found, terms = None, 0
+    for fn in energy_fns:
+        bit = {"stacking": 1, "hydrogen_bonding": 2}.get(fn.term)
+        if bit is None or "pseq" not in fn.params or fn.params["pseq"] is None:
+            continue
+        sc = fn.params["pseq_constraints"]
+        if sc is None:
+            raise ValueError("pseq_constraints must be provided when pseq is provided.")
+        tables = kernel_tables(fn.params["pseq"], sc)
+        if found is not None and not all(np.array_equal(a, b) for a, b in zip(found, tables)):
+            raise ValueError("stacking and hydrogen_bonding carry different probabilistic sequences: a system has one")
+        found, terms = tables, terms | bit
+    return None if found is None else (*found, terms)
+
+
+def _apply_pseq(entry, request) -> None:
+    tag = None if request is None else (request[3], *(a.tobytes() for a in request[:3]))
+    if entry["pseq"] != tag:
+        if request is None:
+            entry["sys"].set_pseq()
+        else:
+            entry["sys"].set_pseq(*request)
+        entry["pseq"] = tag
+
+
+# merged observable sets of energy functions built with_observables(...): (signature, n, dtype, device) -> ObservableSet
+_OBS_SETS: dict = {}
+
+
+def _fused_observables(observables, n: int, dtype, device):
+    """One ObservableSet that serves as many of ``observables`` as share its lists: at most one propeller-twist list,
+    one quartet list (with its geometry, model and displacement) and one skip_ends setting.  Returns
+    (set, [the observables it serves]) or (None, [])."""
+    from mythos_amd.observables.base import ObservableSet
+
+    bp_obs = next((o for o in observables if getattr(o, "base_pairs", None) is not None), None)
+    q_all = [o for o in observables if getattr(o, "quartets", None) is not None]
+    q_obs, served = None, []
+    if q_all:
+        q_obs = q_all[0]
+        ref = q_obs.signature()
+        same = [o for o in q_all if o.signature()[1] == ref[1] and o.signature()[3:] == ref[3:]]
+        skips = {bool(o.skip_ends) for o in same if type(o).__name__ == "PersistenceLength"}
+        if len(skips) > 1:
+            same = [o for o in same if type(o).__name__ != "PersistenceLength" or bool(o.skip_ends) == bool(same[0].skip_ends)]
+        served += same
+    if bp_obs is not None:
+        served.append(bp_obs)
+    if not served:
+        return None, []
+    skip = next((bool(o.skip_ends) for o in served if type(o).__name__ == "PersistenceLength"), False)
+    geo = q_obs.geometry if q_obs is not None else None
+    model = q_obs.model if q_obs is not None else 2
+    box = getattr(q_obs.displacement_fn, "box", None) if q_obs is not None else None
+    sig = (None if bp_obs is None else bp_obs.signature()[0], None if q_obs is None else q_obs.signature()[1], skip,
+           None if q_obs is None else q_obs.signature()[3:], n, dtype, str(device))
+    if sig not in _OBS_SETS:
+        if len(_OBS_SETS) >= 8:
+            _OBS_SETS.pop(next(iter(_OBS_SETS)))
+        _OBS_SETS[sig] = ObservableSet(n, model, geo, box, None if bp_obs is None else bp_obs.base_pairs,
+                                       None if q_obs is None else q_obs.quartets, skip, dtype, device)
+    return _OBS_SETS[sig], served
 
 
 class _EnergyOp(torch.autograd.Function):
@@ -167,7 +238,16 @@ class _EnergyOp(torch.autograd.Function):
             entry["flat"] = tag
         need_x = center.requires_grad or quat.requires_grad
         need_p = flat.requires_grad
-        e, gc, gq, gp = system.energy(center.detach(), quat.detach(), grads=need_x, param_grads=need_p)
+        fuse = entry.get("observe")  # (ObservableSet, [observables]) for this call, set by _evaluate
+        if fuse is not None and center.dim() == 3:
+            from mythos_amd.observables.base import remember_fused
+
+            cd, qd = center.detach().contiguous(), quat.detach().contiguous()
+            e, gc, gq, gp, rows = system.energy(cd, qd, grads=need_x, param_grads=need_p, observables=fuse[0])
+            for o in fuse[1]:
+                remember_fused(center, quat, o.signature(), rows)
+        else:
+            e, gc, gq, gp = system.energy(center.detach(), quat.detach(), grads=need_x, param_grads=need_p)
         single = e.dim() == 1
         if single:
             e = e[None]
@@ -342,6 +422,14 @@ class ComposedEnergyFunction(EnergyFunction):
     def with_props(self, **kwargs: Any) -> "ComposedEnergyFunction":
         return self.replace(energy_fns=[fn.with_props(**kwargs) for fn in self.energy_fns])
 
+    def with_observables(self, *observables) -> "ComposedEnergyFunction":
+        """The same energy function whose ``map`` / ``__call__`` on a batch of frames also evaluates these structural
+        observables in the epilogue of its launch (mythos_oxdna_energy_obs): a later ``observable(trajectory)`` on the
+        same frames returns those rows instead of launching again.  What DiffTRe needs per iteration - energies,
+        dU/dtheta, the observable - then costs one read of the stored trajectory.  (No counterpart in the reference,
+        whose observables are separate jitted functions over the trajectory, mythos/observables/*.py.)"""
+        return self.replace(observables=tuple(observables))
+
     def with_noopt(self, *params: str) -> "ComposedEnergyFunction":
         fns = []
         for fn in self.energy_fns:
@@ -438,7 +526,8 @@ class ComposedEnergyFunction(EnergyFunction):
             k = TERM_ORDER.index(fn.term)
             if fn.term in sections:
                 raise ValueError(f"term '{fn.term}' appears twice in one composed energy function")
-            sections[fn.term] = {n: fn.params[n] for n in (*type(fn.params).required_params, *type(fn.params).optional_params)}
+            sections[fn.term] = {n: fn.params[n] for n in (*type(fn.params).required_params, *type(fn.params).optional_params)
+                                 if n not in ("pseq", "pseq_constraints")}
             term_w[k] = float(w)
             cols.append(k)
         kt = salt = hce = None
@@ -457,7 +546,15 @@ class ComposedEnergyFunction(EnergyFunction):
         box = getattr(first.displacement_fn, "box", None)
         entry = _get_system(model, _np(first.seq), _np(first.is_end) if first.is_end is not None else None,
                             _np(first.bonded_neighbors), first.unbonded_neighbors, box, center.dtype, center.device)
-        total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
+        _apply_pseq(entry, pseq_request(self.energy_fns))
+        entry["observe"] = None
+        if getattr(self, "observables", None) and center.dim() == 3 and center.device.type == "cuda":
+            oset, served = _fused_observables(self.observables, int(center.shape[1]), center.dtype, center.device)
+            entry["observe"] = None if oset is None else (oset, served)
+        try:
+            total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
+        finally:
+            entry["observe"] = None
         return total, terms, cols
 
     def compute_terms(self, body: RigidBody) -> torch.Tensor:

@@ -47,7 +47,8 @@ def _radial_names(term: str, flat_prefix: str) -> dict:
 
 def _derive_with(model: int, section: str, cfg: BaseConfiguration, extra: dict | None = None) -> dict:
     """Run the flat derivation with this section's values and defaults elsewhere."""
-    sections = {section: {k: cfg[k] for k in (*type(cfg).required_params, *type(cfg).optional_params)}}
+    sections = {section: {k: cfg[k] for k in (*type(cfg).required_params, *type(cfg).optional_params)
+                          if k not in ("pseq", "pseq_constraints")}}  # the sequence distribution is not a flat parameter
     fill_missing_sections(model, sections)
     kw = dict(kt=default_kt())
     kw.update(extra or {})
@@ -107,8 +108,8 @@ class UnbondedExcludedVolumeConfiguration(BaseConfiguration):
 
 
 def _stacking_derive(self) -> dict:
-    if self["pseq"] is not None:
-        raise NotImplementedError("probabilistic sequences (pseq) are outside the HIP hot path (SURVEY.md 8f item 4)")
+    if self["pseq"] is not None and self["pseq_constraints"] is None:
+        raise ValueError("pseq_constraints must be provided when pseq is provided.")  # dna1/stacking.py:121-122, hydrogen_bonding.py:149-150
     named = _derive_with(1, "stacking", self, {"kt": self["kt"]})
     m = {**_radial_names("stack", "STCK"), **_f4_names("stack", "STCK", (4, 5, 6))}
     for k in (1, 2):
@@ -138,8 +139,8 @@ class StackingConfiguration(BaseConfiguration):
 
 
 def _hb_derive(self) -> dict:
-    if self["pseq"] is not None:
-        raise NotImplementedError("probabilistic sequences (pseq) are outside the HIP hot path (SURVEY.md 8f item 4)")
+    if self["pseq"] is not None and self["pseq_constraints"] is None:
+        raise ValueError("pseq_constraints must be provided when pseq is provided.")  # dna1/stacking.py:121-122, hydrogen_bonding.py:149-150
     named = _derive_with(1, "hydrogen_bonding", self)
     out = _blocks({**_radial_names("hb", "HYDR"), **_f4_names("hb", "HYDR", (1, 2, 3, 4, 7, 8))}, named)
     out["eps_hb_weights"] = torch.stack([torch.stack([named[f"HYDR_EPS_{i}{j}"] for j in range(4)]) for i in range(4)])

@@ -96,6 +96,22 @@ class OxdnaSystem:
             "set_params",
         )
 
+    def set_pseq(self, marginals=None, unit=None, bp_probs=None, terms: int = 0) -> None:
+        """Probabilistic sequence (mythos_oxdna_set_pseq); ``terms`` = 0 or no arguments: back to the discrete sequence."""
+        if not terms:
+            _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, None, None, 0, None, 0), "set_pseq")
+            return
+        marg = np.ascontiguousarray(marginals, dtype=np.float64)
+        unit = np.ascontiguousarray(unit, dtype=np.int32)
+        bp = np.ascontiguousarray(bp_probs, dtype=np.float64).reshape(-1, 4)
+        if marg.shape != (self.n, 4) or unit.shape != (self.n,):
+            raise ValueError(f"marginals must be ({self.n}, 4) and unit ({self.n},)")
+        n_bp = int(unit.max() // 2 + 1) if (unit >= 0).any() else 0
+        if bp.shape[0] < n_bp:
+            raise ValueError("bp_probs has fewer rows than the base pairs named in unit")
+        _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, marg.ctypes.data_as(_lib.c_double_p), unit.ctypes.data_as(_lib.c_int_p),
+                                                   n_bp, bp.ctypes.data_as(_lib.c_double_p), int(terms)), "set_pseq")
+
     def set_neighbors(self, pairs) -> None:
         pairs = np.ascontiguousarray(pairs, dtype=np.int32)
         if pairs.ndim != 2 or (pairs.size and pairs.shape[1] != 2):
@@ -127,10 +143,12 @@ class OxdnaSystem:
             raise ValueError(f"{name} must have trailing shape {tail}, got {tuple(t.shape)}")
         return t.contiguous()
 
-    def energy(self, center, quat, *, grads=False, param_grads=False):
+    def energy(self, center, quat, *, grads=False, param_grads=False, observables=None):
         """Term energies (F, 8) [float64] and optionally dU/dcenter, dU/dquat, dU/dflat.
 
-        ``center`` (F, N, 3) or (N, 3); ``quat`` likewise with 4.
+        ``center`` (F, N, 3) or (N, 3); ``quat`` likewise with 4.  ``observables``: an
+        ``mythos_amd.observables.ObservableSet`` evaluated in the epilogue of the same launch; its (F, width) rows are
+        then returned as a fifth value.
         """
         single = center.dim() == 2
         c = self._check(center, (self.n, 3), "center")
@@ -144,18 +162,31 @@ class OxdnaSystem:
         gc = torch.empty_like(c) if grads else None
         gq = torch.empty_like(q) if grads else None
         gp = torch.empty((nf, self.n_params), dtype=torch.float64, device=self.device) if param_grads else None
-        _lib.check(
-            self._lib.mythos_oxdna_energy(
-                self._h, _lib.ptr(c), _lib.ptr(q), nf, _lib.ptr(e), _lib.ptr(gc), _lib.ptr(gq), _lib.ptr(gp),
-                _stream(self.device),
-            ),
-            "energy",
-        )
+        if observables is None:
+            _lib.check(
+                self._lib.mythos_oxdna_energy(
+                    self._h, _lib.ptr(c), _lib.ptr(q), nf, _lib.ptr(e), _lib.ptr(gc), _lib.ptr(gq), _lib.ptr(gp),
+                    _stream(self.device),
+                ),
+                "energy",
+            )
+            rows = None
+        else:
+            rows = torch.empty((nf, observables.width), dtype=torch.float64, device=self.device)
+            _lib.check(
+                self._lib.mythos_oxdna_energy_obs(
+                    self._h, _lib.ptr(c), _lib.ptr(q), nf, _lib.ptr(e), _lib.ptr(gc), _lib.ptr(gq), _lib.ptr(gp),
+                    observables._h, _lib.ptr(rows), _stream(self.device),
+                ),
+                "energy_obs",
+            )
         if single:
             e = e[0]
             gc = gc[0] if grads else None
             gq = gq[0] if grads else None
             gp = gp[0] if param_grads else None
+        if observables is not None:
+            return e, gc, gq, gp, rows
         return e, gc, gq, gp
 
 

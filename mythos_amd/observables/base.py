@@ -1,57 +1,146 @@
-"""Shared pieces of the structural observables (mythos/observables/base.py:13-66): nucleotide sites from a
-trajectory, adjacent base pairs ("quartets") of a duplex and the local helical axis they define.  All torch, on
-the device the trajectory lives on: a few flops per base pair per frame."""
+"""Shared pieces of the structural observables (mythos/observables/base.py:13-66): the quartets of a duplex, and the
+HIP evaluation every observable class goes through.
+
+An observable object describes WHAT to measure (index lists, geometry, displacement); the numbers come from one
+workgroup per frame on the GPU (mythos_amd/csrc/observables.h) - either a stand-alone launch, or, when the energy
+function was built ``with_observables(...)``, the epilogue of the same launch that evaluates the energies and
+dU/dtheta of the frames (``mythos_oxdna_energy_obs``), so a DiffTRe iteration reads its trajectory once.
+"""
 
 from __future__ import annotations
 
+import ctypes as C
+import weakref
+
+import numpy as np
 import torch
+
+from mythos_amd import _lib
 
 ANGSTROMS_PER_OXDNA_LENGTH = 8.518  # mythos/utils/units.py:5-8
 
-
-def axes_from_quaternion(q: torch.Tensor):
-    """a1 (back-base vector), a2, a3 (base normal) from [w, x, y, z] quaternions (mythos/energy/utils.py:18-36)."""
-    q0, q1, q2, q3 = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
-    a1 = torch.stack([q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3, 2 * (q1 * q2 + q0 * q3), 2 * (q1 * q3 - q0 * q2)], dim=-1)
-    a2 = torch.stack([2 * (q1 * q2 - q0 * q3), q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3, 2 * (q2 * q3 + q0 * q1)], dim=-1)
-    a3 = torch.stack([2 * (q1 * q3 + q0 * q2), 2 * (q2 * q3 - q0 * q1), q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3], dim=-1)
-    return a1, a2, a3
-
-
-def nucleotide_sites(trajectory, geometry: dict, model: int = 2):
-    """(base_sites, back_sites, stack_sites), each (S, N, 3): the site algebra of ``Nucleotide.from_rigid_body``
-    (dna1/nucleotide.py:29-53, dna2/nucleotide.py:30-58) with the TOML ``[geometry]`` values."""
-    c = trajectory.center
-    a1, a2, _ = axes_from_quaternion(trajectory.orientation.vec)
-    base = c + float(geometry["com_to_hb"]) * a1
-    stack = c + float(geometry["com_to_stacking"]) * a1
-    if model == 2:
-        back = c + float(geometry["com_to_backbone_x"]) * a1 + float(geometry["com_to_backbone_y"]) * a2
-    else:
-        back = c + float(geometry["com_to_backbone"]) * a1
-    return base, back, stack
+# output row of mythos_observables_eval / mythos_oxdna_energy_obs
+COL_PROPELLER, COL_RISE, COL_PITCH, COL_L0, COL_CORR = 0, 1, 2, 3, 4
 
 
 def get_duplex_quartets(n_nucs_per_strand: int) -> torch.Tensor:
     """All pairs of adjacent base pairs of a duplex whose strands are stored one after the other:
-    base pair k = (k, 2n - 1 - k); quartet k = (base pair k, base pair k + 1).  Shape (n - 1, 2, 2)."""
+    base pair k = (k, 2n - 1 - k); quartet k = (base pair k, base pair k + 1).  Shape (n - 1, 2, 2)
+    (mythos/observables/base.py:48-66)."""
     n = int(n_nucs_per_strand)
     k = torch.arange(n)
     bps = torch.stack([k, 2 * n - 1 - k], dim=1)
     return torch.stack([bps[:-1], bps[1:]], dim=1)
 
 
-def base_pair_midpoints(quartets: torch.Tensor, base_sites: torch.Tensor):
-    q = quartets.to(base_sites.device)
-    m1 = 0.5 * (base_sites[..., q[:, 0, 0], :] + base_sites[..., q[:, 0, 1], :])
-    m2 = 0.5 * (base_sites[..., q[:, 1, 0], :] + base_sites[..., q[:, 1, 1], :])
-    return m1, m2
+def _geometry3(geometry: dict, model: int) -> np.ndarray:
+    if model == 2:
+        return np.array([float(geometry["com_to_hb"]), float(geometry["com_to_backbone_x"]), float(geometry["com_to_backbone_y"])])
+    return np.array([float(geometry["com_to_hb"]), float(geometry["com_to_backbone"]), 0.0])
 
 
-def local_helical_axis(quartets: torch.Tensor, base_sites: torch.Tensor, displacement_fn):
-    """Unit vector from the midpoint of the first base pair of every quartet to the midpoint of the second, and
-    its length (base.py:24-45)."""
-    m1, m2 = base_pair_midpoints(quartets, base_sites)
-    dr = displacement_fn(m2, m1)
-    norm = dr.norm(dim=-1, keepdim=True)
-    return dr / norm, norm[..., 0]
+class ObservableSet:
+    """mythos_obs_t: the index lists of up to one propeller-twist list and one quartet list on the device."""
+
+    def __init__(self, n: int, model: int, geometry: dict | None, box, base_pairs, quartets, skip_ends: bool, dtype, device):
+        lib = _lib.load()
+        self.n, self.model, self.dtype, self.device = int(n), int(model), dtype, torch.device(device)
+        bps = np.ascontiguousarray(np.asarray(base_pairs if base_pairs is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2))
+        qs = np.ascontiguousarray(np.asarray(quartets if quartets is not None else np.zeros((0, 2, 2)), dtype=np.int32).reshape(-1, 2, 2))
+        if qs.shape[0] > 0 and geometry is None:
+            raise ValueError("rise, pitch and persistence length need the [geometry] section (site offsets)")
+        g3 = _geometry3(geometry, model) if geometry is not None else np.zeros(3)
+        box_arr = None if box is None else np.ascontiguousarray(np.broadcast_to(np.asarray(box, np.float64), (3,)))
+        self._h = lib.mythos_observables_create(
+            self.model, self.n, g3.ctypes.data_as(_lib.c_double_p), None if box_arr is None else box_arr.ctypes.data_as(_lib.c_double_p),
+            int(bps.shape[0]), bps.ctypes.data_as(_lib.c_int_p), int(qs.shape[0]), qs.ctypes.data_as(_lib.c_int_p), int(bool(skip_ends)),
+            0 if dtype == torch.float32 else 1, self.device.index or 0)
+        if not self._h:
+            raise _lib.MythosHipError(f"mythos_observables_create: {_lib.last_error()}")
+        self._lib = lib
+        self.width = int(lib.mythos_observables_width(self._h))
+        self.n_corr = self.width - COL_CORR
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_observables_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def eval(self, center: torch.Tensor, quat: torch.Tensor) -> torch.Tensor:
+        """(S, width) float64 rows for (S, n, 3) / (S, n, 4) frames - the stand-alone launch."""
+        c, q = center.contiguous(), quat.contiguous()
+        out = torch.empty((c.shape[0], self.width), dtype=torch.float64, device=self.device)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._lib.mythos_observables_eval(self._h, _lib.ptr(c), _lib.ptr(q), int(c.shape[0]), _lib.ptr(out), stream),
+                   "observables_eval")
+        return out
+
+
+def _frames(trajectory):
+    c, q = trajectory.center, trajectory.orientation.vec
+    if c.dim() == 2:
+        c, q = c[None], q[None]
+    if c.device.type != "cuda":
+        raise _lib.MythosHipError("observables are evaluated by the HIP library: the trajectory must live on a GPU "
+                                  "(mythos_amd has no CPU fallback; oracle/observables_oracle.py is the test-side checker)")
+    if c.dtype not in (torch.float32, torch.float64):
+        raise ValueError(f"unsupported dtype {c.dtype}")
+    return c, q.to(c.dtype)
+
+
+# rows computed in the epilogue of an energy launch, keyed by the frames they belong to:
+# (center ptr, version, quat ptr, version, shape, set signature) -> (S, width) tensor.  A handful of entries; an entry
+# is only trusted while the tensors it was computed from are unmodified (torch's version counters).
+_FUSED: dict = {}
+
+
+def _traj_key(c: torch.Tensor, q: torch.Tensor):
+    return (c.data_ptr(), c._version, q.data_ptr(), q._version, tuple(c.shape), c.dtype)
+
+
+def remember_fused(c, q, signature, rows) -> None:
+    if len(_FUSED) >= 8:
+        _FUSED.pop(next(iter(_FUSED)))
+    _FUSED[(*_traj_key(c, q), signature)] = rows
+
+
+class HipObservable:
+    """What the four observable classes share: the description of their index lists and the row lookup."""
+
+    base_pairs = None
+    quartets = None
+    skip_ends = True
+    geometry: dict | None = None
+    model: int = 2
+    displacement_fn = None
+
+    def signature(self):
+        bp = None if self.base_pairs is None else np.asarray(self.base_pairs, dtype=np.int32).tobytes()
+        qs = None if self.quartets is None else np.asarray(self.quartets, dtype=np.int32).tobytes()
+        box = getattr(self.displacement_fn, "box", None)
+        box = None if box is None else tuple(np.broadcast_to(np.asarray(box, np.float64), (3,)).tolist())
+        geo = None if self.geometry is None else tuple(_geometry3(self.geometry, self.model).tolist())
+        return (bp, qs, bool(self.skip_ends), geo, self.model, box)
+
+    def make_set(self, n: int, dtype, device) -> ObservableSet:
+        box = getattr(self.displacement_fn, "box", None)
+        return ObservableSet(n, self.model, self.geometry, box, self.base_pairs, self.quartets, self.skip_ends, dtype, device)
+
+    def rows(self, trajectory) -> torch.Tensor:
+        """(S, width) rows of this observable's set for the frames: from the energy launch that already produced
+        them, or from a stand-alone launch."""
+        c, q = _frames(trajectory)
+        hit = _FUSED.get((*_traj_key(c, q), self.signature()))
+        if hit is not None:
+            return hit
+        cache = self.__dict__.setdefault("_sets", {})
+        key = (int(c.shape[1]), c.dtype, str(c.device))
+        if key not in cache:
+            cache[key] = self.make_set(int(c.shape[1]), c.dtype, c.device)
+        return cache[key].eval(c, q)

@@ -1,29 +1,20 @@
 """Persistence length (mythos/observables/persistence_length.py:21-185).
 
-Per frame: the unit vectors l_k between the midpoints of adjacent base pairs (the local helical axis of each
-quartet), their autocorrelation C(d) = mean_k l_k . l_(k+d) and the mean midpoint spacing <l0>.  Over a trajectory
-(optionally with DiffTRe weights): log C(d) = offset - d <l0> / Lp, fitted by least squares.  Lp comes back in
-the length unit of the trajectory (oxDNA units; x 0.8518 for nm).  All torch on the trajectory's device; the
-autocorrelation is one (n, n) product per frame and a sum along diagonals instead of the reference's doubly vmapped
-masked dot products (same numbers, no n^2 intermediate per lag).
+Per frame (HIP, mythos_amd/csrc/observables.h): the unit vectors l_k between the midpoints of adjacent base pairs (the
+local helical axis of each quartet), their autocorrelation C(d) = mean_k l_k . l_(k+d) and the mean midpoint spacing
+<l0>.  Over a trajectory (optionally with DiffTRe weights): log C(d) = offset - d <l0> / Lp, fitted by least squares on
+the host-side torch tensors - a (n_lags, 2) system.  Lp comes back in the length unit of the trajectory (oxDNA units;
+x 0.8518 for nm).
 """
 
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from mythos_amd.observables import base as B
 
 TARGETS = {"oxDNA": 47.5}  # nm (persistence_length.py:15-17)
-
-
-def vector_autocorrelate(vecs: torch.Tensor) -> torch.Tensor:
-    """(..., n, 3) ordered vectors -> (..., n) mean of v_i . v_(i+d) over the n - d pairs at every lag d
-    (persistence_length.py:47-75)."""
-    n = vecs.shape[-2]
-    gram = vecs @ vecs.transpose(-1, -2)
-    sums = torch.stack([torch.diagonal(gram, offset=d, dim1=-2, dim2=-1).sum(-1) for d in range(n)], dim=-1)
-    return sums / torch.arange(n, 0, -1, dtype=vecs.dtype, device=vecs.device)
 
 
 def persistence_length_fit(correlations: torch.Tensor, l0_av):
@@ -36,21 +27,18 @@ def persistence_length_fit(correlations: torch.Tensor, l0_av):
     return -l0_av / slope, offset
 
 
-class PersistenceLength:
+class PersistenceLength(B.HipObservable):
     def __init__(self, quartets, displacement_fn, geometry: dict, model: int = 2, truncate: int | None = None,
                  skip_ends: bool = True):
-        self.quartets = torch.as_tensor(quartets, dtype=torch.long).reshape(-1, 2, 2)
+        self.quartets = np.asarray(quartets, dtype=np.int64).reshape(-1, 2, 2)
         self.displacement_fn, self.geometry, self.model = displacement_fn, geometry, model
         self.truncate, self.skip_ends = truncate, skip_ends
 
     def get_all_corrs_and_l0s(self, trajectory):
         """(S, n_q') correlations and (S,) mean base-pair spacing per frame; n_q' = n_q - 4 with ``skip_ends``
         (persistence_length.py:78-91, :168-185)."""
-        base, _, _ = B.nucleotide_sites(trajectory, self.geometry, self.model)
-        axis, l0 = B.local_helical_axis(self.quartets, base, self.displacement_fn)
-        if self.skip_ends:
-            axis, l0 = axis[..., 2:-2, :], l0[..., 2:-2]
-        return vector_autocorrelate(axis), l0.mean(-1)
+        rows = self.rows(trajectory)
+        return rows[:, B.COL_CORR:], rows[:, B.COL_L0]
 
     def lp_fit(self, trajectory, weights=None):
         corrs, l0s = self.get_all_corrs_and_l0s(trajectory)

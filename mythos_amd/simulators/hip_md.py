@@ -99,6 +99,11 @@ class HipMDSimulator(Simulator):
         if not isinstance(ef, ComposedEnergyFunction):
             ef = ComposedEnergyFunction(energy_fns=[ef])
         first = ef.energy_fns[0]
+        from mythos_amd.energy.base import pseq_request
+
+        if pseq_request(ef.energy_fns) is not None:
+            raise ValueError("HipMDSimulator: the energy function carries a probabilistic sequence (pseq); dynamics need a "
+                             "discrete sequence - reweight the stored frames with the pseq energy function instead")
         geom = next(fn.transform_fn for fn in ef.energy_fns if fn.transform_fn is not None)
         model = geom.model
         sections = {"geometry": geom.params}
@@ -108,7 +113,8 @@ class HipMDSimulator(Simulator):
         from mythos_amd.energy.base import TERM_ORDER
 
         for fn, w in zip(ef.energy_fns, w_user):
-            sections[fn.term] = {n: fn.params[n] for n in (*type(fn.params).required_params, *type(fn.params).optional_params)}
+            sections[fn.term] = {n: fn.params[n] for n in (*type(fn.params).required_params, *type(fn.params).optional_params)
+                                 if n not in ("pseq", "pseq_constraints")}
             tw[TERM_ORDER.index(fn.term)] = float(w)
             if "kt" in fn.params and kt_e is None:
                 kt_e = fn.params["kt"]

@@ -290,7 +290,7 @@ def init_exc_vol(p, with_backbone: bool):
 
 def init_stacking(p):
     """dna1/stacking.py:120-183.  ``p`` must hold ``kt``; optional ``ss_stack_weights``."""
-    q = {k: (_t(v) if v is not None else None) for k, v in p.items()}
+    q = {k: (v if k in ("pseq", "pseq_constraints") else (_t(v) if v is not None else None)) for k, v in p.items()}
     if q.get("ss_stack_weights") is None:
         q["eps_stack"] = (q["eps_stack_base"] + q["eps_stack_kt_coeff"] * q["kt"]) * STACK_WEIGHTS_SA
     else:
@@ -313,7 +313,7 @@ def init_stacking(p):
 
 def init_hydrogen_bonding(p):
     """dna1/hydrogen_bonding.py:148-223."""
-    q = {k: (_t(v) if v is not None else None) for k, v in p.items()}
+    q = {k: (v if k in ("pseq", "pseq_constraints") else (_t(v) if v is not None else None)) for k, v in p.items()}
     if q.get("ss_hb_weights") is None:
         q["eps_hb_weights"] = HB_WEIGHTS_SA * q["eps_hb"]
     else:

@@ -9,8 +9,8 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 rm -rf "$out"; mkdir -p "$out/profiles"
 export TMPDIR=/tmp
-short="--steps 500 --warmup 100 --cpu-steps 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py > $out/bench_profiled.log 2>&1
+short="--steps 500 --warmup 100 --cpu-steps 0 --no-second-dtype"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --cpu-steps 0 > $out/bench_profiled.log 2>&1
 echo "[profiles] stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py $short > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py $short > $out/pmc_write.log 2>&1
@@ -20,16 +20,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VME
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR \
   --output-format csv -d $out/pmc_sq2 -- python bench.py $short > $out/pmc_sq2.log 2>&1
 echo "[profiles] SQ passes done"
-python scripts/collect_traffic.py $out/pmc_fetch $out/pmc_write --n 24000 --out $out/profiles/traffic.json
+python scripts/collect_traffic.py $out/pmc_fetch $out/pmc_write --n 24000 --kernel 'md_step_kernel<float' --out $out/profiles/traffic.json
 python - "$out" "$tag" <<'PY'
 import glob, json, sys
 import pandas as pd
 out, tag = sys.argv[1], sys.argv[2]
-res = {"kernel": "md_step_kernel", "command": "python bench.py --steps 500 --warmup 100 --cpu-steps 0", "mean_per_dispatch": {}}
+res = {"kernel": "md_step_kernel<float, 2, false>", "command": "python bench.py --steps 500 --warmup 100 --cpu-steps 0 --no-second-dtype", "mean_per_dispatch": {}}
 for d in ["pmc_sq1", "pmc_sq2", "pmc_fetch", "pmc_write"]:
     f = glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True)[0]
     df = pd.read_csv(f)
-    df = df[df.Kernel_Name.str.contains("md_step_kernel")]
+    df = df[df.Kernel_Name.str.contains("md_step_kernel<float", regex=False)]
     for k, v in df.groupby("Counter_Name").Counter_Value.mean().items():
         res["mean_per_dispatch"][k] = v
 m = res["mean_per_dispatch"]

@@ -17,7 +17,7 @@ import pandas as pd
 def mean_counter(d, name, kernel):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     df = pd.read_csv(f)
-    df = df[df.Kernel_Name.str.contains(kernel) & (df.Counter_Name == name)]
+    df = df[df.Kernel_Name.str.contains(kernel, regex=False) & (df.Counter_Name == name)]
     return float(df.Counter_Value.mean()), int(len(df))
 
 

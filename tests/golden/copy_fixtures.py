@@ -24,10 +24,12 @@ DST = Path(__file__).resolve().parent
 
 OXDNA_FILES = ("generated.top", "output.dat", "energy.dat", "split_energy.dat", "pair.dat", "input")
 CASES = {
-    "dna1": ("simple-helix", "simple-coax", "simple-helix-seq-dep"),
+    "dna1": ("simple-helix", "simple-coax", "simple-helix-seq-dep", "helix-4bp"),
     "dna2": ("simple-helix", "simple-coax", "simple-helix-half-charged-ends"),
 }
-EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat")}
+EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
+         # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)
+         ("dna1", "helix-4bp"): ("sys.top",)}
 MARTINI = {
     "test-data/martini/energy/m2/lj": ("martini/m2/lj", ("test.trr", "lj.xvg", "ljconf.json")),
     "test-data/martini/energy/m2/bond": ("martini/m2/bond", ("bond.xvg", "bond_params.json")),

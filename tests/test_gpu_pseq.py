@@ -1,0 +1,153 @@
+"""Probabilistic sequences through the HIP energy kernel (mythos_oxdna_set_pseq): the expected stacking / hydrogen-
+bonding weight of every pair is formed inside the kernel from per-nucleotide marginals.
+
+ * one-hot distribution == the discrete sequence == oxDNA's golden energies (dna1/tests/test_integration.py:192-293,
+   use_pseq=True);
+ * the reference's own check, brute-force enumeration over every allowed sequence with the DISCRETE kernel
+   (dna1/tests/test_expected_energies.py:162-328, atol 1e-4), in both precisions;
+ * energies, forces and dU/dtheta against the oracle's restatement of compute_seq_dep_weight (energy/utils.py:45-132);
+ * the integrator refuses a system with a sequence distribution.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from mythos_amd.energy import dna1, dna2
+from mythos_amd.energy.base import Quaternion, RigidBody, space
+from mythos_amd.input import sequence_constraints as scm
+from oracle import oxdna_oracle as orc
+from tests import helpers as H
+from tests.test_pseq_cpu import _helix4, enumerate_sequences
+
+pytestmark = pytest.mark.gpu
+
+
+def _states(traj, frames, dtype):
+    dev = torch.device("cuda", 0)
+    return RigidBody(center=torch.as_tensor(traj.center[frames], dtype=dtype, device=dev),
+                     orientation=Quaternion(vec=torch.as_tensor(traj.quaternions[frames], dtype=dtype, device=dev)))
+
+
+@pytest.mark.parametrize(("case", "weights"), [("simple-helix", False), ("simple-helix-seq-dep", True)])
+def test_one_hot_distribution_equals_discrete_sequence_and_goldens(case, weights):
+    top, traj, split, _ = H.load_golden(1, case)
+    disp, _ = space.periodic(traj.box_size)
+    ef = dna1.create_default_energy_fn(topology=top, displacement_fn=disp)
+    if weights:
+        ss = H.read_ss_weights(H.GOLDEN / "dna1" / case / "seq_dep.dat")
+        ef = ef.with_params(ss_stack_weights=ss["ss_stack_weights"], eps_stack_kt_coeff=ss["eps_stack_kt_coeff"], ss_hb_weights=ss["ss_hb_weights"])
+    frames = list(range(0, 100, 9))
+    st = _states(traj, frames, torch.float64)
+    sc = scm.from_bps(top.n_nucleotides, np.array([[0, 15], [3, 12]]) if not weights else np.zeros((0, 2), dtype=np.int32))
+    soft = ef.with_params(pseq=scm.dseq_to_pseq(top.seq, sc), pseq_constraints=sc)
+    e_d, e_p = ef.compute_terms(st).cpu().numpy(), soft.compute_terms(st).cpu().numpy()
+    np.testing.assert_allclose(e_p, e_d, rtol=0, atol=1e-12)
+    n = top.n_nucleotides
+    np.testing.assert_allclose(np.around(e_p[:, 4] / n, 6), split[frames, 5], atol=1e-3)
+    np.testing.assert_allclose(np.around(e_p[:, 2] / n, 6), split[frames, 3], atol=1e-6)
+    # switching back: the next discrete evaluation on the same cached system is discrete again
+    np.testing.assert_allclose(ef.compute_terms(st).cpu().numpy(), e_d, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_expected_energy_equals_brute_force_enumeration_with_the_discrete_kernel(dtype):
+    top, traj = _helix4()
+    disp, _ = space.periodic(traj.box_size)
+    sc = scm.from_bps(8, np.array([[0, 7], [1, 6], [2, 5]]))
+    rng = np.random.default_rng(3)
+
+    def dist(rows):
+        a = rng.random((rows, 4))
+        return a / a.sum(1, keepdims=True)
+
+    w_hb, w_st, up, bp = dist(4), dist(4), dist(sc.n_unpaired), dist(sc.n_bp)
+    ef = dna1.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(ss_hb_weights=w_hb, ss_stack_weights=w_st)
+    st = _states(traj, list(range(0, 100, 5)), dtype)
+    got = ef.with_params(pseq=(up, bp), pseq_constraints=sc).compute_terms(st).cpu().numpy()
+    want = np.zeros_like(got)
+    for seq, prob in enumerate_sequences(sc, up, bp):
+        want += prob * ef.with_props(seq=seq.astype(np.int32)).compute_terms(st).cpu().numpy()
+    assert np.abs(want[:, 4]).max() > 1e-2 and np.abs(want[:, 2]).max() > 1e-2
+    tol = 1e-10 if dtype == torch.float64 else 1e-4  # the reference's own tolerance is 1e-4
+    np.testing.assert_allclose(got, want, rtol=0, atol=tol)
+
+
+def test_energies_forces_and_parameter_gradients_match_the_oracle():
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    disp, _ = space.periodic(traj.box_size)
+    n = top.n_nucleotides
+    sc = scm.from_bps(n, np.array([[1, 14], [2, 13], [5, 10], [7, 8]]))
+    rng = np.random.default_rng(5)
+
+    def dist(rows):
+        a = rng.random((rows, 4)) + 0.05
+        return a / a.sum(1, keepdims=True)
+
+    up, bp, w_st = dist(sc.n_unpaired), dist(sc.n_bp), rng.random((4, 4)) + 0.5
+    opt = {"eps_hb": 1.0678, "eps_stack_kt_coeff": 2.6717, "a_stack": 6.0, "theta0_hb_4": float(np.pi), "k_cross": 47.5}
+    leaves_h = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in opt.items()}
+    leaves_o = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in opt.items()}
+    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(ss_stack_weights=w_st)
+    ef = ef.with_params(pseq=(up, bp), pseq_constraints=sc)
+    P = H.oracle_params(2, half_charged_ends=True, overrides={
+        "stacking": {"ss_stack_weights": w_st, "eps_stack_kt_coeff": leaves_o["eps_stack_kt_coeff"], "a_stack": leaves_o["a_stack"],
+                     "pseq": (up, bp), "pseq_constraints": sc},
+        "hydrogen_bonding": {"eps_hb": leaves_o["eps_hb"], "theta0_hb_4": leaves_o["theta0_hb_4"], "pseq": (up, bp), "pseq_constraints": sc},
+        "cross_stacking": {"k_cross": leaves_o["k_cross"]}})
+    tt = H.topo_tensors(top)
+    for f in (4, 61):
+        dev = torch.device("cuda", 0)
+        c = torch.as_tensor(traj.center[f], device=dev).requires_grad_(True)
+        q = torch.as_tensor(traj.quaternions[f], device=dev).requires_grad_(True)
+        body = RigidBody(center=c, orientation=Quaternion(vec=q))
+        e_h = ef.with_params(leaves_h)(body)
+        co = torch.as_tensor(traj.center[f]).requires_grad_(True)
+        qo = torch.as_tensor(traj.quaternions[f]).requires_grad_(True)
+        e_o = orc.energy(2, P, co, qo, *tt, traj.box_size)
+        assert abs(e_h.item() - e_o.item()) <= 1e-10 * abs(e_o.item())
+        g_h = torch.autograd.grad(e_h, [c, q, *leaves_h.values()])
+        g_o = torch.autograd.grad(e_o, [co, qo, *leaves_o.values()], retain_graph=True)
+        for a, b in zip(g_h, g_o):
+            assert (a.cpu() - b).abs().max().item() <= 1e-8 * max(1.0, b.abs().max().item())
+    # the terms each carry the distribution: only stacking soft, hydrogen bonding discrete
+    only = dna2.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(ss_stack_weights=w_st)
+    fns = [fn.with_params(pseq=(up, bp), pseq_constraints=sc) if fn.term == "stacking" else fn for fn in only.energy_fns]
+    mixed = only.replace(energy_fns=fns)
+    st = _states(traj, [4], torch.float64)
+    tm, tf, td = (x.compute_terms(st).cpu().numpy()[0] for x in (mixed, ef, only))
+    assert abs(tm[2] - tf[2]) < 1e-12 and abs(tm[4] - td[4]) < 1e-12 and abs(tm[2] - td[2]) > 1e-3
+
+
+def test_dynamics_refuse_a_sequence_distribution():
+    from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList
+
+    top, traj, _, _ = H.load_golden(2, "simple-helix")
+    disp, shift = space.free()
+    sc = scm.from_bps(top.n_nucleotides, np.zeros((0, 2), dtype=np.int32))
+    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(pseq=scm.dseq_to_pseq(top.seq, sc), pseq_constraints=sc)
+    kT = 296.15 * 0.1 / 300.0
+    sp = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(kT / 2.5, kT / 7.5), bonded_neighbors=top.bonded_neighbors,
+                               checkpoint_every=0, dt=0.005, kT=kT)
+    sim = HipMDSimulator(energy_fn=ef, simulator_params=sp, space=(disp, shift), simulator_init=nvt_langevin,
+                         neighbors=NoNeighborList(unbonded_nbrs=top.unbonded_neighbors))
+    with pytest.raises(ValueError, match="probabilistic sequence"):
+        sim.run({}, _states(traj, 0, torch.float32), 10, key=0)
+    # and the C ABI itself
+    from mythos_amd import _lib
+    from mythos_amd.hip_system import LangevinIntegrator
+    from tests.test_gpu_md_at_size import _system
+
+    s = _system(2, top, torch.float32, hce=False)
+    s.set_neighbors(top.unbonded_neighbors)
+    marg, unit, bp = scm.kernel_tables(scm.dseq_to_pseq(top.seq, sc), sc)
+    s.set_pseq(marg, unit, bp, 3)
+    integ = LangevinIntegrator(s, dt=0.005, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5)
+    c = torch.as_tensor(traj.center[0], dtype=torch.float32, device=s.device).contiguous()
+    q = torch.as_tensor(traj.quaternions[0], dtype=torch.float32, device=s.device).contiguous()
+    p, L = torch.zeros_like(c), torch.zeros_like(c)
+    with pytest.raises(_lib.MythosHipError, match="probabilistic sequence"):
+        integ.run(c, q, p, L, 5)
+    s.set_pseq()
+    integ.run(c, q, p, L, 5)
