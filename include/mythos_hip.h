@@ -226,7 +226,8 @@ int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double
                                  double* frames, int* n_frames);
 
 /* Writer for the same format (mythos/input/trajectory.py:322-331, mythos/simulators/io.py:146-170): host buffers
- * times[F], box[F][3], energies[F][3], frames[F][n][15]; 15 significant digits; append != 0 adds to an existing file. */
+ * times[F], box[F][3], energies[F][3], frames[F][n][15]; every number as the shortest text that parses back to the
+ * same double (what the reference's str(float) prints); append != 0 adds to an existing file. */
 int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const double* times, const double* box,
                                   const double* energies, const double* frames, int append);
 

@@ -177,8 +177,9 @@ int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double
   return MYTHOS_OK;
 }
 
-// Writer: the text of every frame is produced concurrently into its own buffer (std::to_chars, 15 significant
-// digits like "%.15g"), then the buffers are written in order.  Replaces the reference's per-frame numpy.savetxt
+// Writer: the text of every frame is produced concurrently into its own buffer (std::to_chars without a precision:
+// the shortest text that reads back to the same double, what the reference's str(float) prints -
+// mythos/input/trajectory.py:323-331 - so written trajectories restart bit for bit), then the buffers are written in order.  Replaces the reference's per-frame numpy.savetxt
 // (mythos/input/trajectory.py:322-331, mythos/simulators/io.py:146-170).
 int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const double* times, const double* box,
                                   const double* energies, const double* frames, int append) {
@@ -193,7 +194,7 @@ int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const d
   }
   auto put = [](std::string& out, double v) {
     char tmp[40];
-    const auto r = std::to_chars(tmp, tmp + sizeof(tmp), v, std::chars_format::general, 15);
+    const auto r = std::to_chars(tmp, tmp + sizeof(tmp), v);  // shortest text that parses back to v exactly
     out.append(tmp, r.ptr);
   };
   auto format_frame = [&](int k, std::string& out) {

@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 #include <hip/hip_ext.h>
 
@@ -99,7 +100,13 @@ __device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const L
 constexpr int kMdBlock = 256;
 constexpr int kMdG = 8;                    // lanes per nucleotide
 constexpr int kMdPPB = kMdBlock / kMdG;    // nucleotides per workgroup
-constexpr int kMdMaxItems = 16;            // flagged unbonded neighbours per nucleotide (phase 2)
+constexpr int kMdItems = 16;               // flagged unbonded neighbours per nucleotide (phase 2) the stepping kernel has room for
+// ... and the variant a run falls back to when a nucleotide has more (see md_step_kernel): 32, or what the 160 KB of LDS
+// leave for the fp64 energy-trace instantiation, whose result rows carry the 8 term energies as well
+template <typename R, bool SAVE>
+constexpr int md_items_big() {
+  return (sizeof(R) == 8 && SAVE) ? 22 : 32;
+}
 constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 
 // Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
@@ -110,9 +117,12 @@ constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 //        where a bare fp32 coordinate resolves 5e-4).  Differences of nearby centres are then exact to fp32
 //        round-off of the DIFFERENCE: (hi_j - hi_i) is exact (Sterbenz), (lo_j - lo_i) is tiny.
 //   q  = quaternion
+//   mom = (p, 0), ang = (L_body, 0): the momenta of the same time level.  They ping-pong with the positions, so a
+//        launch never modifies the state it read: whatever it discovers on the way (a work list that does not fit),
+//        the host can discard what it wrote and run that step again from intact inputs.
 template <typename R>
 struct Frame {
-  typename Vec4T<R>::type *p0, *p1, *p2, *p3, *q, *pl;
+  typename Vec4T<R>::type *p0, *p1, *p2, *p3, *q, *pl, *mom, *ang;
 };
 
 template <typename R>
@@ -209,15 +219,21 @@ __device__ __forceinline__ void md_pin(T& v) {
 //   integrate: one wavefront advances the 32 nucleotides of the workgroup and writes the next frame.
 // workgroups per CU the register allocator is asked to make room for: what the LDS footprint of the
 // variant allows (fp32 stepping 43 KB; the trace and fp64 variants carry wider result rows)
-template <typename R, bool SAVE>
+template <typename R, bool SAVE, int ITEMS>
 constexpr int md_blocks_per_cu() {
+  if (ITEMS > kMdItems) return sizeof(R) == 4 ? (SAVE ? 1 : 2) : 1;  // result rows of 36 slots: 64 - 100 KB (fp32), 125 - 150 KB (fp64) of LDS
   return sizeof(R) == 4 ? (SAVE ? 2 : 3) : (SAVE ? 1 : 2);
 }
 
-template <typename R, int MODEL, bool SAVE>
-__global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_step_kernel(
+// ITEMS: result rows per nucleotide for the angular work lists.  16 is enough for any duplex, junction or origami
+// at physical density (a base has 3 - 5 partners inside the range of an angular term); a nucleotide with more makes
+// the launch ABORT: it raises flags[3], the host discards what that launch wrote (its inputs are intact: frames and
+// momenta ping-pong) and runs the step again with the ITEMS = 32 instantiation, which stays in use for the rest of
+// the run.  More than 32 is reported as an error (sterically that takes overlapping bases).
+template <typename R, int MODEL, bool SAVE, int ITEMS>
+__global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) void md_step_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
-    const Frame<R> out, typename Vec4T<R>::type* __restrict__ mom, typename Vec4T<R>::type* __restrict__ ang,
+    const Frame<R> out,
     const int* __restrict__ rows, const int* __restrict__ row_len, const int* __restrict__ row_close, int row_stride,
     int extra_bonds, R kick_close, int do_step, uint64_t seed, uint64_t step, const typename Vec4T<R>::type* __restrict__ ref_pos,
     const typename Vec4T<R>::type* __restrict__ ref_off, const typename Vec4T<R>::type* __restrict__ ref_a1,
@@ -228,10 +244,10 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   const int ablate = MD_ABLATE(ablate_arg);
   constexpr int G = kMdG, PPB = kMdPPB;
   constexpr int RW = (SAVE ? 12 + T_COUNT : 12) + 1;  // result row: dc, g1, g2, g3 (+ energies), padded to odd
-  constexpr int kSlots = ROW_BONDED_SLOTS + kMdMaxItems;
+  constexpr int kSlots = ROW_BONDED_SLOTS + ITEMS;
   // two work lists per nucleotide: 0 = base-pair terms (H-bond and / or cross-stacking: they share the base-base
   // vector and all six angles, so one evaluation serves both), 1 = coaxial stacking
-  __shared__ int items[2][PPB][kMdMaxItems];  // the flagged row ENTRIES (index | role bit), not their slots
+  __shared__ int items[2][PPB][ITEMS];  // the flagged row ENTRIES (index | role bit), not their slots
   __shared__ int item_cnt[2][PPB];
   __shared__ int item_pre[4][PPB + 1];  // per WAVEFRONT: the prefix of the list that wavefront will walk
   __shared__ R self_lds[PPB][13];
@@ -262,8 +278,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   // the SAME launch that starts after the word was set keeps going - on a grid larger than what is resident at once
   // the late workgroups of launch k would otherwise skip a step the early ones took.
   if (threadIdx.x == 0) {
-    const int hw = flags[1];
-    halt_word = ((hw != 0 && hw <= k_index) ? 1 : 0) | (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
+    const int hw = flags[1], aw = flags[3];  // aw: an earlier launch aborted (work lists too short, see ITEMS)
+    halt_word = ((hw != 0 && hw <= k_index) ? 1 : 0) | ((aw != 0 && aw <= k_index) ? 1 : 0) |
+                (list_overflow ? (list_overflow[0] | list_overflow[1]) : 0);
   }
   // chunk_order (host, from the positions at the start of a run): the chunks of 32 nucleotides in spatial order, so
   // the contiguous eighth an XCD works on is also contiguous in space - in a duplex the two complementary
@@ -425,7 +442,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
         const unsigned int gm = (unsigned int)(bal >> gshift) & ((1u << G) - 1u);
         if (flag[t]) {
           const int pos = n_items[t] + __popc(gm & ((1u << lane) - 1u));
-          if (pos < kMdMaxItems) items[t][grp][pos] = entry;
+          if (pos < ITEMS) items[t][grp][pos] = entry;
         }
         n_items[t] += __popc(gm);
       }
@@ -483,8 +500,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
       }
     }
   }
-  if (n_items[0] + n_items[1] > kMdMaxItems) {  // result rows of one nucleotide exhausted
-    if (lane == 0) atomicOr(flags, 4);
+  if (n_items[0] + n_items[1] > ITEMS) {  // result rows of one nucleotide exhausted: this launch does not count
+    if (lane == 0) atomicMax(flags + 3, k_index + 1);
     n_items[0] = n_items[1] = 0;
   }
   // The radial sums are folded over the group now and parked in LDS: nothing computed so far stays in
@@ -622,7 +639,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
   R z[6] = {R(0), R(0), R(0), R(0), R(0), R(0)};
   V4 pm{}, lm{}, qv{}, r0{}, f0{}, a0{};
   if (integrates) {
-    pm = mom[i_int], lm = ang[i_int], qv = in.q[i_int];
+    pm = in.mom[i_int], lm = in.ang[i_int], qv = in.q[i_int];
     if (do_step && K.skin_half_sq > R(0)) r0 = ref_pos[i_int], f0 = ref_off[i_int], a0 = ref_a1[i_int];
     if (do_step && !MD_ABLATE(ablate & (4 | 32))) normals6(seed, (uint32_t)i_int, step, 0u, z);
 #pragma unroll
@@ -794,8 +811,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE>())) void md_st
     // axes whose cross product may round differently - advance(a); advance(b) then equals advance(a + b) exactly)
     out.p3[i] = do_step ? V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)} : in.p3[i];
     out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
-    mom[i] = V4{p[0], p[1], p[2], R(0)};
-    ang[i] = V4{L[0], L[1], L[2], R(0)};
+    out.mom[i] = V4{p[0], p[1], p[2], R(0)};
+    out.ang[i] = V4{L[0], L[1], L[2], R(0)};
   }
   MD_STAMP(7);
   if constexpr (SAVE) {
@@ -828,8 +845,7 @@ __global__ void reduce_trace_kernel(const double* __restrict__ part, int n_block
 template <typename R>
 __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c, const R* __restrict__ q,
                                   const R* __restrict__ p, const R* __restrict__ l, const int* __restrict__ meta,
-                                  const Frame<R> f, typename Vec4T<R>::type* mom, typename Vec4T<R>::type* ang,
-                                  const R* __restrict__ keep_hi, const R* __restrict__ keep_lo) {
+                                  const Frame<R> f, const R* __restrict__ keep_hi, const R* __restrict__ keep_lo) {
   using V4 = typename Vec4T<R>::type;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -855,12 +871,11 @@ __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c
   f.p2[i] = V4{a3.x, a3.y, a3.z, R(0)};
   f.p3[i] = V4{g_k1 * a1.x + g_k2 * a2.x, g_k1 * a1.y + g_k2 * a2.y, g_k1 * a1.z + g_k2 * a2.z, R(0)};
   f.q[i] = V4{q0, q1, q2, q3};
-  mom[i] = V4{p[3 * i], p[3 * i + 1], p[3 * i + 2], R(0)};
-  ang[i] = V4{l[3 * i], l[3 * i + 1], l[3 * i + 2], R(0)};
+  f.mom[i] = V4{p[3 * i], p[3 * i + 1], p[3 * i + 2], R(0)};
+  f.ang[i] = V4{l[3 * i], l[3 * i + 1], l[3 * i + 2], R(0)};
 }
 template <typename R>
-__global__ void unpack_state_kernel(int n, const Frame<R> f, const typename Vec4T<R>::type* mom,
-                                    const typename Vec4T<R>::type* ang, R* __restrict__ c, R* __restrict__ q,
+__global__ void unpack_state_kernel(int n, const Frame<R> f, R* __restrict__ c, R* __restrict__ q,
                                     R* __restrict__ p, R* __restrict__ l, R* __restrict__ keep_hi,
                                     R* __restrict__ keep_lo) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -872,8 +887,8 @@ __global__ void unpack_state_kernel(int n, const Frame<R> f, const typename Vec4
     keep_lo[3 * i] = lo.x, keep_lo[3 * i + 1] = lo.y, keep_lo[3 * i + 2] = lo.z;
   }
   const auto b = f.q[i];
-  const auto m = mom[i];
-  const auto w = ang[i];
+  const auto m = f.mom[i];
+  const auto w = f.ang[i];
   c[3 * i] = a.x, c[3 * i + 1] = a.y, c[3 * i + 2] = a.z;
   q[4 * i] = b.x, q[4 * i + 1] = b.y, q[4 * i + 2] = b.z, q[4 * i + 3] = b.w;
   p[3 * i] = m.x, p[3 * i + 1] = m.y, p[3 * i + 2] = m.z;
@@ -919,8 +934,9 @@ struct mythos_sim {
   // neighbour policy
   double r_cut = 0, skin = 0;
   int rebuild_every = 0;
-  // device state: two ping-pong frames of 6 vec4 arrays each (p0, p1, p2, p3, q, pl) + momenta
-  void* frame[2][6] = {};
+  // device state: two ping-pong frames of 8 vec4 arrays each (p0, p1, p2, p3, q, pl, mom, ang)
+  static constexpr int kFrameArrays = 8;
+  void* frame[2][kFrameArrays] = {};
   int cur = 0;             // the frame that holds the current state
   bool resident = false;   // the frames hold a state (mythos_langevin_load, or the last run)
   bool list_valid = false; // the rows were built from this state's history and the rebuild schedule continues
@@ -930,8 +946,8 @@ struct mythos_sim {
   // centres as the last run handed them out (hi) and the low parts that went with them (fp32 systems)
   void *keep_hi = nullptr, *keep_lo = nullptr;
   bool keep_valid = false;
-  void *mom = nullptr, *ang = nullptr;
-  static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN, 4 angular items), [1] halt, [2] progress
+  static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN), [1] halt, [2] progress, [3] aborted launch + 1
+  bool items_big = false;              // the ITEMS = 32 instantiation is in use (a launch of this load found 16 too few)
   int* d_flags = nullptr;
   // control words as the device published them at the end of a segment: [0..3] d_flags, [4..6] the list builder's
   // overflow words.  Pinned host memory the publishing kernel writes directly: one stream synchronisation per
@@ -1007,7 +1023,7 @@ template <typename R>
 static Frame<R> frame_of(const mythos_sim* sim, int k) {
   using V4 = typename Vec4T<R>::type;
   return Frame<R>{(V4*)sim->frame[k][0], (V4*)sim->frame[k][1], (V4*)sim->frame[k][2], (V4*)sim->frame[k][3],
-                  (V4*)sim->frame[k][4], (V4*)sim->frame[k][5]};
+                  (V4*)sim->frame[k][4], (V4*)sim->frame[k][5], (V4*)sim->frame[k][6], (V4*)sim->frame[k][7]};
 }
 
 // Spatial order of the workgroups' chunks (chunk_order.h): two small kernels on the run's stream, at every load and
@@ -1026,7 +1042,6 @@ static int update_chunk_order(mythos_sim* sim, const typename Vec4T<R>::type* p0
 // Caller's (N,3)/(N,4) arrays -> the resident frames.  The list of a previous state does not carry over.
 template <typename R, int MODEL>
 static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* p_lin, const R* p_ang, hipStream_t st) {
-  using V4 = typename Vec4T<R>::type;
   mythos_system* sys = sim->sys;
   const int n = sys->n;
   const int tb = (n + 255) / 256;
@@ -1035,12 +1050,13 @@ static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* 
   sim->cur = 0;
   const Frame<R> f0 = frame_of<R>(sim, 0);
   hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
-                     sys->d_meta, f0, (V4*)sim->mom, (V4*)sim->ang, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
+                     sys->d_meta, f0, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
                      (const R*)sim->keep_lo);
   MYTHOS_HIP_TRY(hipGetLastError());
   sim->resident = true;
   sim->list_valid = false;
   sim->since_build = 0;
+  sim->items_big = false;
   return update_chunk_order<R>(sim, f0.p0, (n + kMdPPB - 1) / kMdPPB, st);
 }
 
@@ -1050,7 +1066,7 @@ static int store_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, 
   using V4 = typename Vec4T<R>::type;
   const int n = sim->sys->n;
   hipLaunchKernelGGL(unpack_state_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, frame_of<R>(sim, sim->cur),
-                     (const V4*)sim->mom, (const V4*)sim->ang, center, quat, p_lin, p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
+                     center, quat, p_lin, p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
   MYTHOS_HIP_TRY(hipGetLastError());
   sim->keep_valid = true;
   return 0;
@@ -1073,8 +1089,6 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
   const LangevinConst<R> K = make_const<R>(sim);
   const MdCut<R> cut = make_cut<R>(sys);
   const Frame<R> fr[2] = {frame_of<R>(sim, 0), frame_of<R>(sim, 1)};
-  V4* mom = (V4*)sim->mom;
-  V4* ang = (V4*)sim->ang;
   int cur = sim->cur;
 #ifdef MYTHOS_MD_DIAG
   const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
@@ -1137,24 +1151,29 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       const V4* ref_off = (const V4*)sys->d_ref_off;
       const V4* ref_a1 = (const V4*)sys->d_ref_a1;
       const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
+      auto launch = [&](auto save_tag, auto items_tag, hipEvent_t ea, hipEvent_t eb) {
+        constexpr bool SV = decltype(save_tag)::value;
+        constexpr int IT = decltype(items_tag)::value;
+        // with events: the pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
+        // kernel trace reports), not the time between two markers in the queue
+        hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, SV, IT>), dim3(grid), dim3(kMdBlock), 0, st, ea, eb, 0, Pdev, box, K, cut, n,
+                              fr[cur], fr[cur ^ 1], sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride,
+                              sys->extra_bonds ? 1 : 0, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off,
+                              ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+      };
+      using T = std::true_type;
+      using F = std::false_type;
+      using Small = std::integral_constant<int, kMdItems>;
+      using BigS = std::integral_constant<int, md_items_big<R, true>()>;
+      using BigN = std::integral_constant<int, md_items_big<R, false>()>;
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (sampled) ea = sim->sa[samples], eb = sim->sb[samples], ++samples;
       if (save) {
-        hipLaunchKernelGGL((md_step_kernel<R, MODEL, true>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                           fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                           do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+        if (sim->items_big) launch(T{}, BigS{}, ea, eb); else launch(T{}, Small{}, ea, eb);
         hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
                            e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
-      } else if (sampled) {
-        // the event pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
-        // kernel trace reports), not the time between two markers in the queue
-        hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, sim->sa[samples],
-                              sim->sb[samples], 0, Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows,
-                              sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step,
-                              sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
-        ++samples;
       } else {
-        hipLaunchKernelGGL((md_step_kernel<R, MODEL, false>), dim3(grid), dim3(kMdBlock), 0, st, Pdev, box, K, cut, n,
-                           fr[cur], fr[cur ^ 1], mom, ang, sys->d_rows, sys->d_row_len, row_close_of(sys), sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close,
-                           do_step, sim->seed, (uint64_t)(sim->step + k), ref, ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+        if (sim->items_big) launch(F{}, BigN{}, ea, eb); else launch(F{}, Small{}, ea, eb);
       }
       ++launches;
       cur ^= 1;
@@ -1166,26 +1185,38 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
     const int* ctl = sim->h_ctl;
     err_bits |= ctl[0];
     for (int w = 0; w < kOverflowWords; ++w) ovw[w] = ctl[4 + w];
-    if ((err_bits & (2 | 4)) != 0) break;                        // NaN / angular items: reported below
-    if (ctl[1] == 0 && ovw[0] == 0 && ovw[1] == 0) continue;     // nothing halted
-    if (!dynamic_list) break;                                    // (a static list cannot halt; defensive)
+    if ((err_bits & 2) != 0) break;                              // NaN: reported below
+    const int aborted = ctl[3];  // launch index + 1 whose angular work lists were too short (its output does not count)
+    if (ctl[1] == 0 && ovw[0] == 0 && ovw[1] == 0 && aborted == 0) continue;  // nothing halted
+    if (aborted != 0) {
+      if (sim->items_big) {  // a failed advance leaves state and step counter where they were
+        set_error("mythos_langevin_run: more than " + std::to_string(md_items_big<R, false>()) + " (" + std::to_string(md_items_big<R, true>()) +
+                  " on steps that save energies)"
+                  " neighbours of one nucleotide are inside the range of an angular term (overlapping bases?)");
+        return MYTHOS_ERR_OVERFLOW;
+      }
+      sim->items_big = true;  // run that step again, and the rest of the run, with the wider instantiation
+    } else if (!dynamic_list) {
+      break;  // (a static list cannot halt; defensive)
+    }
     if (++recoveries > kMaxRecoveries) {
-      sim->step += ctl[2];
-      sim->resident = false;
       set_error("mythos_langevin_run: the neighbour list had to be rebuilt out of turn more than " + std::to_string(kMaxRecoveries) +
                 " times in one run: the skin (" + std::to_string(sim->skin) + ") is too small for a rebuild every " +
                 std::to_string(sim->rebuild_every) + " steps");
       return MYTHOS_ERR_OVERFLOW;
     }
-    // kernels 0 .. k-1 ran; the state they left is in the frame kernel k would have read
-    const int ran = ctl[2];
+    // kernels 0 .. ran-1 count; the state they left is in the frame kernel `ran` reads (an aborted launch and
+    // everything behind it do not count: their inputs are untouched)
+    const int ran = aborted != 0 ? std::min(ctl[2], aborted - 1) : ctl[2];
     cur = sim->cur ^ (ran & 1);
     k = ran;
     seg_len = std::max(256, seg_len / 4);
-    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
-    if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
-      return rc;
-    built_at = k;
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, 3 * sizeof(int), st));
+    if (dynamic_list) {
+      if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
+        return rc;
+      built_at = k;
+    }
     ovw[0] = ovw[1] = 0;
   }
   sim->last_recoveries = recoveries;
@@ -1233,11 +1264,6 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
               ") did not fit the buckets of their cells during a neighbour rebuild");
     return MYTHOS_ERR_OVERFLOW;
   }
-  if (err_bits & 4) {
-    set_error("mythos_langevin_run: more than " + std::to_string(kMdMaxItems) +
-              " neighbours of one nucleotide are inside the range of an angular term");
-    return MYTHOS_ERR_OVERFLOW;
-  }
   return MYTHOS_OK;
 }
 
@@ -1268,10 +1294,9 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
   s->epart_blocks = (sys->n + kMdPPB - 1) / kMdPPB;
   bool ok = true;
   for (int k = 0; k < 2; ++k)
-    for (int a = 0; a < 6; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
+    for (int a = 0; a < mythos_sim::kFrameArrays; ++a) ok = ok && hipMalloc(&s->frame[k][a], v4) == hipSuccess;
   ok = ok && hipMalloc(&s->keep_hi, v4) == hipSuccess && hipMalloc(&s->keep_lo, v4) == hipSuccess;
-  ok = ok && hipMalloc(&s->mom, v4) == hipSuccess && hipMalloc(&s->ang, v4) == hipSuccess &&
-       hipMalloc((void**)&s->d_flags, mythos_sim::kCtlWords * sizeof(int)) == hipSuccess &&
+  ok = ok && hipMalloc((void**)&s->d_flags, mythos_sim::kCtlWords * sizeof(int)) == hipSuccess &&
        hipMalloc((void**)&s->d_epart, (size_t)s->epart_blocks * 64 * sizeof(double)) == hipSuccess &&
        hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess &&
        hipHostMalloc((void**)&s->h_ctl, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
@@ -1294,12 +1319,10 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
 void mythos_langevin_destroy(mythos_sim_t* s) {
   if (!s) return;
   for (int k = 0; k < 2; ++k)
-    for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < mythos_sim::kFrameArrays; ++a)
       if (s->frame[k][a]) (void)hipFree(s->frame[k][a]);
   if (s->keep_hi) (void)hipFree(s->keep_hi);
   if (s->keep_lo) (void)hipFree(s->keep_lo);
-  if (s->mom) (void)hipFree(s->mom);
-  if (s->ang) (void)hipFree(s->ang);
   if (s->d_flags) (void)hipFree(s->d_flags);
   if (s->d_chunk_order) (void)hipFree(s->d_chunk_order);
   if (s->d_chunk_keys) (void)hipFree(s->d_chunk_keys);

@@ -97,19 +97,19 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // With the reference's all-pairs list (63 entries per nucleotide in a 32-bp duplex, ~8 near, ~5 with angular
 // support) a single fused loop ran ~200 instructions of radial terms for every entry and the ~1 000-instruction
 // angular code in every iteration for a lane or two; the kernel is VALU-bound, so instructions are its time.
-// items: this group's LDS, two lists of row_stride ints (near entries, angular entries).
+// items: this group's LDS, two lists of list_cap ints (near entries, angular entries of the segment being walked).
 template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
-                                           PG& pg, int* __restrict__ items, R rnear2) {
+                                           PG& pg, int* __restrict__ items, R rnear2, int list_cap) {
   static_assert(G <= 32, "group masks below are 32-bit");
   const int* __restrict__ row = rows + (size_t)i * row_stride;
   const int gshift = (threadIdx.x & 63) & ~(G - 1);
   constexpr unsigned int kGroupMask = (G == 32) ? 0xffffffffu : ((1u << G) - 1u);
   const unsigned int below = (1u << lane) - 1u;
   int* __restrict__ near_list = items;
-  int* __restrict__ ang_list = items + row_stride;
+  int* __restrict__ ang_list = items + list_cap;
   // 1. bonded slots
   if (BONDED && lane < ROW_BONDED_SLOTS && lane < len) {
     const int entry = row[lane];
@@ -120,50 +120,59 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
       bonded_pair<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (lane & 1) == 1, R(0.5), e, sg, pg);
     }
   }
-  // 2. centre-distance filter
-  int n_near = 0;
-  for (int s0 = ROW_BONDED_SLOTS; s0 < len; s0 += G) {
-    const int s = s0 + lane;
-    const int entry = (s < len) ? row[s] : -1;
-    bool near = false;
-    if (entry >= 0) {
-      const V3<R> d = min_image(ld.centre(entry & ROW_INDEX_MASK) - self.c, box);
-      near = dot(d, d) < rnear2;
+  // Stages 2 - 4 run per SEGMENT of list_cap row entries, so the two LDS lists have a fixed size whatever the row
+  // length: the reference's all-pairs lists (mythos/simulators/jax_md/utils.py:49-67) put n - 3 entries in every row,
+  // 997 for the 1 000-nt persistence-length system, and a list sized by the row would not fit the LDS.  Rows up to
+  // list_cap entries (every Verlet list, and all-pairs lists of the DiffTRe-sized systems) are one segment.
+  for (int seg0 = ROW_BONDED_SLOTS; seg0 < len; seg0 += list_cap) {
+    const int seg_end = min(len, seg0 + list_cap);
+    // 2. centre-distance filter
+    int n_near = 0;
+    for (int s0 = seg0; s0 < seg_end; s0 += G) {
+      const int s = s0 + lane;
+      const int entry = (s < seg_end) ? row[s] : -1;
+      bool near = false;
+      if (entry >= 0) {
+        const V3<R> d = min_image(ld.centre(entry & ROW_INDEX_MASK) - self.c, box);
+        near = dot(d, d) < rnear2;
+      }
+      const unsigned int m = (unsigned int)(__ballot(near) >> gshift) & kGroupMask;
+      if (near) near_list[n_near + __popc(m & below)] = entry;
+      n_near += __popc(m);
     }
-    const unsigned int m = (unsigned int)(__ballot(near) >> gshift) & kGroupMask;
-    if (near) near_list[n_near + __popc(m & below)] = entry;
-    n_near += __popc(m);
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // 3. radial terms of the near entries
-  int n_ang = 0;
-  for (int k0 = 0; k0 < n_near; k0 += G) {
-    const int k = k0 + lane;
-    bool flag = false;
-    int entry = -1;
-    if (k < n_near) {
-      entry = near_list[k];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // 3. radial terms of the near entries
+    int n_ang = 0;
+    for (int k0 = 0; k0 < n_near; k0 += G) {
+      const int k = k0 + lane;
+      bool flag = false;
+      int entry = -1;
+      if (k < n_near) {
+        entry = near_list[k];
+        Nuc<R> other;
+        R q4[4];
+        ld.load(entry & ROW_INDEX_MASK, other, q4);
+        flag = unbonded_radial<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5),
+                                                   e, sg, pg);
+      }
+      const unsigned int m = (unsigned int)(__ballot(flag) >> gshift) & kGroupMask;
+      if (flag) ang_list[n_ang + __popc(m & below)] = entry;
+      n_ang += __popc(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // 4. angular terms
+    for (int k = lane; k < n_ang; k += G) {
+      const int entry = ang_list[k];
       Nuc<R> other;
       R q4[4];
       ld.load(entry & ROW_INDEX_MASK, other, q4);
-      flag = unbonded_radial<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5),
-                                                 e, sg, pg);
+      unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5), e, sg,
+                                           pg);
     }
-    const unsigned int m = (unsigned int)(__ballot(flag) >> gshift) & kGroupMask;
-    if (flag) ang_list[n_ang + __popc(m & below)] = entry;
-    n_ang += __popc(m);
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  // 4. angular terms
-  for (int k = lane; k < n_ang; k += G) {
-    const int entry = ang_list[k];
-    Nuc<R> other;
-    R q4[4];
-    ld.load(entry & ROW_INDEX_MASK, other, q4);
-    unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5), e, sg,
-                                         pg);
+    __builtin_amdgcn_wave_barrier();  // the lists are rewritten by the next segment
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
 }
 

@@ -16,6 +16,8 @@
 namespace mythos {
 
 constexpr int kBlock = 256;
+// entries of a neighbour row walked at a time: 32 nucleotides x 2 lists x 192 ints = 48 KB of LDS per workgroup
+constexpr int kEnergyListCap = 192;
 
 // Parameter-partial sink: fp64 LDS atomics into one of kPgCopies private copies of the accumulator (chosen by
 // lane), so the 64 lanes of a wave instruction that add to the SAME parameter - the common case: the index is a
@@ -50,11 +52,11 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
-    double* __restrict__ pg_part, R rnear2, const PseqView<R> pseq, const ObsView obs, double* __restrict__ obs_out) {
+    double* __restrict__ pg_part, R rnear2, const PseqView<R> pseq, const ObsView obs, double* __restrict__ obs_out, int list_cap) {
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
-  extern __shared__ int item_lds[];  // [PPB][2][row_stride]: per group, the near and the angular entries of its row (gather_row)
+  extern __shared__ int item_lds[];  // [PPB][2][list_cap]: per group, the near and the angular entries of a row segment (gather_row)
   __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
       LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
-      gather_row<R, MODEL, GRAD, LdsPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
+      gather_row<R, MODEL, GRAD, LdsPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     } else {
       NoPG pg;
-      gather_row<R, MODEL, GRAD, NoPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * row_stride, rnear2);
+      gather_row<R, MODEL, GRAD, NoPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     }
   }
   __syncthreads();  // the bonded results are in LDS
@@ -251,6 +253,8 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   if (sys->pseq_terms != 0) {
     pseq.marg = (const R*)sys->d_ps_marg, pseq.unit = sys->d_ps_unit, pseq.bp = (const R*)sys->d_ps_bp, pseq.terms = sys->pseq_terms;
   }
+  // LDS lists of the row walk: a row is walked in segments of list_cap entries (gather_row)
+  const int list_cap = std::min(sys->row_stride, kEnergyListCap);
   ObsView obs;  // width 0: no epilogue
   if (oset && obs_out) {
     if (int rc = obs_view_for(oset, n_frames, &obs)) return rc;
@@ -264,17 +268,17 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
     R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
     if (mode == 0)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
     else if (mode == 1)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
     else
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * 2 * sys->row_stride * sizeof(int), stream, P, box, n, c, q,
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
                          sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr);
+                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
                        e_terms + (size_t)f0 * T_COUNT);
@@ -288,30 +292,21 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
 
 int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat, int n_frames, double* e_terms,
                         void* dU_dcenter, void* dU_dquat, double* dU_dparams, mythos_obs* oset, double* obs_out, hipStream_t stream) {
-  // Lanes per nucleotide by what the row walk's LDS lists (two of row_stride ints per nucleotide) leave room for:
-  // 8 lanes = 32 nucleotides per workgroup is the fastest (half the wavefronts of 16 lanes for the same rows, and the
-  // short angular lists fill 8 lanes better than 16), up to rows of 192 slots; longer rows take wider groups.
-  auto run = [&](auto g_tag) -> int {
-    constexpr int G = decltype(g_tag)::value;
-    if (sys->dtype == MYTHOS_F32) {
-      if (sys->model == 1)
-        return launch_typed<float, 1, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
-                                         (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
-      return launch_typed<float, 2, G>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
-                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
-    }
+  // 8 lanes per nucleotide = 32 nucleotides per workgroup (half the wavefronts of 16 lanes for the same rows, and the
+  // short angular lists fill 8 lanes better than 16).  Rows of any length: the walk is segmented (gather_row), so the
+  // reference's all-pairs lists of a 1 000-nt system (997 entries per row) go through the same kernel.
+  if (sys->dtype == MYTHOS_F32) {
     if (sys->model == 1)
-      return launch_typed<double, 1, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
-                                        (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
-    return launch_typed<double, 2, G>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+      return launch_typed<float, 1, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
+    return launch_typed<float, 2, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                     (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
+  }
+  if (sys->model == 1)
+    return launch_typed<double, 1, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
                                       (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
-  };
-  const size_t list_bytes = (size_t)2 * sys->row_stride * sizeof(int);  // per nucleotide
-  if ((kBlock / 8) * list_bytes <= (size_t)48 << 10) return run(std::integral_constant<int, 8>{});
-  if ((kBlock / 16) * list_bytes <= (size_t)60 << 10) return run(std::integral_constant<int, 16>{});
-  if ((kBlock / 32) * list_bytes <= (size_t)60 << 10) return run(std::integral_constant<int, 32>{});
-  set_error("mythos_oxdna_energy: neighbour rows of " + std::to_string(sys->row_stride) + " slots are longer than the energy kernel's lists allow");
-  return MYTHOS_ERR_OVERFLOW;
+  return launch_typed<double, 2, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                    (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
 }
 
 }  // namespace mythos

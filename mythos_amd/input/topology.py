@@ -121,16 +121,16 @@ class Topology:
 
     @property
     def bonded_partners(self) -> np.ndarray:
-        """(N,2) int32: [3' side partner (k-1), 5' side partner (k+1)] or -1.
-
-        Row k lists the bonds *(k-1,k)* and *(k,k+1)* in file order, which is the
-        per-nucleotide view the gather-form kernels consume.
-        """
-        part = np.full((self.n_nucleotides, 2), -1, dtype=np.int32)
+        """(N,4) int32, the slot convention of the kernels' neighbour rows (mythos_amd/csrc/mythos_internal.h): slot 0 =
+        partner of which this nucleotide is ``nn_j`` (bond (partner, self)), slot 1 = partner of which it is ``nn_i``
+        (bond (self, partner)), slots 2 / 3 = a second partner in the same role, -1 where there is none.  Only the two
+        ends of a circular strand use slots 2 / 3: the ring is closed by the pair (first, last) in that order
+        (reference: input/topology.py:178-180), so ``first`` is nn_i of two bonds and ``last`` is nn_j of two."""
+        part = np.full((self.n_nucleotides, 4), -1, dtype=np.int32)
         for i, j in np.asarray(self.bonded_neighbors):
-            # bond (i, j): i is the "nn_i" role, j the "nn_j" role
-            part[i, 1] = j
-            part[j, 0] = i
+            # bond (i, j): i is the "nn_i" role (odd slots), j the "nn_j" role (even slots)
+            part[i, 1 if part[i, 1] < 0 else 3] = j
+            part[j, 0 if part[j, 0] < 0 else 2] = i
         return part
 
 

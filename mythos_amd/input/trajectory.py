@@ -159,7 +159,8 @@ class Trajectory:
 
     def to_file(self, filepath, *, native: bool | None = None) -> None:
         """``native``: True = the C++ writer of libmythos_hip.so (frames formatted concurrently), False = numpy,
-        None = native when the library is built.  Both write 15 significant digits."""
+        None = native when the library is built.  Both write text that parses back to the same doubles
+        (native: the shortest such text, like the reference's str(float); numpy: 17 significant digits)."""
         box = self.box_size if self.box_size is not None else (0, 0, 0)
         write_frames(filepath, self.times, np.broadcast_to(np.asarray(box, dtype=np.float64), (len(self.times), 3)),
                      self.energies, self.frames, native=native)
@@ -170,7 +171,9 @@ def write_state(file, time, energies, state, box_size=(0, 0, 0)) -> None:
     file.write(f"t = {time}\n")
     file.write(f"b = {box_size[0]} {box_size[1]} {box_size[2]}\n")
     file.write(f"E = {energies[0]} {energies[1]} {energies[2]}\n")
-    np.savetxt(file, np.asarray(state), fmt="%.15g")
+    # 17 significant digits read back to the same double (the reference prints str(float): the shortest text that
+    # does, trajectory.py:323-331; the native writer below prints exactly that)
+    np.savetxt(file, np.asarray(state), fmt="%.17g")
 
 
 def write_frames(filepath, times, boxes, energies, frames, *, native: bool | None = None) -> None:

@@ -10,6 +10,7 @@ import torch
 from mythos_amd import _lib
 from mythos_amd.energy import flat_params as fp
 from mythos_amd.input import defaults, topology
+from mythos_amd.utils import generators
 from oracle import oxdna_oracle as orc
 from tests import helpers as H
 
@@ -236,3 +237,100 @@ def test_row_builder_equals_a_kd_tree_on_random_clouds():
         r = subprocess.run([sys.executable, str(root / "scripts" / "stress_rows.py"), str(seed)], cwd=root,
                            env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+
+
+def test_reference_all_pairs_list_of_a_1000_nt_system_goes_through_the_energy_kernel():
+    """The reference's NoNeighborList (simulators/jax_md/utils.py:49-67) is every i < j pair that is not bonded:
+    497 503 pairs and 997 entries per row for the 1 000-nt persistence-length system (data/sys-defs/
+    persistence-length-500bp).  The row walk is segmented, so such rows are no overflow: same energies, forces and
+    dU/dtheta as over the Verlet list (a subset that holds every interacting pair), in both precisions."""
+    from mythos_amd import _lib
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.hip_system import OxdnaSystem
+    from mythos_amd.input import defaults
+    from mythos_amd.simulators.neighbors import verlet_pairs_numpy
+
+    top, c, q = generators.ideal_duplex(500, model=2, seed=2)
+    rng = np.random.default_rng(0)
+    c = c + 0.03 * rng.standard_normal(c.shape)
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    allp = np.asarray(top.unbonded_neighbors)
+    assert len(allp) == 1000 * 999 // 2 - 998
+    ver = verlet_pairs_numpy(c, top.bonded_neighbors, 3.25)
+    for dtype, tol in ((torch.float64, 1e-11), (torch.float32, 2e-5)):
+        s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype)
+        s.set_params(flat)
+        cd = torch.as_tensor(np.stack([c, c + 0.01]), dtype=dtype, device=s.device)
+        qd = torch.as_tensor(np.stack([q, q]), dtype=dtype, device=s.device)
+        out = []
+        for pairs in (ver, allp):
+            s.set_neighbors(pairs)
+            out.append(s.energy(cd, qd, grads=True, param_grads=True))
+        mx, _ = s.neighbor_stats()
+        assert mx == 997
+        for a, b in zip(out[0], out[1]):
+            scale = max(1.0, float(a.abs().max()))
+            assert float((a.double() - b.double()).abs().max()) <= tol * scale
+
+
+def test_a_crowded_nucleotide_makes_the_step_rerun_with_wider_work_lists():
+    """More than 16 neighbours of one nucleotide inside the range of an angular term: the launch that finds out aborts
+    (nothing it wrote counts: frames and momenta ping-pong), the run switches to the 32-row instantiation, repeats
+    the step and carries on.  A blob of unbonded nucleotides, tiny time step, fp64: the trajectory equals the
+    oracle's.  More than 32 is an error, not a wrong answer."""
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+    from mythos_amd import _lib
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.input import defaults, topology
+    from oracle.langevin_oracle import LangevinOracle
+
+    def blob(n, radius, seed):
+        rng = np.random.default_rng(seed)
+        v = rng.standard_normal((n, 3))
+        c = radius * v / np.linalg.norm(v, axis=1, keepdims=True) * rng.random((n, 1)) ** (1 / 3)
+        qq = rng.standard_normal((n, 4))
+        return c, qq / np.linalg.norm(qq, axis=1, keepdims=True)
+
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=False), _lib.param_names())
+    kT, dt = 296.15 * 0.1 / 300.0, 2e-6
+    n = 26
+    top = topology.from_arrays(np.arange(n) % 4, [1] * n)
+    c0, q0 = blob(n, 0.62, 4)
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=torch.float64)
+    s.set_params(flat)
+    s.set_neighbors(top.unbonded_neighbors)
+    integ = LangevinIntegrator(s, dt=dt, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5, seed=12)
+    c = torch.as_tensor(c0, device=s.device).contiguous()
+    q = torch.as_tensor(q0, device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    tc, tq, et = integ.run(c, q, p, L, 4, save_every=2)
+    assert integ.last_recoveries() == 1 and integ.step == 4
+    lo = LangevinOracle(2, H.oracle_params(2), H.topo_tensors(top), None, dt, kT, kT / 2.5, kT / 7.5, 1.0, (1.0, 1.0, 1.0), seed=12)
+    for k in range(4):
+        x, qq, pp, LL, u = lo.step(x, qq, pp, LL)
+        if k % 2 == 1:
+            np.testing.assert_allclose(tc[k // 2].cpu().numpy(), x, rtol=0, atol=1e-12)
+            assert abs(et[k // 2, :8].sum().item() - u) <= 1e-9 * abs(u)
+    np.testing.assert_allclose(p.cpu().numpy(), pp, rtol=1e-9, atol=1e-9 * np.abs(pp).max())
+    np.testing.assert_allclose(L.cpu().numpy(), LL, rtol=1e-9, atol=1e-9 * np.abs(LL).max())
+    # a later run of the same integrator starts with the narrow lists again and recovers again
+    integ.run(c, q, p, L, 1)
+    assert integ.last_recoveries() == 1
+    # 60 nucleotides in the same volume: more than 32 partners in range
+    n2 = 60
+    top2 = topology.from_arrays(np.arange(n2) % 4, [1] * n2)
+    c2, q2 = blob(n2, 0.62, 5)
+    s2 = OxdnaSystem(2, top2.seq, top2.is_end, top2.bonded_neighbors, box=None, dtype=torch.float32)
+    s2.set_params(flat)
+    s2.set_neighbors(top2.unbonded_neighbors)
+    integ2 = LangevinIntegrator(s2, dt=dt, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5, seed=1)
+    cc = torch.as_tensor(c2, dtype=torch.float32, device=s2.device).contiguous()
+    qc = torch.as_tensor(q2, dtype=torch.float32, device=s2.device).contiguous()
+    pc, Lc = integ2.init_momenta()
+    before = cc.clone()
+    with pytest.raises(_lib.MythosHipError, match="angular term"):
+        integ2.run(cc, qc, pc, Lc, 3)
+    assert torch.equal(cc, before)  # the state handed back is the last valid one: the start

@@ -22,8 +22,11 @@ def test_bonded_and_unbonded_pairs_of_linear_and_circular_strands():
     assert not ({tuple(p) for p in u} & {tuple(p) for p in b})
     top = topology.from_arrays(np.array([0, 1, 2, 3, 0]), [3, 2], is_circular=[True, False])
     assert top.is_end.tolist() == [0, 0, 0, 1, 1] and top.n_nucleotides == 5
+    # ring (0, 1, 2): bonds (0,1), (1,2) and the closing (0,2) - nucleotide 0 is nn_i of two bonds, nucleotide 2 nn_j of two
     part = top.bonded_partners
-    assert part.shape[0] == 5
+    assert part.tolist() == [[-1, 1, -1, 2], [0, 2, -1, -1], [1, -1, 0, -1], [-1, 4, -1, -1], [3, -1, -1, -1]]
+    lin = topology.from_arrays(np.array([0, 1, 2]), [3]).bonded_partners
+    assert lin.tolist() == [[-1, 1, -1, -1], [0, 2, -1, -1], [1, -1, -1, -1]]
 
 
 def test_classic_and_new_topology_formats_describe_the_same_system():
@@ -130,8 +133,9 @@ def test_native_trajectory_reader_matches_the_numpy_parse(tmp_path):
 
 
 def test_native_trajectory_writer_round_trips_and_matches_the_numpy_writer(tmp_path):
-    """mythos_oxdna_write_trajectory: what it writes parses back to the same arrays as what numpy.savetxt writes
-    (15 significant digits both), headers included; written by several threads, frames stay in order."""
+    """mythos_oxdna_write_trajectory and the numpy writer: what they write parses back to EXACTLY the arrays that
+    were written (shortest round-trip text, as the reference's str(float) / 17 significant digits), headers included;
+    written by several threads, frames stay in order."""
     from mythos_amd import _lib
 
     if not _lib.lib_path().exists():
@@ -149,12 +153,14 @@ def test_native_trajectory_writer_round_trips_and_matches_the_numpy_writer(tmp_p
     rb = trajectory.from_file(b, [30, 7], is_5p_3p=False, native=False)
     assert np.array_equal(ra.frames, rb.frames) and np.array_equal(ra.times, rb.times)
     assert np.array_equal(ra.box_size, rb.box_size)
-    np.testing.assert_allclose(ra.energies, rb.energies, rtol=1e-14)  # the Python header prints floats in full
-    np.testing.assert_allclose(ra.frames, frames, rtol=1e-14, atol=0)
+    assert np.array_equal(ra.energies, rb.energies) and np.array_equal(ra.energies, traj.energies)
+    assert np.array_equal(ra.frames, frames) and np.array_equal(rb.frames, frames)  # bit for bit: restarts lose nothing
     assert np.array_equal(ra.times, traj.times)
-    # the frame text itself is the same as numpy's (the header lines differ only in how Python prints a float)
-    body = lambda p: [ln for ln in p.read_text().splitlines() if ln[0] not in "tbE"]  # noqa: E731
-    assert body(a) == body(b)
+    # the native text is the shortest that round-trips, e.g. 0.1 stays "0.1"
+    traj1 = trajectory.Trajectory(n_nucleotides=1, strand_lengths=[1], times=np.array([0.0]), energies=np.zeros((1, 3)),
+                                  frames=np.full((1, 1, 15), 0.1), box_size=np.array([1.0, 1.0, 1.0]))
+    traj1.to_file(tmp_path / "short.dat", native=True)
+    assert (tmp_path / "short.dat").read_text().splitlines()[3].split()[0] == "0.1"
     # SimulatorTrajectory.to_file goes through the same writer
     import torch
 
