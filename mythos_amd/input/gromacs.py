@@ -134,6 +134,14 @@ class MartiniTopology:
             bonded_neighbors=np.array(bonds, dtype=np.int32).reshape(-1, 2),
         )
 
+    @classmethod
+    def from_tpr(cls, path) -> "MartiniTopology":
+        """Names, residues, bonds and angles from a GROMACS run input file (the reference goes through
+        MDAnalysis.Universe(tpr), mythos/energy/martini/base.py:76-84)."""
+        t = read_tpr_topology(path)
+        return cls(atom_types=t["atom_types"], atom_names=t["atom_names"], residue_names=t["residue_names"],
+                   angles=t["angles"], bonded_neighbors=t["bonds"])
+
     def tile(self, reps: int) -> "MartiniTopology":
         """The same molecules repeated ``reps`` times (for tiled boxes)."""
         n = len(self.atom_types)
@@ -142,6 +150,142 @@ class MartiniTopology:
             angles=np.concatenate([self.angles + k * n for k in range(reps)]),
             bonded_neighbors=np.concatenate([self.bonded_neighbors + k * n for k in range(reps)]),
         )
+
+
+# ---- .tpr -------------------------------------------------------------------------------------------------------------
+# Function types (GROMACS ifunc.h order) whose parameter records this reader knows, with their number of reals; a
+# topology with any other type is refused rather than mis-read.
+_TPR_IPARAM_REALS = {0: 4, 1: 4, 5: 4, 10: 4, 11: 4, 16: 6, 33: 4, 37: 2, 62: 2, 63: 2}
+_F_BONDS, _F_G96BONDS, _F_HARMONIC, _F_ANGLES, _F_G96ANGLES = 0, 1, 5, 10, 11
+_TPR_F_NRE = {137: 95}  # interaction lists per molecule type, by tpx version
+
+
+class _Xdr:
+    """Big-endian cursor over the in-memory serialisation GROMACS uses for the tpr body (tpx generation >= 27):
+    fixed-size fields at their natural width, strings as int64 length + bytes."""
+
+    def __init__(self, data: bytes, off: int = 0):
+        self.d, self.o = data, off
+
+    def _take(self, fmt: str, size: int):
+        v = struct.unpack_from(fmt, self.d, self.o)[0]
+        self.o += size
+        return v
+
+    def i4(self):
+        return self._take(">i", 4)
+
+    def u2(self):
+        return self._take(">H", 2)
+
+    def u1(self):
+        return self._take(">B", 1)
+
+    def i8(self):
+        return self._take(">q", 8)
+
+    def f4(self):
+        return self._take(">f", 4)
+
+    def f8(self):
+        return self._take(">d", 8)
+
+    def ints(self, n: int) -> list:
+        v = list(struct.unpack_from(f">{n}i", self.d, self.o))
+        self.o += 4 * n
+        return v
+
+    def xdr_string(self) -> str:  # header strings: XDR (size incl. terminator, length, bytes padded to 4)
+        self.i4()
+        n = self.i4()
+        v = self.d[self.o:self.o + n].decode("latin1")
+        self.o += (n + 3) // 4 * 4
+        return v
+
+    def string(self) -> str:
+        n = self.i8()
+        v = self.d[self.o:self.o + n].decode("latin1")
+        self.o += n
+        return v
+
+
+def read_tpr_topology(path) -> dict:
+    """Atom types / names / residue names and the bond and angle index lists of a GROMACS ``.tpr``.
+
+    A narrow reader, written from the layout of GROMACS' tpxio serialisation: single precision, tpx version 137
+    (GROMACS 2025), force fields made of bonds, (G96) angles, constraints and LJ tables - what MARTINI lipid systems
+    use.  Anything else raises ``ValueError`` instead of guessing.  Walks: header, box, symbol table, force-field
+    parameter table, molecule types (atoms, interaction lists, exclusions) and molecule blocks; the result is
+    checked against the atom count in the header."""
+    data = Path(path).read_bytes()
+    r = _Xdr(data)
+    version = r.xdr_string()
+    precision, fver, fgen = r.i4(), r.i4(), r.i4()
+    if not version.startswith("VERSION") or precision != 4 or fgen < 27 or fver not in _TPR_F_NRE:
+        raise ValueError(f"{path}: unsupported tpr ({version!r}, precision {precision}, tpx version {fver}, generation {fgen})")
+    r.xdr_string()  # file tag
+    natoms, ngtc = r.i4(), r.i4()
+    r.i4(), r.f4()  # fep state, lambda
+    has_ir, has_top, has_x, has_v, has_f, has_box = (r.i4() for _ in range(6))
+    body = r.i8()
+    if not has_top or r.o + body != len(data):
+        raise ValueError(f"{path}: no topology in this tpr, or a truncated file")
+    if has_box:
+        r.o += 3 * 9 * 4  # box, relative box, box velocity
+    r.o += 4 * ngtc       # thermostat integrals of old file versions (kept for alignment)
+    syms = [r.string() for _ in range(r.i4())]
+    r.i4()                # system name
+    r.i4()                # number of atom types
+    ftypes = r.ints(r.i4())
+    r.f8(), r.f4()        # reppow, fudgeQQ
+    for ft in ftypes:
+        if ft not in _TPR_IPARAM_REALS:
+            raise ValueError(f"{path}: interaction function type {ft} is not known to this reader")
+        r.o += 4 * _TPR_IPARAM_REALS[ft]
+    f_nre = _TPR_F_NRE[fver]
+    moltypes = []
+    for _ in range(r.i4()):
+        r.i4()  # molecule type name
+        nat, nres = r.i4(), r.i4()
+        resind = []
+        for _ in range(nat):
+            r.o += 16      # m, q, mB, qB
+            r.u2(), r.u2()  # type, typeB
+            r.i4()         # particle type
+            resind.append(r.i4())
+            r.i4()         # atomic number
+        names = [syms[k] for k in r.ints(nat)]
+        types = [syms[k] for k in r.ints(nat)]
+        r.ints(nat)        # type names of the B state
+        resnames = []
+        for _ in range(nres):
+            resnames.append(syms[r.i4()])
+            r.i4(), r.u1()  # residue number, insertion code
+        ilists = [r.ints(r.i4()) for _ in range(f_nre)]
+        r.ints(r.i4() + 1)  # the obsolete charge-group index
+        n_excl, n_excl_a = r.i4(), r.i4()
+        r.ints(n_excl + 1 + n_excl_a)
+        bonds = [tuple(il[k + 1:k + 3]) for ft in (_F_BONDS, _F_G96BONDS, _F_HARMONIC) for il in [ilists[ft]] for k in range(0, len(il), 3)]
+        angles = [tuple(il[k + 1:k + 4]) for ft in (_F_ANGLES, _F_G96ANGLES) for il in [ilists[ft]] for k in range(0, len(il), 4)]
+        moltypes.append({"names": names, "types": types, "res": [resnames[k] for k in resind], "bonds": bonds, "angles": angles})
+    out = {"atom_types": [], "atom_names": [], "residue_names": [], "bonds": [], "angles": []}
+    base = 0
+    for _ in range(r.i4()):
+        mt, nmol, nat_mol = moltypes[r.i4()], r.i4(), r.i4()
+        r.i4(), r.i4()  # position-restraint counts
+        if nat_mol != len(mt["names"]):
+            raise ValueError(f"{path}: molecule block disagrees with its molecule type")
+        for _ in range(nmol):
+            out["atom_types"] += mt["types"]
+            out["atom_names"] += mt["names"]
+            out["residue_names"] += mt["res"]
+            out["bonds"] += [(base + i, base + j) for i, j in mt["bonds"]]
+            out["angles"] += [(base + i, base + j, base + k) for i, j, k in mt["angles"]]
+            base += nat_mol
+    if base != natoms or r.i4() != natoms:
+        raise ValueError(f"{path}: {base} atoms in the molecule blocks, {natoms} in the header")
+    return {"atom_types": tuple(out["atom_types"]), "atom_names": tuple(out["atom_names"]), "residue_names": tuple(out["residue_names"]),
+            "bonds": np.array(out["bonds"], dtype=np.int32).reshape(-1, 2), "angles": np.array(out["angles"], dtype=np.int32).reshape(-1, 3)}
 
 
 def read_xvg(path) -> np.ndarray:

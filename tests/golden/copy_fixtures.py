@@ -35,6 +35,9 @@ MARTINI = {
     "test-data/martini/energy/m2/bond": ("martini/m2/bond", ("bond.xvg", "bond_params.json")),
     "test-data/martini/energy/m2/angle": ("martini/m2/angle", ("test.trr", "angle.xvg", "angle_params.json")),
     "templates/martini/m2/DMPC/273K": ("martini/template", ("membrane.gro", "topol.top")),
+    # MARTINI-3 harmonic angles: DOPC bilayer + water, topology only as a GROMACS run input file
+    # (reference test: mythos/energy/martini/m3/tests/test_angle_m3.py:61-77)
+    "test-data/martini/energy/m3/angle": ("martini/m3/angle", ("test.trr", "test.tpr", "angle.xvg", "angle_params_rad.json")),
 }
 
 

@@ -223,3 +223,25 @@ def test_coupled_parameter_receives_the_summed_gradient():
     # U is linear in a common epsilon: dU/deps_all = U / eps_all
     u = fn.map(traj).sum().item()
     assert abs(shared.grad.item() - u / 3.0) <= 1e-9 * abs(u)
+
+
+def test_m3_harmonic_angle_energy_against_gromacs():
+    """mythos/energy/martini/m3/tests/test_angle_m3.py:61-77 on the GPU: DOPC bilayer + water (5 831 beads, topology
+    from the .tpr), harmonic angles against gmx energy on ten frames, rtol 1e-5; both precisions."""
+    import json
+
+    from mythos_amd.input import gromacs
+
+    base = MH.MG / "m3" / "angle"
+    top = gromacs.MartiniTopology.from_tpr(base / "test.tpr")
+    params = json.loads((base / "angle_params_rad.json").read_text())
+    x, box, _ = gromacs.read_trr(base / "test.trr")
+    e = gromacs.read_xvg(base / "angle.xvg")[1:]
+    dev = torch.device("cuda", 0)
+    for dtype, rtol in ((torch.float64, 1e-5), (torch.float32, 1e-5)):
+        fn = M.Angle3.from_topology(topology=top, params=M.AngleConfiguration(**params)).with_props(dtype=dtype)
+        traj = Traj(torch.as_tensor(x, dtype=dtype, device=dev), torch.as_tensor(box, dtype=dtype, device=dev))
+        got = fn.map(traj).cpu().numpy()
+        assert got.shape == (10,)
+        np.testing.assert_allclose(got, e, rtol=rtol)
+    assert not np.allclose(M.Angle.from_topology(topology=top, params=M.AngleConfiguration(**params)).map(traj).cpu().numpy(), e, rtol=1e-3)
