@@ -174,7 +174,11 @@ int mythos_langevin_init_momenta(mythos_sim_t* sim, void* p_lin, void* p_ang, my
  *   the 8 term energies + translational + rotational kinetic energy (any of the three may be NULL).
  * A site that outruns the Verlet skin before the scheduled rebuild, or rows / cell buckets that outgrow their
  * allocation, halt the queued launches; the run rebuilds at the last valid state and resumes (not an error; counted
- * by mythos_langevin_last_recoveries).  MYTHOS_ERR_OVERFLOW only after 64 such rebuilds in one run. */
+ * by mythos_langevin_last_recoveries).  MYTHOS_ERR_OVERFLOW only after 64 such rebuilds in one run, or when one
+ * nucleotide has more than 32 neighbours inside the range of an angular term (up to 16 the fast instantiation runs; a
+ * launch that finds more aborts, nothing it wrote counts, and the step is repeated with 32 result rows per nucleotide).
+ * After an error the arrays hold the positions of the last step that counted and momenta short of that step's closing
+ * half kick; mythos_langevin_get_step tells how many steps that was. */
 int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin, void* p_ang, int n_steps,
                         int save_every, void* traj_center, void* traj_quat, double* e_trace,
                         mythos_stream_t stream);

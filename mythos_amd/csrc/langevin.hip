@@ -1189,7 +1189,10 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
     const int aborted = ctl[3];  // launch index + 1 whose angular work lists were too short (its output does not count)
     if (ctl[1] == 0 && ovw[0] == 0 && ovw[1] == 0 && aborted == 0) continue;  // nothing halted
     if (aborted != 0) {
-      if (sim->items_big) {  // a failed advance leaves state and step counter where they were
+      if (sim->items_big) {
+        // what is handed back: the positions after the last step that counted, momenta short of its closing half kick
+        sim->cur ^= ((aborted - 1) & 1);
+        sim->step += aborted - 1;
         set_error("mythos_langevin_run: more than " + std::to_string(md_items_big<R, false>()) + " (" + std::to_string(md_items_big<R, true>()) +
                   " on steps that save energies)"
                   " neighbours of one nucleotide are inside the range of an angular term (overlapping bases?)");
@@ -1200,6 +1203,8 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       break;  // (a static list cannot halt; defensive)
     }
     if (++recoveries > kMaxRecoveries) {
+      sim->cur ^= (ctl[2] & 1);  // positions after the last step that counted, momenta short of its closing half kick
+      sim->step += ctl[2];
       set_error("mythos_langevin_run: the neighbour list had to be rebuilt out of turn more than " + std::to_string(kMaxRecoveries) +
                 " times in one run: the skin (" + std::to_string(sim->skin) + ") is too small for a rebuild every " +
                 std::to_string(sim->rebuild_every) + " steps");
