@@ -19,12 +19,18 @@ constexpr int kBlock = 256;
 // entries of a neighbour row walked at a time: 32 nucleotides x 2 lists x 192 ints = 48 KB of LDS per workgroup
 constexpr int kEnergyListCap = 192;
 
-// Parameter-partial sink: fp64 LDS atomics into one of kPgCopies private copies of the accumulator (chosen by
-// lane), so the 64 lanes of a wave instruction that add to the SAME parameter - the common case: the index is a
-// compile-time constant at most call sites - hit kPgCopies addresses in different bank pairs instead of one.
+// Parameter-partial sink: fp64 LDS atomics into one of kPgCopies private copies of the accumulator, so the 64 lanes
+// of a wave instruction that add to the SAME parameter - the common case: the index is a compile-time constant at
+// most call sites - do not all hit one address.  A copy belongs to ONE wavefront (two copies per wavefront, by lane
+// parity): everything added to it comes from that wavefront's instruction stream, in program order, and lanes that
+// collide inside one instruction are served in lane order - so the sum a copy holds does not depend on how the four
+// wavefronts of the workgroup interleave, and dU/dtheta is reproducible bit for bit like energies and forces (copies
+// chosen by lane alone were shared by the wavefronts and were not).
 // Eight copies, not sixteen: the LDS atomics are a few per cent of the kernel's time either way, but 35 KB of copies
 // left room for two workgroups per CU where the registers allow three (dU/dtheta call -30 % in fp32).
 constexpr int kPgCopies = 8;
+__device__ __forceinline__ int pg_copy_of(unsigned int tid) { return (int)((tid >> 6) * 2u + (tid & 1u)); }
+static_assert(kPgCopies == 2 * (256 / 64), "two accumulator copies per wavefront of the 256-thread workgroup");
 constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: the copies of one parameter land in different bank pairs
 struct LdsPG {
   static constexpr bool on = true;
@@ -109,7 +115,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
         ld.load(entry & ROW_INDEX_MASK, other, q4);
         const V3<R> dco = min_image(other.c - sp.c, box);
         if constexpr (MODE == 2) {
-          LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
+          LdsPG pg{pg_lds + pg_copy_of(threadIdx.x) * kPgStride};
           bonded_pair<R, MODEL, GRAD, LdsPG>(P, sp, other, dco, (slot & 1) == 1, R(0.5), eb, sb, pg);
         } else {
           NoPG pg;
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     Nuc<R> self;
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
-      LdsPG pg{pg_lds + (threadIdx.x % kPgCopies) * kPgStride};
+      LdsPG pg{pg_lds + pg_copy_of(threadIdx.x) * kPgStride};
       gather_row<R, MODEL, GRAD, LdsPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     } else {
       NoPG pg;

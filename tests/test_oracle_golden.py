@@ -37,9 +37,13 @@ def test_total_energy(model, name, hce):
     top, traj, _, energy = H.load_golden(model, name)
     P = H.oracle_params(model, half_charged_ends=hce)
     e = H.oracle_terms_traj(model, P, top, traj).sum(1)
-    # dna2 total: atol 1e-3 (dna2/tests/test_integration.py:374); dna1: rtol 1e-5/atol 1e-6 is only
-    # met by the reference for terms without mesh interpolation; 1e-4 holds for every frame here.
-    np.testing.assert_allclose(e, energy, atol=1e-3 if model == 2 else 1e-4)
+    # dna2 total: atol 1e-3 (dna2/tests/test_integration.py:374).  dna1: the reference asserts its total on
+    # simple-helix only, rounded to 6 digits, rtol 1e-5 / atol 1e-6 (dna1/tests/test_integration.py:322-389) - held to
+    # exactly that here; the other dna1 directories (which the reference does not assert) at 1e-4.
+    if model == 1 and name == "simple-helix":
+        np.testing.assert_allclose(np.around(e, 6), energy, rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_allclose(e, energy, atol=1e-3 if model == 2 else 1e-4)
 
 
 def test_quaternion_route_equals_axes_route():
