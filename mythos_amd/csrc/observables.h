@@ -150,4 +150,7 @@ struct mythos_obs {
 namespace mythos {
 // makes sure the axis scratch covers n_frames and returns the view to pass to a kernel
 int obs_view_for(mythos_obs* o, int n_frames, ObsView* out);
+// the stand-alone kernel on n_frames frames (view: from obs_view_for, its axis pointer already at the first frame)
+int observables_launch(mythos_obs* o, const ObsView& view, const void* center, const void* quat, int n_frames, double* out,
+                       hipStream_t stream);
 }  // namespace mythos

@@ -29,6 +29,18 @@ int obs_view_for(mythos_obs* o, int n_frames, ObsView* out) {
   return 0;
 }
 
+int observables_launch(mythos_obs* o, const ObsView& v, const void* center, const void* quat, int n_frames, double* out,
+                       hipStream_t st) {
+  if (o->dtype == MYTHOS_F32)
+    hipLaunchKernelGGL(observables_kernel<float>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const float*)center,
+                       (const float*)quat, out);
+  else
+    hipLaunchKernelGGL(observables_kernel<double>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const double*)center,
+                       (const double*)quat, out);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 }  // namespace mythos
 
 using namespace mythos;
@@ -109,15 +121,7 @@ int mythos_observables_eval(mythos_obs_t* o, const void* center, const void* qua
   MYTHOS_HIP_TRY(hipSetDevice(o->device));
   ObsView v;
   if (int rc = obs_view_for(o, n_frames, &v)) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  if (o->dtype == MYTHOS_F32)
-    hipLaunchKernelGGL(observables_kernel<float>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const float*)center,
-                       (const float*)quat, out);
-  else
-    hipLaunchKernelGGL(observables_kernel<double>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const double*)center,
-                       (const double*)quat, out);
-  MYTHOS_HIP_TRY(hipGetLastError());
-  return MYTHOS_OK;
+  return observables_launch(o, v, center, quat, n_frames, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

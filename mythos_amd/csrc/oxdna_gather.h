@@ -98,7 +98,7 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // support) a single fused loop ran ~200 instructions of radial terms for every entry and the ~1 000-instruction
 // angular code in every iteration for a lane or two; the kernel is VALU-bound, so instructions are its time.
 // items: this group's LDS, two lists of list_cap ints (near entries, angular entries of the segment being walked).
-template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, class Loader, class PT>
+template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, bool SEGMENTED = false, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
@@ -124,8 +124,10 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
   // length: the reference's all-pairs lists (mythos/simulators/jax_md/utils.py:49-67) put n - 3 entries in every row,
   // 997 for the 1 000-nt persistence-length system, and a list sized by the row would not fit the LDS.  Rows up to
   // list_cap entries (every Verlet list, and all-pairs lists of the DiffTRe-sized systems) are one segment.
-  for (int seg0 = ROW_BONDED_SLOTS; seg0 < len; seg0 += list_cap) {
-    const int seg_end = min(len, seg0 + list_cap);
+  // (SEGMENTED = false: the row fits the lists; one pass, and the compiler sees no outer loop - with the loop the
+  // fp64 energy-only instantiation ran 50 % longer on rows that never needed a second segment)
+  for (int seg0 = ROW_BONDED_SLOTS; seg0 < len; seg0 = SEGMENTED ? seg0 + list_cap : len) {
+    const int seg_end = SEGMENTED ? min(len, seg0 + list_cap) : len;
     // 2. centre-distance filter
     int n_near = 0;
     for (int s0 = seg0; s0 < seg_end; s0 += G) {

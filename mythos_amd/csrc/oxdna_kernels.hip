@@ -29,7 +29,11 @@ constexpr int kEnergyListCap = 192;
 // Eight copies, not sixteen: the LDS atomics are a few per cent of the kernel's time either way, but 35 KB of copies
 // left room for two workgroups per CU where the registers allow three (dU/dtheta call -30 % in fp32).
 constexpr int kPgCopies = 8;
+#ifdef MYTHOS_EN_OLD_PGCOPY  // (dev A/B: copies chosen by lane, shared by the wavefronts)
+__device__ __forceinline__ int pg_copy_of(unsigned int tid) { return (int)(tid % 8u); }
+#else
 __device__ __forceinline__ int pg_copy_of(unsigned int tid) { return (int)((tid >> 6) * 2u + (tid & 1u)); }
+#endif
 static_assert(kPgCopies == 2 * (256 / 64), "two accumulator copies per wavefront of the 256-thread workgroup");
 constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: the copies of one parameter land in different bank pairs
 struct LdsPG {
@@ -50,10 +54,14 @@ template <typename R, int MODE>
 constexpr int energy_blocks_per_cu() {
   // fp64: the energy-only mode runs faster at three workgroups per CU with 100 B of scratch than at two without
   // (0.58 -> 0.49 ms on the DiffTRe shape); the gradient modes spill too much for that (0.72 -> 1.43 ms)
-  return sizeof(R) == 4 ? (MODE == 0 ? 4 : EN_LB) : (MODE == 0 ? 3 : 2);
+  // fp32 forces mode: 128 registers without scratch, so four fit (at three the allocator takes 138 and the call is 18 % slower)
+  return sizeof(R) == 4 ? (MODE <= 1 ? 4 : EN_LB) : (MODE == 0 ? 3 : 2);
 }
 
-template <typename R, int MODEL, int MODE, int G>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
+// SEG: rows longer than the LDS lists are walked in segments (gather_row)
+// OBS: the instantiation carries the observables epilogue.  A template parameter, not a run-time branch: the epilogue's
+// fp64 site algebra would otherwise set the register count of every launch (energy-only fp32: 96 -> 128 VGPRs + scratch).
+template <typename R, int MODEL, int MODE, int G, bool SEG, bool OBS>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
 __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxdna_energy_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
@@ -67,7 +75,11 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
+#ifdef MYTHOS_EN_NO_PSEQ  // (dev A/B)
+  const ConstParams<R, false> P(Pg);
+#else
   const ConstParams<R, true> P(Pg, pseq);
+#endif
 
   const int frame = blockIdx.y;
   const int grp = threadIdx.x / G;
@@ -139,10 +151,10 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     ld.load(i, self, qs);
     if constexpr (MODE == 2) {
       LdsPG pg{pg_lds + pg_copy_of(threadIdx.x) * kPgStride};
-      gather_row<R, MODEL, GRAD, LdsPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
+      gather_row<R, MODEL, GRAD, LdsPG, G, false, SEG>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     } else {
       NoPG pg;
-      gather_row<R, MODEL, GRAD, NoPG, G, false>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
+      gather_row<R, MODEL, GRAD, NoPG, G, false, SEG>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     }
   }
   __syncthreads();  // the bonded results are in LDS
@@ -199,10 +211,12 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   }
   // ---- epilogue: the frame's structural observables, by the first workgroup of the frame (observables.h).  The
   //      frame was just read by this launch, so the second look at it comes out of L2, not HBM.
-  if (obs.width > 0 && blockIdx.x == 0) {
+  if constexpr (OBS) {
+    if (obs.width > 0 && blockIdx.x == 0) {
     __shared__ double obs_red[kBlock / 64];
     frame_observables<R>(obs, center + fo * 3, quat + fo * 4, obs_out + (size_t)frame * obs.width,
                          obs.axis + (size_t)frame * obs.n_q * 3, obs_red);
+    }
   }
 }
 
@@ -273,18 +287,28 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     const R* q = quat + (size_t)f0 * n * 4;
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
     R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
-    if (mode == 0)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 0, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
-                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
-    else if (mode == 1)
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 1, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
-                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
-    else
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, 2, G>), grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q,
-                         sys->d_meta, sys->d_rows, sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq,
-                         sys->d_pgpart, rnear2, pseq, obs, obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
+    // the epilogue rides on the energy-only and the dU/dtheta launches (what a DiffTRe evaluation issues); a forces
+    // launch with observables is followed by the stand-alone observables kernel instead (rare, and it keeps the
+    // forces instantiation at four workgroups per CU)
+    const bool fuse = obs.width > 0 && mode != 1;
+    auto launch = [&](auto mode_tag, auto seg_tag, auto obs_tag) {
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, decltype(mode_tag)::value, G, decltype(seg_tag)::value, decltype(obs_tag)::value>),
+                         grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q, sys->d_meta, sys->d_rows,
+                         sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq, sys->d_pgpart, rnear2, pseq, obs,
+                         obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
+    };
+    auto by_seg = [&](auto mode_tag, auto obs_tag) {
+      if (sys->row_stride > list_cap) launch(mode_tag, std::true_type{}, obs_tag); else launch(mode_tag, std::false_type{}, obs_tag);
+    };
+    using T = std::true_type;
+    using F = std::false_type;
+    if (mode == 0) { if (fuse) by_seg(std::integral_constant<int, 0>{}, T{}); else by_seg(std::integral_constant<int, 0>{}, F{}); }
+    else if (mode == 1) by_seg(std::integral_constant<int, 1>{}, F{});
+    else { if (fuse) by_seg(std::integral_constant<int, 2>{}, T{}); else by_seg(std::integral_constant<int, 2>{}, F{}); }
+    if (obs.width > 0 && !fuse) {
+      MYTHOS_HIP_TRY(hipGetLastError());
+      if (int rc = observables_launch(oset, obs, c, q, nf, obs_out + (size_t)f0 * obs.width, stream)) return rc;
+    }
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
                        e_terms + (size_t)f0 * T_COUNT);
