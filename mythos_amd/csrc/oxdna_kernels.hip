@@ -10,6 +10,8 @@
 // tiny kernel sums the partials in a fixed order, so e_terms are run-to-run reproducible.
 // Roofline: HBM; algorithmic bytes per frame = (7 s + 4) N + 4 (nbar + 2) N  read,
 // 7 s N + 8*8 + 8 K written (s = sizeof(real)).
+#include <cstdlib>
+
 #include "observables.h"
 #include "oxdna_gather.h"
 
@@ -274,7 +276,11 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     pseq.marg = (const R*)sys->d_ps_marg, pseq.unit = sys->d_ps_unit, pseq.bp = (const R*)sys->d_ps_bp, pseq.terms = sys->pseq_terms;
   }
   // LDS lists of the row walk: a row is walked in segments of list_cap entries (gather_row)
-  const int list_cap = std::min(sys->row_stride, kEnergyListCap);
+  int list_cap = std::min(sys->row_stride, kEnergyListCap);
+  if (const char* ov = getenv("MYTHOS_ENERGY_LIST_CAP")) {  // test hook: short segments on small systems
+    const int v = atoi(ov);
+    if (v >= 8 && v <= kEnergyListCap) list_cap = std::min(list_cap, v);
+  }
   ObsView obs;  // width 0: no epilogue
   if (oset && obs_out) {
     if (int rc = obs_view_for(oset, n_frames, &obs)) return rc;
