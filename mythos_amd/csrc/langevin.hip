@@ -613,6 +613,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
         if (wave == 0) {
           bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else if (wave != 3) {
+#ifdef MYTHOS_MD_EXP_HALF_ITEMS  // (dev experiment, WRONG physics: the step's cost if ONE wavefront's sweep covered the base-pair list)
+          if (wave == 1)
+#endif
           unbonded_angular<R, MODEL, true, NoPG, 3>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else {
           unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
