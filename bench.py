@@ -345,7 +345,7 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     # ---- instrumented pass (untimed): duration of the step kernel from HIP events attached to sampled dispatches on
     #      the launch stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
     integ.set_timing(16)
-    integ.advance(max(args.steps, 64))
+    integ.advance(max(args.steps, 512))  # sampled dispatches far apart: a bracketed one disturbs the few behind it
     timing = integ.last_kernel_ms()
     integ.set_timing(0)
     integ.store(c, q, p, L)
