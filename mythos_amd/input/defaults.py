@@ -1,7 +1,7 @@
-"""Default oxDNA1 / oxDNA2 parameter tables, restated as Python data.
+"""Default oxDNA1 / oxDNA2 / oxRNA2 parameter tables, restated as Python data.
 
 Values restate the reference's TOML tables
-(mythos/input/dna1/default_energy.toml, mythos/input/dna2/default_energy.toml,
+(mythos/input/dna1/default_energy.toml, mythos/input/dna2/default_energy.toml, mythos/input/rna2/default_energy.toml,
 mythos/input/dna{1,2}/default_simulation.toml); expressions the TOML writes as
 strings ("pi - 2.35") are evaluated here with ``math.pi`` in fp64.  A TOML file
 with the same section/key layout can be loaded with :func:`parse_toml`.
@@ -167,6 +167,49 @@ DNA2_ENERGY = {
     "debye": {"q_eff": 0.815, "lambda_factor": 0.3616455075438555, "prefactor_coeff": 0.08173808693529228},
 }
 
+def _rna2_stacking() -> dict:
+    d = {"eps_stack_base": 1.40206, "eps_stack_kt_coeff": 2.77, "a_stack": 6.0, "dr0_stack": 0.43, "dr_c_stack": 0.93,
+         "dr_low_stack": 0.35, "dr_high_stack": 0.78, "a_stack_1": 2.00, "neg_cos_phi1_star_stack": -0.65, "a_stack_2": 2.00,
+         "neg_cos_phi2_star_stack": -0.65}
+    for k, (t0, ds, a) in {5: (0.0, 0.95, 0.90), 6: (0.0, 0.95, 0.90), 9: (0.0, 0.8, 1.3), 10: (0.0, 0.8, 1.3)}.items():
+        d[f"theta0_stack_{k}"], d[f"delta_theta_star_stack_{k}"], d[f"a_stack_{k}"] = t0, ds, a
+    return d
+
+
+def _rna2_cross_stacking() -> dict:
+    d = {"k_cross": 59.9626, "r0_cross": 0.5, "dr_c_cross": 0.6, "dr_low_cross": 0.42, "dr_high_cross": 0.58}
+    for k, (t0, ds, a) in {1: (0.505, 0.58, 2.25), 2: (1.266, 0.68, 1.70), 3: (1.266, 0.68, 1.70), 7: (0.309, 0.68, 1.70),
+                           8: (0.309, 0.68, 1.70)}.items():
+        d[f"theta0_cross_{k}"], d[f"delta_theta_star_cross_{k}"], d[f"a_cross_{k}"] = t0, ds, a
+    return d
+
+
+def _rna2_coaxial() -> dict:
+    d = {"k_coax": 80.0, "dr0_coax": 0.5, "dr_c_coax": 0.6, "dr_low_coax": 0.42, "dr_high_coax": 0.58,
+         "a_coax_3p": 2.0, "cos_phi3_star_coax": -0.65, "a_coax_4p": 2.0, "cos_phi4_star_coax": -0.65}
+    for k, (t0, ds, a) in {4: (0.151, 0.8, 1.30), 1: (2.592, 0.65, 2.00), 5: (0.685, 0.95, 0.90), 6: (0.685, 0.95, 0.90)}.items():
+        d[f"theta0_coax_{k}"], d[f"delta_theta_star_coax_{k}"], d[f"a_coax_{k}"] = t0, ds, a
+    return d
+
+
+# oxRNA2 (mythos/input/rna2/default_energy.toml): the oxDNA1 term set with its own numbers, a backbone site off a1 and
+# a3, separate 3' / 5' stacking sites, the p3 / p5 vectors of its stacking term, and Debye-Hueckel
+RNA2_ENERGY = {
+    "geometry": {
+        "pos_stack": 0.34, "pos_base": 0.4, "pos_back_a1": -0.4, "pos_back_a3": 0.2, "pos_back_a2": 0.0,
+        "pos_stack_3_a1": 0.4, "pos_stack_3_a2": 0.1, "pos_stack_5_a1": 0.124906078525, "pos_stack_5_a2": -0.00866274917473,
+        "p5_x": -0.104402, "p5_y": -0.841783, "p5_z": 0.529624, "p3_x": -0.462510, "p3_y": -0.528218, "p3_z": 0.712089,
+    },
+    "fene": {**_FENE, "r0_backbone": 0.761070781051},
+    "bonded_excluded_volume": dict(_COMMON_EXC_BONDED),
+    "stacking": _rna2_stacking(),
+    "unbonded_excluded_volume": dict(_COMMON_EXC_UNBONDED),
+    "hydrogen_bonding": _hydrogen_bonding(0.870439),
+    "cross_stacking": _rna2_cross_stacking(),
+    "coaxial_stacking": _rna2_coaxial(),
+    "debye": {"q_eff": 1.26, "lambda_factor": 0.3667258, "prefactor_coeff": 0.05404383975812547},
+}
+
 _SIM_COMMON = {
     "kT": 296.15 * 0.1 / 300.0,
     "dt": 5e-3,
@@ -179,6 +222,8 @@ _SIM_COMMON = {
 }
 DNA1_SIMULATION = dict(_SIM_COMMON)
 DNA2_SIMULATION = {**_SIM_COMMON, "salt_conc": 0.5, "half_charged_ends": 1}
+# the reference ships no rna2 simulation TOML; its golden run (data/test-data/rna2/*/input) is at salt 1.0, whole end charges
+RNA2_SIMULATION = {**_SIM_COMMON, "salt_conc": 1.0, "half_charged_ends": 0}
 
 
 def default_configs_for(base: str) -> tuple[dict, dict]:
@@ -190,7 +235,9 @@ def default_configs_for(base: str) -> tuple[dict, dict]:
         return copy.deepcopy(DNA1_SIMULATION), copy.deepcopy(DNA1_ENERGY)
     if base == "dna2":
         return copy.deepcopy(DNA2_SIMULATION), copy.deepcopy(DNA2_ENERGY)
-    raise ValueError(f"unknown model '{base}' (expected 'dna1' or 'dna2')")
+    if base == "rna2":
+        return copy.deepcopy(RNA2_SIMULATION), copy.deepcopy(RNA2_ENERGY)
+    raise ValueError(f"unknown model '{base}' (expected 'dna1', 'dna2' or 'rna2')")
 
 
 # ---------------------------------------------------------------------------------------------

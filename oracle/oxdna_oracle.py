@@ -300,7 +300,10 @@ def init_stacking(p):
     (q["b_low_stack"], q["dr_c_low_stack"], q["b_high_stack"], q["dr_c_high_stack"]) = get_f1_smoothing_params(
         q["dr0_stack"], q["a_stack"], q["dr_c_stack"], q["dr_low_stack"], q["dr_high_stack"]
     )
-    for k in (4, 5, 6):
+    # dna1 / dna2: theta 4, 5, 6; rna2 (rna2/stacking.py:60-176): theta 5, 6, 9, 10 - whichever the section holds
+    for k in (4, 5, 6, 9, 10):
+        if f"a_stack_{k}" not in q:
+            continue
         q[f"b_stack_{k}"], q[f"delta_theta_stack_{k}_c"] = get_f4_smoothing_params(
             q[f"a_stack_{k}"], q[f"theta0_stack_{k}"], q[f"delta_theta_star_stack_{k}"]
         )
@@ -334,7 +337,9 @@ def init_cross_stacking(p):
     (q["b_low_cross"], q["dr_c_low_cross"], q["b_high_cross"], q["dr_c_high_cross"]) = get_f2_smoothing_params(
         q["r0_cross"], q["dr_c_cross"], q["dr_low_cross"], q["dr_high_cross"]
     )
-    for k in (1, 2, 3, 4, 7, 8):
+    for k in (1, 2, 3, 4, 7, 8):  # rna2/cross_stacking.py:97-147 has no theta4 block
+        if f"a_cross_{k}" not in q:
+            continue
         q[f"b_cross_{k}"], q[f"delta_theta_cross_{k}_c"] = get_f4_smoothing_params(
             q[f"a_cross_{k}"], q[f"theta0_cross_{k}"], q[f"delta_theta_star_cross_{k}"]
         )
@@ -387,9 +392,11 @@ def init_all(model: int, cfg: dict, kt, salt_conc=0.5, half_charged_ends=True) -
         "unbonded_excluded_volume": init_exc_vol(cfg["unbonded_excluded_volume"], with_backbone=True),
         "hydrogen_bonding": init_hydrogen_bonding(cfg["hydrogen_bonding"]),
         "cross_stacking": init_cross_stacking(cfg["cross_stacking"]),
-        "coaxial_stacking": init_coaxial(cfg["coaxial_stacking"], model),
+        # oxRNA2 composes the dna1 coaxial term (f5 of cos phi3 / phi4) with its own parameters
+        # (rna2/tests/test_integration.py:258-287)
+        "coaxial_stacking": init_coaxial(cfg["coaxial_stacking"], 1 if model == 3 else model),
     }
-    if model == 2:
+    if model in (2, 3):
         out["debye"] = init_debye(
             {**cfg["debye"], "kt": kt, "salt_conc": salt_conc, "half_charged_ends": half_charged_ends}
         )
@@ -416,9 +423,21 @@ class Sites:
     def __init__(self, model: int, geometry: dict, center, a1, a2, a3):
         g = geometry
         self.center, self.a1, self.a2, self.a3 = center, a1, a2, a3
-        self.stack = center + g["com_to_stacking"] * a1
-        self.base = center + g["com_to_hb"] * a1
-        if model == 1:
+        if model != 3:
+            self.stack = center + g["com_to_stacking"] * a1
+            self.base = center + g["com_to_hb"] * a1
+        if model == 3:
+            # oxRNA2 (rna2/nucleotide.py:52-63): backbone offset on a1 and a3, stacking through separate 3' / 5' sites,
+            # and two body-fixed vectors p3 / p5 towards the neighbouring phosphates
+            self.stack = center + g["pos_stack"] * a1
+            self.base = center + g["pos_base"] * a1
+            self.back = center + g["pos_back_a1"] * a1 + g["pos_back_a3"] * a3
+            self.back_dna1 = self.back
+            self.p3 = g["p3_x"] * a1 + g["p3_y"] * a2 + g["p3_z"] * a3
+            self.p5 = g["p5_x"] * a1 + g["p5_y"] * a2 + g["p5_z"] * a3
+            self.stack3 = center + g["pos_stack_3_a1"] * a1 + g["pos_stack_3_a2"] * a2
+            self.stack5 = center + g["pos_stack_5_a1"] * a1 + g["pos_stack_5_a2"] * a2
+        elif model == 1:
             self.back = center + g["com_to_backbone"] * a1
             self.back_dna1 = self.back
         else:
@@ -565,6 +584,31 @@ def pair_stacking(p, s: Sites, seq, bonded, disp):
     return _seq_weights(p, "eps_stack", seq, i, j) * v
 
 
+def pair_stacking_rna2(p, s: Sites, seq, bonded, disp):
+    """rna2/stacking.py:186-292 + rna2/interactions.py:15-135: the stacking sites are the 5' site of nn_i and the 3' site
+    of nn_j, there is no theta4, and theta9 / theta10 measure the backbone vector against the p3 vector of nn_j and
+    the p5 vector of nn_i."""
+    i, j = bonded[:, 0], bonded[:, 1]
+    dr_stack = disp(s.stack5[i], s.stack3[j])
+    r_stack = _norm(dr_stack)
+    theta5 = PI - torch.acos(clamp(_dot(dr_stack, s.a3[j]) / r_stack))
+    theta6 = PI - torch.acos(clamp(_dot(s.a3[i], dr_stack) / r_stack))
+    dr_back = disp(s.back[i], s.back[j])
+    r_back = _norm(dr_back)
+    theta9 = torch.acos(clamp(_dot(-s.p3[j], dr_back) / r_back))
+    theta10 = torch.acos(clamp(_dot(-s.p5[i], dr_back) / r_back))
+    cosphi1 = -_dot(s.a2[i], dr_back) / r_back
+    cosphi2 = -_dot(s.a2[j], dr_back) / r_back
+    v = f1(r_stack, p["dr_low_stack"], p["dr_high_stack"], p["dr_c_low_stack"], p["dr_c_high_stack"], _t(1.0), p["a_stack"],
+           p["dr0_stack"], p["dr_c_stack"], p["b_low_stack"], p["b_high_stack"])
+    for k, th in ((5, theta5), (6, theta6), (9, theta9), (10, theta10)):
+        v = v * f4(th, p[f"theta0_stack_{k}"], p[f"delta_theta_star_stack_{k}"], p[f"delta_theta_stack_{k}_c"], p[f"a_stack_{k}"],
+                   p[f"b_stack_{k}"])
+    v = v * f5(-cosphi1, p["neg_cos_phi1_star_stack"], p["neg_cos_phi1_c_stack"], p["a_stack_1"], p["b_neg_cos_phi1_stack"])
+    v = v * f5(-cosphi2, p["neg_cos_phi2_star_stack"], p["neg_cos_phi2_c_stack"], p["a_stack_2"], p["b_neg_cos_phi2_stack"])
+    return _seq_weights(p, "eps_stack", seq, i, j) * v
+
+
 def pair_exc_vol_unbonded(p, s: Sites, pairs, disp):
     """dna1/unbonded_excluded_volume.py:105-146 + dna1/interactions.py:86-135."""
     i, j = pairs[:, 0], pairs[:, 1]
@@ -641,7 +685,7 @@ def pair_cross_stacking(p, s: Sites, pairs, disp):
         * g(1, t1)
         * g(2, t2)
         * g(3, t3)
-        * (g(4, t4) + g(4, PI - t4))
+        * ((g(4, t4) + g(4, PI - t4)) if "a_cross_4" in p else 1.0)  # no theta4 factor in oxRNA2 (rna2/interactions.py:238-256)
         * (g(7, t7) + g(7, PI - t7))
         * (g(8, t8) + g(8, PI - t8))
     )
@@ -725,15 +769,15 @@ def pair_terms(model, P, center, quat, seq, is_end, bonded, unbonded, box=None, 
     bt = {
         "fene": pair_fene(P["fene"], s, bonded, disp),
         "bonded_excluded_volume": pair_exc_vol_bonded(P["bonded_excluded_volume"], s, bonded, disp),
-        "stacking": pair_stacking(P["stacking"], s, seq, bonded, disp),
+        "stacking": (pair_stacking_rna2 if model == 3 else pair_stacking)(P["stacking"], s, seq, bonded, disp),
     }
     ut = {
         "unbonded_excluded_volume": pair_exc_vol_unbonded(P["unbonded_excluded_volume"], s, unbonded, disp),
         "hydrogen_bonding": pair_hydrogen_bonding(P["hydrogen_bonding"], s, seq, unbonded, disp),
         "cross_stacking": pair_cross_stacking(P["cross_stacking"], s, unbonded, disp),
-        "coaxial_stacking": pair_coaxial(P["coaxial_stacking"], s, unbonded, disp, model),
+        "coaxial_stacking": pair_coaxial(P["coaxial_stacking"], s, unbonded, disp, 1 if model == 3 else model),
     }
-    if model == 2:
+    if model in (2, 3):
         ut["debye"] = pair_debye(P["debye"], s, is_end, unbonded, disp)
     return bt, ut
 
@@ -744,7 +788,7 @@ def energy_terms(model, P, center, quat, seq, is_end, bonded, unbonded, box=None
     Equivalent of ``ComposedEnergyFunction.compute_terms`` (mythos/energy/base.py:312-314).
     """
     bt, ut = pair_terms(model, P, center, quat, seq, is_end, bonded, unbonded, box, axes)
-    names = TERMS_DNA1 if model == 1 else TERMS_DNA2
+    names = TERMS_DNA1 if model == 1 else TERMS_DNA2  # oxRNA2 reports the eight oxDNA2 columns
     both = {**bt, **ut}
     return torch.stack([both[n].sum() for n in names])
 

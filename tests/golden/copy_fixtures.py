@@ -26,6 +26,8 @@ OXDNA_FILES = ("generated.top", "output.dat", "energy.dat", "split_energy.dat", 
 CASES = {
     "dna1": ("simple-helix", "simple-coax", "simple-helix-seq-dep", "helix-4bp"),
     "dna2": ("simple-helix", "simple-coax", "simple-helix-half-charged-ends"),
+    # oxRNA2 (reference tests: mythos/energy/rna2/tests/test_integration.py)
+    "rna2": ("simple-helix-12bp", "simple-coax"),
 }
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
          # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)

@@ -41,9 +41,14 @@ TERM_ATOL = {
 }
 
 
+def model_dir(model: int) -> str:
+    """1 -> dna1, 2 -> dna2, 3 -> rna2 (the model numbers of the C ABI)."""
+    return {1: "dna1", 2: "dna2", 3: "rna2"}[model]
+
+
 @functools.lru_cache(maxsize=None)
 def load_golden(model: int, name: str, top_file: str = "generated.top"):
-    base = GOLDEN / f"dna{model}" / name
+    base = GOLDEN / model_dir(model) / name
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         top = topology.from_oxdna_file(base / top_file)
@@ -72,7 +77,7 @@ def read_ss_weights(path) -> dict:
 
 
 def oracle_params(model: int, *, half_charged_ends=False, overrides=None, kt=None, salt=0.5):
-    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    sim, cfg = defaults.default_configs_for(model_dir(model))
     for sec, d in (overrides or {}).items():
         cfg[sec].update(d)
     return orc.init_all(model, cfg, kt=sim["kT"] if kt is None else kt, salt_conc=salt, half_charged_ends=half_charged_ends)

@@ -104,3 +104,18 @@ def test_pair_dat(model, name, hce):
                     tol = 2e-4 if term in ("hydrogen_bonding", "cross_stacking") else 2e-6
                     rtol = 3e-4 if term == "debye" else 1e-5
                     assert abs(ours[k] - val) <= tol + rtol * abs(val), (term, f, i, j, ours[k], val)
+
+
+@pytest.mark.parametrize("name", ["simple-helix-12bp", "simple-coax"])
+def test_oxrna2_terms_and_total(name):
+    """mythos/energy/rna2/tests/test_integration.py:85-325: the eight oxRNA2 terms (dna1 FENE / excluded volumes / H-bond /
+    coaxial with RNA numbers, rna2 stacking and cross-stacking, dna2 Debye at salt 1.0 with whole end charges) against
+    oxDNA's split energies at the reference's tolerances; the total against energy.dat."""
+    top, traj, split, energy = H.load_golden(3, name)
+    P = H.oracle_params(3, half_charged_ends=False, salt=1.0)
+    e = H.oracle_terms_traj(3, P, top, traj)
+    assert e.shape == (100, 8)
+    for k, term in enumerate(H.SPLIT_COLUMNS[1:9]):
+        np.testing.assert_allclose(np.around(e[:, k], 6), split[:, 1 + k], atol=H.TERM_ATOL[term] + 5e-7, err_msg=term)
+    np.testing.assert_allclose(e.sum(1), energy, atol=1e-3)
+    assert np.abs(split[:, 3]).max() > 0.5 and np.abs(split[:, 6]).max() > 0.03  # stacking and cross-stacking are live
