@@ -71,7 +71,8 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
 
 /* ---- system ---------------------------------------------------------------------------------
  * Replaces BaseEnergyFunction.__post_init__ topology capture (mythos/energy/base.py:133-140).
- *   model     1 = oxDNA1, 2 = oxDNA2
+ *   model     1 = oxDNA1, 2 = oxDNA2, 3 = oxRNA2 (mythos/energy/rna2/: backbone site on a1 and a3, stacking between the
+ *             3' / 5' sites with theta9 / theta10, cross-stacking without theta4, oxDNA1-form coaxial term, Debye-Hueckel)
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
  *   bonded    host int32[n_bonded][2] rows (nn_i, nn_j) as mythos/input/topology.py:166-183
@@ -125,7 +126,8 @@ int mythos_oxdna_energy(mythos_system_t* sys, const void* center, const void* qu
 /* ---- per-frame structural observables ------------------------------------------------------------
  * Replaces mythos/observables/propeller.py:19-71, pitch.py:33-102, rise.py:21-80 and the per-state part of
  * persistence_length.py:47-91, 168-185 (base.py:24-66 for the local helical axis and the quartets).
- *   geometry    host double[3]: com_to_hb, backbone offset along a1, backbone offset along a2 (0 for oxDNA1)
+ *   geometry    host double[3]: com_to_hb, backbone offset along a1, backbone offset along a2 (0 for oxDNA1; for
+ *               oxRNA2, model 3, the offset along a3)
  *   box         host double[3] periodic box of the displacement function, or NULL (free space)
  *   base_pairs  host int32[n_bp][2]       hydrogen-bonded pairs of the propeller twist
  *   quartets    host int32[n_q][2][2]     adjacent base pairs ((a1, b1), (a2, b2)) of rise / pitch / persistence length

@@ -48,7 +48,7 @@ const char* mythos_oxdna_param_name(int index) {
 mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded,
                                      const int32_t* bonded, const double* box, int dtype, int device) {
   g_last_error.clear();
-  if ((model != 1 && model != 2) || n < 1 || !seq || n_bonded < 0 || (n_bonded > 0 && !bonded) ||
+  if ((model < 1 || model > 3) || n < 1 || !seq || n_bonded < 0 || (n_bonded > 0 && !bonded) ||
       (dtype != MYTHOS_F32 && dtype != MYTHOS_F64) || n >= ROW_ROLE_Q) {
     set_error("mythos_oxdna_create: invalid argument");
     return nullptr;

@@ -327,9 +327,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   const F3P<R> f_bb = f3_params<R>(P, NEXC_BACKBONE_RSTAR), f_base = f3_params<R>(P, NEXC_BASE_RSTAR);
   const F3P<R> f_bkba = f3_params<R>(P, NEXC_BACK_BASE_RSTAR), f_babk = f3_params<R>(P, NEXC_BASE_BACK_RSTAR);
   const R eps_n = P[NEXC_EPS];
-  const R tw_n = P[TW_NEXC], tw_dh = (MODEL == 2) ? P[TW_DH] : R(0);
-  const bool half_ends = (MODEL == 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
-  const DebyeP<R> dhp = (MODEL == 2) ? debye_params<R>(P) : DebyeP<R>{};
+  const R tw_n = P[TW_NEXC], tw_dh = (MODEL >= 2) ? P[TW_DH] : R(0);
+  const bool half_ends = (MODEL >= 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
+  const DebyeP<R> dhp = (MODEL >= 2) ? debye_params<R>(P) : DebyeP<R>{};
   int n_items[2] = {0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
             const FD<R> v = f3_eval(r, eps_n, f_bb);
             R dVdr = tw_n * v.d;
             R en = v.f;
-            if constexpr (MODEL == 2) {
+            if constexpr (MODEL >= 2) {
               const FD<R> dh = debye_eval(r, dhp);
               R mult = R(1);
               if (half_ends) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
           const R r = m_sqrt(r2);
           const FD<R> v = f3_eval(r, eps_n, f_bb);
           R dVdr = tw_n * v.d;
-          if constexpr (MODEL == 2) {
+          if constexpr (MODEL >= 2) {
             const FD<R> dh = debye_eval(r, dhp);
             R mult = R(1);
             if (half_ends) {
@@ -682,6 +682,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     axpy(sg.g1, -P[GEO_BACK_A1], rbk);
     axpy(sg.g1, -P[GEO_BASE], rba);
     if constexpr (MODEL == 2) axpy(sg.g2, -P[GEO_BACK_A2], rbk);
+    if constexpr (MODEL == 3) axpy(sg.g3, -P[GEO_BACK_A2], rbk);  // oxRNA2: the backbone site's second axis is a3
   }
   if constexpr (SAVE) {
     group_reduce<G, R, true>(e, sg);
@@ -724,7 +725,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
       sg.g3 = V3<R>{fr[9], fr[10], fr[11]};
     }
     const R g_k1 = P[GEO_BACK_A1];
-    const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+    const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
     const V3<R> F = -sg.dc;
     const V3<R> tl = axes_grad_to_torque(self, sg);
     const R tb[3] = {dot(self.a1, tl), dot(self.a2, tl), dot(self.a3, tl)};
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     R dxa[3] = {R(0), R(0), R(0)};                                      // this step's displacement
     R* const xd = kHiLo<R> ? dxa : x;
     V3<R> n1 = self.a1, n2 = self.a2, n3 = self.a3;
+    V3<R> nbk = (MODEL == 3) ? n3 : n2;  // second axis of the backbone site (a2; a3 in oxRNA2)
     if (do_step && !(ablate & 4)) {
       p[0] += K.half_dt * F.x;
       p[1] += K.half_dt * F.y;
@@ -792,12 +794,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
       qs[3] *= inv;
       if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
       quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
+      nbk = (MODEL == 3) ? n3 : n2;
       if (K.skin_half_sq > R(0)) {
         // the list is valid while neither the centre nor the backbone and base sites (the segments are selected
         // by site distances, and a rotation moves the sites) have travelled more than skin / 2 since the build
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
-        const R bx = dx + (g_k1 * n1.x + g_k2 * n2.x - f0.x), by = dy + (g_k1 * n1.y + g_k2 * n2.y - f0.y),
-                bz = dz + (g_k1 * n1.z + g_k2 * n2.z - f0.z);
+        const R bx = dx + (g_k1 * n1.x + g_k2 * nbk.x - f0.x), by = dy + (g_k1 * n1.y + g_k2 * nbk.y - f0.y),
+                bz = dz + (g_k1 * n1.z + g_k2 * nbk.z - f0.z);
         // base site c + g_base a1 (the stacking site lies between it and the centre)
         const R gb = P[GEO_BASE];
         const R sx = dx + gb * (n1.x - a0.x), sy = dy + gb * (n1.y - a0.y), sz = dz + gb * (n1.z - a0.z);
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     out.p2[i] = V4{n3.x, n3.y, n3.z, R(0)};
     // (a closing-only launch hands the frame on unchanged, bit for bit: the offset is copied, not re-derived from
     // axes whose cross product may round differently - advance(a); advance(b) then equals advance(a + b) exactly)
-    out.p3[i] = do_step ? V4{g_k1 * n1.x + g_k2 * n2.x, g_k1 * n1.y + g_k2 * n2.y, g_k1 * n1.z + g_k2 * n2.z, R(0)} : in.p3[i];
+    out.p3[i] = do_step ? V4{g_k1 * n1.x + g_k2 * nbk.x, g_k1 * n1.y + g_k2 * nbk.y, g_k1 * n1.z + g_k2 * nbk.z, R(0)} : in.p3[i];
     out.q[i] = V4{qs[0], qs[1], qs[2], qs[3]};
     out.mom[i] = V4{p[0], p[1], p[2], R(0)};
     out.ang[i] = V4{L[0], L[1], L[2], R(0)};
@@ -845,7 +848,7 @@ __global__ void reduce_trace_kernel(const double* __restrict__ part, int n_block
 }
 
 // ------------------------------------------------------------------ packed (N,3)/(N,4) <-> frame
-template <typename R>
+template <typename R, int BX>
 __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c, const R* __restrict__ q,
                                   const R* __restrict__ p, const R* __restrict__ l, const int* __restrict__ meta,
                                   const Frame<R> f, const R* __restrict__ keep_hi, const R* __restrict__ keep_lo) {
@@ -872,7 +875,8 @@ __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c
   f.p0[i] = V4{c[3 * i], c[3 * i + 1], c[3 * i + 2], R(meta[i])};
   f.p1[i] = V4{a1.x, a1.y, a1.z, R(0)};
   f.p2[i] = V4{a3.x, a3.y, a3.z, R(0)};
-  f.p3[i] = V4{g_k1 * a1.x + g_k2 * a2.x, g_k1 * a1.y + g_k2 * a2.y, g_k1 * a1.z + g_k2 * a2.z, R(0)};
+  const V3<R> ab = BX == 3 ? a3 : a2;  // second axis of the backbone site
+  f.p3[i] = V4{g_k1 * a1.x + g_k2 * ab.x, g_k1 * a1.y + g_k2 * ab.y, g_k1 * a1.z + g_k2 * ab.z, R(0)};
   f.q[i] = V4{q0, q1, q2, q3};
   f.mom[i] = V4{p[3 * i], p[3 * i + 1], p[3 * i + 2], R(0)};
   f.ang[i] = V4{l[3 * i], l[3 * i + 1], l[3 * i + 2], R(0)};
@@ -1007,7 +1011,7 @@ template <typename R>
 static MdCut<R> make_cut(const mythos_system* sys) {
   const OxParams<double>& P = sys->pd;
   double rbb = P[NEXC_BACKBONE_RC];
-  if (sys->model == 2) rbb = std::max(rbb, (double)P[DH_RCUT]);
+  if (sys->model >= 2) rbb = std::max(rbb, (double)P[DH_RCUT]);
   const double rcom = oxdna_close_range(sys);
   MdCut<R> c;
   c.rbb2 = R(rbb * rbb);
@@ -1049,10 +1053,10 @@ static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* 
   const int n = sys->n;
   const int tb = (n + 255) / 256;
   const OxParams<R>& P = params_of<R>(sys);
-  const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
   sim->cur = 0;
   const Frame<R> f0 = frame_of<R>(sim, 0);
-  hipLaunchKernelGGL(pack_state_kernel<R>, dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
+  hipLaunchKernelGGL((pack_state_kernel<R, back_axis<MODEL>()>), dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
                      sys->d_meta, f0, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
                      (const R*)sim->keep_lo);
   MYTHOS_HIP_TRY(hipGetLastError());
@@ -1066,7 +1070,6 @@ static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* 
 // The resident frames -> caller's arrays (asynchronous on st; the state stays resident).
 template <typename R>
 static int store_typed(mythos_sim* sim, R* center, R* quat, R* p_lin, R* p_ang, hipStream_t st) {
-  using V4 = typename Vec4T<R>::type;
   const int n = sim->sys->n;
   hipLaunchKernelGGL(unpack_state_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, frame_of<R>(sim, sim->cur),
                      center, quat, p_lin, p_ang, (R*)sim->keep_hi, (R*)sim->keep_lo);
@@ -1403,19 +1406,23 @@ int md_ready(mythos_sim_t* s, const char* who) {
 int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
   mythos_system* sys = s->sys;
   if (sys->dtype == MYTHOS_F32)
-    return sys->model == 1 ? load_typed<float, 1>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
-                           : load_typed<float, 2>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
-  return sys->model == 1 ? load_typed<double, 1>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
-                         : load_typed<double, 2>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
+    return sys->model == 1   ? load_typed<float, 1>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+           : sys->model == 2 ? load_typed<float, 2>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+                             : load_typed<float, 3>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
+  return sys->model == 1   ? load_typed<double, 1>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
+         : sys->model == 2 ? load_typed<double, 2>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
+                           : load_typed<double, 3>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
 }
 
 int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
   mythos_system* sys = s->sys;
   if (sys->dtype == MYTHOS_F32)
-    return sys->model == 1 ? advance_typed<float, 1>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
-                           : advance_typed<float, 2>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st);
-  return sys->model == 1 ? advance_typed<double, 1>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
-                         : advance_typed<double, 2>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
+    return sys->model == 1   ? advance_typed<float, 1>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
+           : sys->model == 2 ? advance_typed<float, 2>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
+                             : advance_typed<float, 3>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st);
+  return sys->model == 1   ? advance_typed<double, 1>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
+         : sys->model == 2 ? advance_typed<double, 2>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
+                           : advance_typed<double, 3>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
 }
 
 int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {

@@ -138,7 +138,7 @@ inline int* row_close_of(const mythos_system* sys) { return sys->d_row_len + (si
 inline double oxdna_close_range(const mythos_system* sys) {
   const OxParams<double>& P = sys->pd;
   const double off_back =
-      std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model == 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
+      std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model >= 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
   const double off_base = std::fabs(P[GEO_BASE]), off_stack = std::fabs(P[GEO_STACK]);
   double rcom = std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]) + off_back + off_base;
   rcom = std::max(rcom, P[NEXC_BASE_RC] + 2 * off_base);

@@ -349,7 +349,7 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   double rbb = rl;
   if (off && sys->params_set) {
     rbb = sys->pd[NEXC_BACKBONE_RC];
-    if (sys->model == 2) rbb = std::max(rbb, (double)sys->pd[DH_RCUT]);
+    if (sys->model >= 2) rbb = std::max(rbb, (double)sys->pd[DH_RCUT]);
     rbb = std::min(rl, rbb + skin);
   }
   if (!sys->params_set || !a1) off = nullptr;

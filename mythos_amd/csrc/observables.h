@@ -34,7 +34,7 @@ struct ObsView {
   int n_corr = 0;                 // n_q - 2 * skip (>= 0)
   int width = 0;                  // 4 + n_corr; 0 = no observables
   int model = 2;
-  double g_hb = 0, g_k1 = 0, g_k2 = 0;  // base site c + g_hb a1; backbone site c + g_k1 a1 + g_k2 a2
+  double g_hb = 0, g_k1 = 0, g_k2 = 0;  // base site c + g_hb a1; backbone site c + g_k1 a1 + g_k2 a2 (model 3: g_k2 a3)
   int box_on = 0;
   double box[3] = {1, 1, 1};
 };
@@ -107,9 +107,10 @@ __device__ __forceinline__ void frame_observables(const ObsView& v, const R* __r
     rise += ddot(dr, ax) * kAngstromPerOxdnaLength;
     if (k >= v.skip && k < v.n_q - v.skip) l0 += norm;
     // backbone-backbone vectors of the two pairs, helical component removed
-    auto back = [&](D3 c, D3 a1, D3 a2) { return c + v.g_k1 * a1 + v.g_k2 * a2; };
-    D3 bb1 = obs_min_image(back(c2, x2, y2) - back(c1, x1, y1), v);
-    D3 bb2 = obs_min_image(back(c4, x4, y4) - back(c3, x3, y3), v);
+    auto back = [&](D3 c, D3 a1, D3 ab) { return c + v.g_k1 * a1 + v.g_k2 * ab; };
+    const bool on_a3 = v.model == 3;  // oxRNA2 backbone site: second coefficient on a3 (rna2/nucleotide.py:56)
+    D3 bb1 = obs_min_image(back(c2, x2, on_a3 ? z2 : y2) - back(c1, x1, on_a3 ? z1 : y1), v);
+    D3 bb2 = obs_min_image(back(c4, x4, on_a3 ? z4 : y4) - back(c3, x3, on_a3 ? z3 : y3), v);
     bb1 = obs_min_image(bb1 - ddot(ax, bb1) * ax, v);
     bb2 = obs_min_image(bb2 - ddot(ax, bb2) * ax, v);
     const double c = ddot(bb1, bb2) / sqrt(ddot(bb1, bb1) * ddot(bb2, bb2));

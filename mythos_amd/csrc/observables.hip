@@ -50,7 +50,7 @@ extern "C" {
 mythos_obs_t* mythos_observables_create(int model, int n, const double* geometry, const double* box, int n_bp,
                                         const int32_t* base_pairs, int n_quartets, const int32_t* quartets, int skip_ends,
                                         int dtype, int device) {
-  if ((model != 1 && model != 2) || n <= 0 || !geometry || n_bp < 0 || n_quartets < 0 || (n_bp > 0 && !base_pairs) ||
+  if ((model < 1 || model > 3) || n <= 0 || !geometry || n_bp < 0 || n_quartets < 0 || (n_bp > 0 && !base_pairs) ||
       (n_quartets > 0 && !quartets) || (dtype != MYTHOS_F32 && dtype != MYTHOS_F64)) {
     set_error("mythos_observables_create: invalid argument");
     return nullptr;
@@ -77,7 +77,7 @@ mythos_obs_t* mythos_observables_create(int model, int n, const double* geometry
   v.n_corr = std::max(0, n_quartets - 2 * v.skip);
   v.width = 4 + v.n_corr;
   v.model = model;
-  v.g_hb = geometry[0], v.g_k1 = geometry[1], v.g_k2 = model == 2 ? geometry[2] : 0.0;
+  v.g_hb = geometry[0], v.g_k1 = geometry[1], v.g_k2 = model >= 2 ? geometry[2] : 0.0;
   if (box) {
     v.box_on = 1;
     for (int k = 0; k < 3; ++k) v.box[k] = box[k];

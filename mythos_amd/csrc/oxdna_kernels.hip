@@ -37,7 +37,10 @@ __device__ __forceinline__ int pg_copy_of(unsigned int tid) { return (int)(tid %
 __device__ __forceinline__ int pg_copy_of(unsigned int tid) { return (int)((tid >> 6) * 2u + (tid & 1u)); }
 #endif
 static_assert(kPgCopies == 2 * (256 / 64), "two accumulator copies per wavefront of the 256-thread workgroup");
-constexpr int kPgStride = OXP_COUNT + 1;  // odd stride in doubles: the copies of one parameter land in different bank pairs
+template <int MODEL>
+constexpr int pg_stride() {  // one past the count (242 doubles for oxDNA): the copies of one parameter land in different bank pairs
+  return oxp_used<MODEL>() + 1;
+}
 struct LdsPG {
   static constexpr bool on = true;
   double* acc;  // this lane's copy
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
   extern __shared__ int item_lds[];  // [PPB][2][list_cap]: per group, the near and the angular entries of a row segment (gather_row)
+  constexpr int kPgStride = pg_stride<MODEL>(), kPgUsed = oxp_used<MODEL>();
   __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
@@ -204,11 +208,11 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
     e_part[bo * T_COUNT + threadIdx.x] = s;
   }
   if constexpr (MODE == 2) {
-    for (int k = threadIdx.x; k < OXP_COUNT; k += kBlock) {
+    for (int k = threadIdx.x; k < kPgUsed; k += kBlock) {
       double s = 0.0;
 #pragma unroll
       for (int c = 0; c < kPgCopies; ++c) s += pg_lds[c * kPgStride + k];  // fixed order
-      pg_part[bo * OXP_COUNT + k] = s;
+      pg_part[bo * kPgUsed + k] = s;
     }
   }
   // ---- epilogue: the frame's structural observables, by the first workgroup of the frame (observables.h).  The
@@ -222,15 +226,17 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   }
 }
 
-// out[frame][k] = sum_b part[frame][b][k], fixed order
+// out[frame][k] = sum_b part[frame][b][k] for k < width, fixed order; 0 for width <= k < out_width
 __global__ void reduce_partials_kernel(const double* __restrict__ part, int n_blocks, int width,
-                                       double* __restrict__ out) {
+                                       double* __restrict__ out, int out_width) {
   const int frame = blockIdx.x;
-  for (int k = threadIdx.x; k < width; k += blockDim.x) {
+  for (int k = threadIdx.x; k < out_width; k += blockDim.x) {
     double s = 0.0;
-    const double* p = part + (size_t)frame * n_blocks * width + k;
-    for (int b = 0; b < n_blocks; ++b) s += p[(size_t)b * width];
-    out[(size_t)frame * width + k] = s;
+    if (k < width) {
+      const double* p = part + (size_t)frame * n_blocks * width + k;
+      for (int b = 0; b < n_blocks; ++b) s += p[(size_t)b * width];
+    }
+    out[(size_t)frame * out_width + k] = s;
   }
 }
 
@@ -266,8 +272,8 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   const OxParams<double>& Pd = sys->pd;
   double range = std::max({(double)Pd[NEXC_BACKBONE_RC], (double)Pd[NEXC_BASE_RC], (double)Pd[NEXC_BACK_BASE_RC],
                            (double)Pd[NEXC_BASE_BACK_RC], (double)Pd[HYDR_RCHIGH], (double)Pd[CRST_RCHIGH], (double)Pd[CXST_RCHIGH]});
-  if (MODEL == 2) range = std::max(range, (double)Pd[DH_RCUT]);
-  const double reach = std::max({std::hypot((double)Pd[GEO_BACK_A1], MODEL == 2 ? (double)Pd[GEO_BACK_A2] : 0.0),
+  if (MODEL >= 2) range = std::max(range, (double)Pd[DH_RCUT]);
+  const double reach = std::max({std::hypot((double)Pd[GEO_BACK_A1], MODEL >= 2 ? (double)Pd[GEO_BACK_A2] : 0.0),
                                  std::fabs((double)Pd[GEO_BASE]), std::fabs((double)Pd[GEO_STACK])});
   const double rnear = (range + 2.0 * reach) * (1.0 + 1e-4) + 1e-4;
   const R rnear2 = R(rnear * rnear);
@@ -317,10 +323,10 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     }
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
-                       e_terms + (size_t)f0 * T_COUNT);
+                       e_terms + (size_t)f0 * T_COUNT, (int)T_COUNT);
     if (mode == 2)
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(256), 0, stream, sys->d_pgpart, blocks,
-                         (int)OXP_COUNT, dU_dparams + (size_t)f0 * OXP_COUNT);
+                         oxp_used<MODEL>(), dU_dparams + (size_t)f0 * OXP_COUNT, (int)OXP_COUNT);
     MYTHOS_HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -335,11 +341,17 @@ int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat
     if (sys->model == 1)
       return launch_typed<float, 1, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
                                        (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
+    if (sys->model == 3)
+      return launch_typed<float, 3, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
     return launch_typed<float, 2, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
                                      (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
   }
   if (sys->model == 1)
     return launch_typed<double, 1, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                      (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
+  if (sys->model == 3)
+    return launch_typed<double, 3, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
                                       (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
   return launch_typed<double, 2, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
                                     (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);

@@ -19,6 +19,14 @@ enum OxParamIndex : int {
 #undef OXP
   OXP_COUNT
 };
+// The entries only oxRNA2 reads are at the end of the list: the oxDNA instantiations accumulate, reduce and write
+// parameter partials for the entries before them only (the rest of a dU/dparams row is zero).  With all 261 the
+// per-workgroup reduction of the partials took two passes of the 256 threads where 241 take one (+2 - 4 % per call).
+constexpr int OXP_COUNT_DNA = GEO_STACK3_A1;
+template <int MODEL>
+constexpr int oxp_used() {
+  return MODEL == 3 ? (int)OXP_COUNT : OXP_COUNT_DNA;
+}
 
 // The flat parameter vector on the host (and, for the Debye / cut-off helpers, as a plain array).
 template <typename R>

@@ -128,21 +128,28 @@ struct SelfGrad {  // gradient of U with respect to the owner's centre and axes
   V3<R> dc, g1, g2, g3;
 };
 
-// gd = dV/dd with d = site_other - site_self and site_self = c + al*a1 + be*a2
-template <typename R>
+// Which axis the second coefficient of a site offset multiplies: a2 for oxDNA (dna2/nucleotide.py:44-49: the
+// groove backbone site; the stacking sites of oxRNA2 too), a3 for the oxRNA2 backbone site (rna2/nucleotide.py:56).
+template <int MODEL>
+constexpr int back_axis() {
+  return MODEL == 3 ? 3 : 2;
+}
+
+// gd = dV/dd with d = site_other - site_self and site_self = c + al*a1 + be*a_AX
+template <int AX = 2, typename R>
 __device__ __forceinline__ void acc_self_site(SelfGrad<R>& sg, V3<R> gd, R al, R be) {
   axpy(sg.dc, R(-1), gd);
   axpy(sg.g1, -al, gd);
-  axpy(sg.g2, -be, gd);
+  if constexpr (AX == 3) axpy(sg.g3, -be, gd); else axpy(sg.g2, -be, gd);
 }
 
-template <typename R>
+template <int AX = 2, typename R>
 __device__ __forceinline__ V3<R> site_disp(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o, R als, R bes, R alo, R beo) {
   V3<R> d = dco;
   axpy(d, alo, o.a1);
-  axpy(d, beo, o.a2);
+  axpy(d, beo, AX == 3 ? o.a3 : o.a2);
   axpy(d, -als, s.a1);
-  axpy(d, -bes, s.a2);
+  axpy(d, -bes, AX == 3 ? s.a3 : s.a2);
   return d;
 }
 
@@ -154,13 +161,13 @@ __device__ __forceinline__ void acc_dir(V3<R>& gd, R coef, R sg, R c, V3<R> u, V
 }
 
 // one radial f3 site pair: energy, self gradient, parameter partials
-template <typename R, bool GRAD, class PG, class PT>
+template <typename R, bool GRAD, class PG, int AX = 2, class PT>
 __device__ __forceinline__ R f3_site_pair(const PT& P, int ie, const F3P<R>& fp, V3<R> d, R als, R bes,
                                           R tw, SelfGrad<R>& sg, PG& pg) {
   const R r = m_sqrt(dot(d, d));
   const FD<R> v = f3_eval(r, P[ie], fp);
   if constexpr (GRAD)
-    if (v.d != R(0)) acc_self_site(sg, (tw * v.d / r) * d, als, bes);
+    if (v.d != R(0)) acc_self_site<AX>(sg, (tw * v.d / r) * d, als, bes);
   f3_pgrad(r, P[ie], ie, fp, tw, pg);
   return v.f;
 }
@@ -171,17 +178,19 @@ __device__ __forceinline__ R f3_site_pair(const PT& P, int ie, const F3P<R>& fp,
 template <typename R, int MODEL, bool GRAD, class PG, class PT>
 __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                             bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  constexpr int BX = back_axis<MODEL>();
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
   const R g_d1 = (MODEL == 2) ? P[GEO_BACK_DNA1] : g_k1;
+  (void)g_st, (void)g_d1;
 
   // ---- FENE on the backbone sites (symmetric)
   {
-    const V3<R> d = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const V3<R> d = site_disp<BX>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
     const R r = m_sqrt(dot(d, d));
     const FD<R> v = fene_eval(r, P);
     e[T_FENE] += wgt * v.f;
-    if constexpr (GRAD) acc_self_site(sg, (P[TW_FENE] * v.d / r) * d, g_k1, g_k2);
+    if constexpr (GRAD) acc_self_site<BX>(sg, (P[TW_FENE] * v.d / r) * d, g_k1, g_k2);
     fene_pgrad(r, P, v.d, P[TW_FENE], pg);
   }
   // ---- bonded excluded volume: base-base, back_p-base_q, base_p-back_q
@@ -189,12 +198,107 @@ __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const 
     R eb = f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params<R>(P, BEXC_BASE_RSTAR),
                                      site_disp(dco, s, o, g_ba, R(0), g_ba, R(0)), g_ba, R(0), P[TW_BEXC], sg, pg);
     // self backbone - other base: "back_p - base_q" if self is p, else "base_p - back_q"
-    eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel<R>(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
-                                    site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_BEXC], sg, pg);
+    eb += f3_site_pair<R, GRAD, PG, BX>(P, BEXC_EPS, f3_params_sel<R>(P, role_p, BEXC_BACK_BASE_RSTAR, BEXC_BASE_BACK_RSTAR),
+                                        site_disp<BX>(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_BEXC], sg, pg);
     eb += f3_site_pair<R, GRAD, PG>(P, BEXC_EPS, f3_params_sel<R>(P, role_p, BEXC_BASE_BACK_RSTAR, BEXC_BACK_BASE_RSTAR),
-                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_BEXC], sg, pg);
+                                    site_disp<BX>(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_BEXC], sg, pg);
     e[T_BEXC] += wgt * eb;
   }
+  // ---- oxRNA2 stacking (rna2/stacking.py:186-292, rna2/interactions.py:15-135): the 5' stacking site of nn_i against the
+  //      3' site of nn_j, no theta4, and theta9 = acos(-p3_q . dr_b / r_b), theta10 = acos(-p5_p . dr_b / r_b) with the
+  //      body-fixed vectors p3 / p5 and dr_b = back_p - back_q on the oxRNA2 backbone sites.  With d = other - self,
+  //      dr = sgm * d (sgm = -1 if self is p): self's own vector gives theta10 if self is p, theta9 if self is q.
+  if constexpr (MODEL == 3) {
+    const R s5a = P[GEO_STACK5_A1], s5b = P[GEO_STACK5_A2], s3a = P[GEO_STACK3_A1], s3b = P[GEO_STACK3_A2];
+    const R als = role_p ? s5a : s3a, bes = role_p ? s5b : s3b, alo = role_p ? s3a : s5a, beo = role_p ? s3b : s5b;
+    const V3<R> ds = site_disp(dco, s, o, als, bes, alo, beo);
+    const R rs = m_sqrt(dot(ds, ds));
+    const FD<R> F1 = f1_eval(rs, P, STCK_RLOW);
+    if (F1.f == R(0) && F1.d == R(0)) return;
+    const R sgm = role_p ? R(-1) : R(1);
+    const R irs = R(1) / rs;
+    const V3<R> ns = irs * ds;
+    const R cs = sgm * dot(s.a3, ns);  // theta6 if p, theta5 if q
+    const R co = sgm * dot(o.a3, ns);  // theta5 if p, theta6 if q
+    FD<R> ts = acos_clamped(cs), to = acos_clamped(co);
+    ts.f = R(kPi) - ts.f;
+    ts.d = -ts.d;
+    to.f = R(kPi) - to.f;
+    to.d = -to.d;
+    const F4P<R> ps = f4_params_sel<R>(P, role_p, STCK_TH6_T0, STCK_TH5_T0);
+    const F4P<R> po = f4_params_sel<R>(P, role_p, STCK_TH5_T0, STCK_TH6_T0);
+    const FD<R> As = f4_eval(ts.f, ps);
+    if (As.f == R(0)) return;
+    const FD<R> Ao = f4_eval(to.f, po);
+    if (Ao.f == R(0)) return;
+    const V3<R> db = site_disp<3>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const R irb = m_rsqrt(dot(db, db));
+    const V3<R> nb = irb * db;
+    // self's vector: p5 if self is p, p3 if self is q; other's the opposite
+    const R vsx = role_p ? P[GEO_P5_X] : P[GEO_P3_X], vsy = role_p ? P[GEO_P5_Y] : P[GEO_P3_Y], vsz = role_p ? P[GEO_P5_Z] : P[GEO_P3_Z];
+    const R vox = role_p ? P[GEO_P3_X] : P[GEO_P5_X], voy = role_p ? P[GEO_P3_Y] : P[GEO_P5_Y], voz = role_p ? P[GEO_P3_Z] : P[GEO_P5_Z];
+    V3<R> vs = vsx * s.a1, vo = vox * o.a1;
+    axpy(vs, vsy, s.a2), axpy(vs, vsz, s.a3);
+    axpy(vo, voy, o.a2), axpy(vo, voz, o.a3);
+    const R cvs = -sgm * dot(vs, nb);  // cos(theta10) if p, cos(theta9) if q
+    const R cvo = -sgm * dot(vo, nb);  // cos(theta9) if p, cos(theta10) if q
+    const FD<R> tvs = acos_clamped(cvs), tvo = acos_clamped(cvo);
+    const F4P<R> pvs = f4_params_sel<R>(P, role_p, STCK_TH10_T0, STCK_TH9_T0);
+    const F4P<R> pvo = f4_params_sel<R>(P, role_p, STCK_TH9_T0, STCK_TH10_T0);
+    const FD<R> Avs = f4_eval(tvs.f, pvs);
+    if (Avs.f == R(0)) return;
+    const FD<R> Avo = f4_eval(tvo.f, pvo);
+    if (Avo.f == R(0)) return;
+    const R xs = sgm * dot(s.a2, nb);  // -cos(phi1) if p, -cos(phi2) if q
+    const R xo = sgm * dot(o.a2, nb);
+    const F5P<R> qs = f5_params_sel<R>(P, role_p, STCK_PHI1_XS, STCK_PHI2_XS);
+    const F5P<R> qo = f5_params_sel<R>(P, role_p, STCK_PHI2_XS, STCK_PHI1_XS);
+    const FD<R> Bs = f5_eval(xs, qs);
+    if (Bs.f == R(0)) return;
+    const FD<R> Bo = f5_eval(xo, qo);
+    if (Bo.f == R(0)) return;
+    const R wseq = seq_weight(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s);
+    const R ang = As.f * Ao.f * Avs.f * Avo.f;
+    const R phi = Bs.f * Bo.f;
+    const R v = F1.f * ang * phi;
+    e[T_STCK] += wgt * wseq * v;
+    const R w = wseq * P[TW_STCK];
+    if constexpr (PG::on) {
+      seq_weight_pgrad(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s, P[TW_STCK] * v, pg);
+      f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
+      f4_pgrad(ts.f, ps, w * F1.f * Ao.f * Avs.f * Avo.f * phi, pg);
+      f4_pgrad(to.f, po, w * F1.f * As.f * Avs.f * Avo.f * phi, pg);
+      f4_pgrad(tvs.f, pvs, w * F1.f * As.f * Ao.f * Avo.f * phi, pg);
+      f4_pgrad(tvo.f, pvo, w * F1.f * As.f * Ao.f * Avs.f * phi, pg);
+      f5_pgrad(xs, qs, w * F1.f * ang * Bo.f, pg);
+      f5_pgrad(xo, qo, w * F1.f * ang * Bs.f, pg);
+    }
+    if constexpr (GRAD) {
+      const R wf = w * F1.f;
+      V3<R> gds{R(0), R(0), R(0)}, gdb{R(0), R(0), R(0)};
+      axpy(gds, w * F1.d * ang * phi, ns);
+      const R ks = wf * Ao.f * Avs.f * Avo.f * phi * As.d * ts.d;
+      axpy(sg.g3, ks * sgm, ns);
+      acc_dir(gds, ks, sgm, cs, s.a3, ns, irs);
+      const R ko = wf * As.f * Avs.f * Avo.f * phi * Ao.d * to.d;
+      acc_dir(gds, ko, sgm, co, o.a3, ns, irs);
+      // cvs = -sgm (vs . nb), vs = vsx a1 + vsy a2 + vsz a3 of self
+      const R kvs = wf * As.f * Ao.f * Avo.f * phi * Avs.d * tvs.d;
+      axpy(sg.g1, -kvs * sgm * vsx, nb);
+      axpy(sg.g2, -kvs * sgm * vsy, nb);
+      axpy(sg.g3, -kvs * sgm * vsz, nb);
+      acc_dir(gdb, kvs, -sgm, cvs, vs, nb, irb);
+      const R kvo = wf * As.f * Ao.f * Avs.f * phi * Avo.d * tvo.d;
+      acc_dir(gdb, kvo, -sgm, cvo, vo, nb, irb);
+      const R kxs = wf * ang * Bo.f * Bs.d;
+      axpy(sg.g2, kxs * sgm, nb);
+      acc_dir(gdb, kxs, sgm, xs, s.a2, nb, irb);
+      const R kxo = wf * ang * Bs.f * Bo.d;
+      acc_dir(gdb, kxo, sgm, xo, o.a2, nb, irb);
+      acc_self_site(sg, gds, als, bes);
+      acc_self_site<3>(sg, gdb, g_k1, g_k2);
+    }
+  } else
   // ---- stacking.  Reference: dr = site_p - site_q, theta5 = pi - acos(dr.a3_q / r),
   //      theta6 = pi - acos(a3_p.dr / r), -cos(phi1) = a2_p.dr_b / r_b, -cos(phi2) = a2_q.dr_b / r_b.
   //      With d = other - self:  dr = -d if self is p, +d if self is q  ->  sign sgm.
@@ -291,18 +395,19 @@ template <typename R, int MODEL, bool GRAD, class PG, class PT>
 __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
+  constexpr int BX = back_axis<MODEL>();
 
   // ---- backbone-backbone: excluded volume and (dna2) Debye-Hueckel share the distance
   {
-    const V3<R> d = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const V3<R> d = site_disp<BX>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
     const R r = m_sqrt(dot(d, d));
     const F3P<R> fp = f3_params<R>(P, NEXC_BACKBONE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     R dVdr = P[TW_NEXC] * v.d;
     f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
-    if constexpr (MODEL == 2) {
+    if constexpr (MODEL >= 2) {  // oxDNA2 and oxRNA2 carry the Debye-Hueckel term
       const FD<R> dh = debye_eval(r, P);
       R mult = R(1);
       if (P[DH_HALF_CHARGED_ENDS] != R(0)) mult = (s.is_end ? R(0.5) : R(1)) * (o.is_end ? R(0.5) : R(1));
@@ -311,14 +416,14 @@ __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, co
       debye_pgrad(r, P, P[TW_DH] * mult, pg);
     }
     if constexpr (GRAD)
-      if (dVdr != R(0)) acc_self_site(sg, (dVdr / r) * d, g_k1, g_k2);
+      if (dVdr != R(0)) acc_self_site<BX>(sg, (dVdr / r) * d, g_k1, g_k2);
   }
   // ---- self backbone - other base ("back_p - base_q" if self is p) and self base - other backbone
   {
-    R en = f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
-                                     site_disp(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_NEXC], sg, pg);
+    R en = f3_site_pair<R, GRAD, PG, BX>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
+                                         site_disp<BX>(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_NEXC], sg, pg);
     en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
-                                    site_disp(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_NEXC], sg, pg);
+                                    site_disp<BX>(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_NEXC], sg, pg);
     e[T_NEXC] += wgt * en;
   }
   // ---- base-base excluded volume
@@ -356,7 +461,9 @@ template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT>
 __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                  bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL == 2) ? P[GEO_BACK_A2] : R(0);
+  const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
+  constexpr int BX = back_axis<MODEL>();
+  constexpr bool kCoaxF5 = MODEL != 2;  // dna1-style coaxial term, f5(cos phi3) f5(cos phi4): oxDNA1 and oxRNA2 (rna2/tests/test_integration.py:258-287)
   (void)g_st;
   (void)g_k1;
   (void)g_k2;
@@ -439,7 +546,9 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
           const F4P<R> p4 = f4_params<R>(P, CRST_TH4_T0);
           const F4P<R> ps3 = f4_params_sel<R>(P, role_p, CRST_TH8_T0, CRST_TH7_T0);
           const F4P<R> po3 = f4_params_sel<R>(P, role_p, CRST_TH7_T0, CRST_TH8_T0);
-          const FD<R> A4a = f4_eval(t4.f, p4), A4b = f4_eval(R(kPi) - t4.f, p4);
+          // (oxRNA2's cross-stacking has no theta4 factor, rna2/interactions.py:238-256: H4 = 1)
+          const FD<R> A4a = (MODEL == 3) ? FD<R>{R(1), R(0)} : f4_eval(t4.f, p4);
+          const FD<R> A4b = (MODEL == 3) ? FD<R>{R(0), R(0)} : f4_eval(R(kPi) - t4.f, p4);
           const FD<R> Sa = f4_eval(ts3.f, ps3), Sb = f4_eval(R(kPi) - ts3.f, ps3);
           const FD<R> Oa = f4_eval(to3.f, po3), Ob = f4_eval(R(kPi) - to3.f, po3);
           const R H4 = A4a.f + A4b.f, Hs = Sa.f + Sb.f, Ho = Oa.f + Ob.f;
@@ -455,8 +564,10 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
               f4_pgrad(t1.f, p1, F2w.f * o1, pg);
               f4_pgrad(ts1.f, ps1, F2w.f * os1, pg);
               f4_pgrad(to1.f, po1, F2w.f * oo1, pg);
-              f4_pgrad(t4.f, p4, F2w.f * o4, pg);
-              f4_pgrad(R(kPi) - t4.f, p4, F2w.f * o4, pg);
+              if constexpr (MODEL != 3) {
+                f4_pgrad(t4.f, p4, F2w.f * o4, pg);
+                f4_pgrad(R(kPi) - t4.f, p4, F2w.f * o4, pg);
+              }
               f4_pgrad(ts3.f, ps3, F2w.f * os3, pg);
               f4_pgrad(R(kPi) - ts3.f, ps3, F2w.f * os3, pg);
               f4_pgrad(to3.f, po3, F2w.f * oo3, pg);
@@ -520,7 +631,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
     const FD<R> A1a = f4_eval(t1.f, p1);
     FD<R> A1b;
     R dH1;
-    if constexpr (MODEL == 1) {
+    if constexpr (kCoaxF5) {
       A1b = f4_eval(R(2 * kPi) - t1.f, p1);
       dH1 = A1a.d - A1b.d;
     } else {
@@ -534,10 +645,10 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
     R xs = R(0), xo = R(0), irb = R(0);
     V3<R> nb{R(0), R(0), R(0)};
     F5P<R> qs{}, qo{};
-    if constexpr (MODEL == 1) {
+    if constexpr (kCoaxF5) {
       // cos(phi3) = n.(nb x a1q), cos(phi4) = n.(nb x a1p): both vectors flip with the role, the
       // triple product does not.
-      const V3<R> db = site_disp(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+      const V3<R> db = site_disp<BX>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
       irb = m_rsqrt(dot(db, db));
       nb = irb * db;
       xs = dot(n, cross(nb, s.a1));
@@ -558,7 +669,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
       const R ss = F2w.f * A4.f * H1 * Ho * phi, so = F2w.f * A4.f * H1 * Hs * phi;
       f4_pgrad(t4.f, p4, s4, pg);
       f4_pgrad(t1.f, p1, s1, pg);
-      if constexpr (MODEL == 1) {
+      if constexpr (kCoaxF5) {
         f4_pgrad(R(2 * kPi) - t1.f, p1, s1, pg);
         f5_pgrad(xs, qs, F2w.f * ang * Bo.f, pg);
         f5_pgrad(xo, qo, F2w.f * ang * Bs.f, pg);
@@ -580,7 +691,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
       acc_dir(gd, ks, R(1), cs, s.a3, n, ir);
       const R ko = F2w.f * A4.f * H1 * Hs * phi * (Oa.d - Ob.d) * to.d;
       acc_dir(gd, ko, R(-1), co, o.a3, n, ir);
-      if constexpr (MODEL == 1) {
+      if constexpr (kCoaxF5) {
         // t = n.(nb x a):  dt/da = n x nb,  dt/dn = nb x a,  dt/dnb = a x n
         V3<R> gn{R(0), R(0), R(0)}, gnb{R(0), R(0), R(0)};
         const R kxs = F2w.f * ang * Bo.f * Bs.d, kxo = F2w.f * ang * Bs.f * Bo.d;
@@ -594,7 +705,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
         V3<R> gdb{R(0), R(0), R(0)};
         axpy(gdb, irb, gnb);
         axpy(gdb, -irb * dot(gnb, nb), nb);
-        acc_self_site(sg, gdb, g_k1, g_k2);
+        acc_self_site<BX>(sg, gdb, g_k1, g_k2);
       }
       acc_self_site(sg, gd, g_st, R(0));
     }

@@ -514,13 +514,13 @@ class ComposedEnergyFunction(EnergyFunction):
         if geom is None:
             raise ValueError("transform_fn (site geometry) must be provided")
         model = geom.model  # the site geometry decides oxDNA1 vs oxDNA2 (shared term classes exist in both)
-        if any(fn.model > model for fn in self.energy_fns):
-            raise ValueError("an oxDNA2-only term (Debye / dna2 stacking / dna2 coaxial) needs the oxDNA2 geometry")
+        from mythos_amd.energy import terms as _terms
+
+        _terms.check_term_models(model, self.energy_fns)
         sections = {"geometry": geom.params}
         term_w = [0.0] * 8
         cols = []
         w_user = self.weights if self.weights is not None else torch.ones(len(self.energy_fns), dtype=torch.float64)
-        from mythos_amd.energy import terms as _terms
 
         for fn, w in zip(self.energy_fns, w_user):
             k = TERM_ORDER.index(fn.term)

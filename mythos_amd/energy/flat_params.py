@@ -131,9 +131,26 @@ def derive_flat(
     zero = torch.zeros((), dtype=F64)
 
     g = S["geometry"]
-    out["GEO_STACK"] = g["com_to_stacking"]
-    out["GEO_BASE"] = g["com_to_hb"]
-    if model == 1:
+    rna_only = ("GEO_STACK3_A1", "GEO_STACK3_A2", "GEO_STACK5_A1", "GEO_STACK5_A2", "GEO_P3_X", "GEO_P3_Y", "GEO_P3_Z",
+                "GEO_P5_X", "GEO_P5_Y", "GEO_P5_Z")
+    if model == 3:
+        # oxRNA2 (rna2/nucleotide.py:52-63): the backbone site is c + pos_back_a1 a1 + pos_back_a3 a3 (the kernels'
+        # model-3 instantiation puts the second coefficient on a3); stacking runs between separate 3' / 5' sites.
+        out["GEO_STACK"] = g["pos_stack"]
+        out["GEO_BASE"] = g["pos_base"]
+        out["GEO_BACK_A1"] = g["pos_back_a1"]
+        out["GEO_BACK_A2"] = g["pos_back_a3"]
+        out["GEO_BACK_DNA1"] = g["pos_back_a1"]  # unused by model 3
+        out.update(GEO_STACK3_A1=g["pos_stack_3_a1"], GEO_STACK3_A2=g["pos_stack_3_a2"], GEO_STACK5_A1=g["pos_stack_5_a1"],
+                   GEO_STACK5_A2=g["pos_stack_5_a2"], GEO_P3_X=g["p3_x"], GEO_P3_Y=g["p3_y"], GEO_P3_Z=g["p3_z"],
+                   GEO_P5_X=g["p5_x"], GEO_P5_Y=g["p5_y"], GEO_P5_Z=g["p5_z"])
+    else:
+        out["GEO_STACK"] = g["com_to_stacking"]
+        out["GEO_BASE"] = g["com_to_hb"]
+        out.update({k: zero for k in rna_only})
+    if model == 3:
+        pass
+    elif model == 1:
         out["GEO_BACK_A1"] = g["com_to_backbone"]
         out["GEO_BACK_A2"] = zero
         out["GEO_BACK_DNA1"] = g["com_to_backbone"]
@@ -171,8 +188,13 @@ def derive_flat(
     st_kt = st.get("kt", kt)
     st_kt = kt if st_kt is None else st_kt
     _f1_block("STCK", st["dr_low_stack"], st["dr_high_stack"], st["a_stack"], st["dr0_stack"], st["dr_c_stack"], out)
-    for k in (4, 5, 6):
-        _f4_block(f"STCK_TH{k}", st[f"theta0_stack_{k}"], st[f"delta_theta_star_stack_{k}"], st[f"a_stack_{k}"], out)
+    # oxDNA: theta 4, 5, 6; oxRNA2: theta 5, 6, 9, 10 (rna2/stacking.py:60-176).  The blocks a model does not have are
+    # filled with a well-formed unused modulation (the kernels never read them).
+    for k in (4, 5, 6, 9, 10):
+        if f"a_stack_{k}" in st:
+            _f4_block(f"STCK_TH{k}", st[f"theta0_stack_{k}"], st[f"delta_theta_star_stack_{k}"], st[f"a_stack_{k}"], out)
+        else:
+            _f4_block(f"STCK_TH{k}", zero, _t(0.5), _t(1.0), out)
     for k in (1, 2):
         _f5_block(f"STCK_PHI{k}", st[f"neg_cos_phi{k}_star_stack"], st[f"a_stack_{k}"], out)
     if st.get("ss_stack_weights") is None:
@@ -191,14 +213,17 @@ def derive_flat(
     cr = S["cross_stacking"]
     _f2_block("CRST", cr["dr_low_cross"], cr["dr_high_cross"], cr["k_cross"], cr["r0_cross"], cr["dr_c_cross"], out)
     for k in (1, 2, 3, 4, 7, 8):
-        _f4_block(f"CRST_TH{k}", cr[f"theta0_cross_{k}"], cr[f"delta_theta_star_cross_{k}"], cr[f"a_cross_{k}"], out)
+        if f"a_cross_{k}" in cr:
+            _f4_block(f"CRST_TH{k}", cr[f"theta0_cross_{k}"], cr[f"delta_theta_star_cross_{k}"], cr[f"a_cross_{k}"], out)
+        else:  # oxRNA2 has no theta4 factor in cross-stacking (rna2/cross_stacking.py:97-147)
+            _f4_block(f"CRST_TH{k}", zero, _t(0.5), _t(1.0), out)
 
     # coaxial stacking (dna1/coaxial_stacking.py:106-172, dna2/coaxial_stacking.py:79-130)
     cx = S["coaxial_stacking"]
     _f2_block("CXST", cx["dr_low_coax"], cx["dr_high_coax"], cx["k_coax"], cx["dr0_coax"], cx["dr_c_coax"], out)
     for k in (4, 1, 5, 6):
         _f4_block(f"CXST_TH{k}", cx[f"theta0_coax_{k}"], cx[f"delta_theta_star_coax_{k}"], cx[f"a_coax_{k}"], out)
-    if model == 1:
+    if model in (1, 3):  # oxRNA2 keeps the oxDNA1 form of the coaxial term (rna2/tests/test_integration.py:258-287)
         _f5_block("CXST_PHI3", cx["cos_phi3_star_coax"], cx["a_coax_3p"], out)
         _f5_block("CXST_PHI4", cx["cos_phi4_star_coax"], cx["a_coax_4p"], out)
         out["CXST_F6_A"] = zero
@@ -209,8 +234,8 @@ def derive_flat(
         out["CXST_F6_A"] = cx["a_coax_1_f6"]
         out["CXST_F6_B"] = cx["b_coax_1_f6"]
 
-    # Debye-Hueckel (dna2/debye.py:47-64)
-    if model == 2:
+    # Debye-Hueckel (dna2/debye.py:47-64; oxRNA2 uses the same term)
+    if model in (2, 3):
         d = S["debye"]
         d_kt = d.get("kt")
         d_kt = kt if d_kt is None else d_kt

@@ -55,9 +55,26 @@ def _derive_with(model: int, section: str, cfg: BaseConfiguration, extra: dict |
     return fp.derive_flat(model, sections, **kw)
 
 
+MODEL_NAMES = {1: "dna1", 2: "dna2", 3: "rna2"}  # the model numbers of the C ABI (include/mythos_hip.h)
+
+
+def check_term_models(model: int, energy_fns) -> None:
+    """The site geometry decides which instantiation of the kernels runs; a term class written for another functional
+    form must not be evaluated by it silently."""
+    if any(fn.model > model for fn in energy_fns):
+        raise ValueError("an oxDNA2-only term (Debye / dna2 stacking / dna2 coaxial) needs the oxDNA2 geometry, an oxRNA2 "
+                         "term (rna2 stacking / cross-stacking) the oxRNA2 geometry")
+    if model == 3:
+        for fn in energy_fns:
+            if fn.term in ("stacking", "cross_stacking") and fn.model != 3:
+                raise ValueError(f"the oxRNA2 geometry needs the rna2 {fn.term} term (mythos_amd.energy.rna2), got an oxDNA one")
+            if fn.term == "coaxial_stacking" and fn.model != 1:
+                raise ValueError("oxRNA2 uses the oxDNA1 form of the coaxial term (dna1.CoaxialStacking)")
+
+
 def fill_missing_sections(model: int, sections: dict) -> None:
     """Terms absent from a composed function still need well-formed (unused, weight 0) parameters."""
-    _, cfg = defaults.default_configs_for(f"dna{model}")
+    _, cfg = defaults.default_configs_for(MODEL_NAMES[model])
     for sec, vals in cfg.items():
         if sec not in sections:
             sections[sec] = vals
@@ -266,6 +283,65 @@ class Stacking2(Stacking):
     """dna2/stacking.py:14-44: cos(phi) terms on the oxDNA1 backbone site."""
 
     model = 2
+
+
+# ------------------------------------------------------------------------------------------------
+# oxRNA2 (mythos/energy/rna2/): its own stacking and cross-stacking; everything else is composed from the oxDNA1 / oxDNA2
+# classes above with the oxRNA2 site geometry (rna2/tests/test_integration.py:52-374)
+# ------------------------------------------------------------------------------------------------
+def _stacking_rna2_derive(self) -> dict:
+    if self["pseq"] is not None and self["pseq_constraints"] is None:
+        raise ValueError("pseq_constraints must be provided when pseq is provided.")  # rna2/stacking.py:121-122
+    named = _derive_with(3, "stacking", self, {"kt": self["kt"]})
+    m = {**_radial_names("stack", "STCK"), **_f4_names("stack", "STCK", (5, 6, 9, 10))}
+    for k in (1, 2):
+        m[f"b_neg_cos_phi{k}_stack"] = f"STCK_PHI{k}_B"
+        m[f"neg_cos_phi{k}_c_stack"] = f"STCK_PHI{k}_XC"
+    out = _blocks(m, named)
+    out["eps_stack"] = torch.stack([torch.stack([named[f"STCK_EPS_{i}{j}"] for j in range(4)]) for i in range(4)])
+    return out
+
+
+class StackingConfigurationRna2(BaseConfiguration):
+    """rna2/stacking.py:18-176: theta 5, 6, 9, 10 (no theta 4)."""
+
+    required_params = (
+        "eps_stack_base", "eps_stack_kt_coeff", "dr_low_stack", "dr_high_stack", "a_stack", "dr0_stack", "dr_c_stack",
+    ) + tuple(n for k in (5, 6, 9, 10) for n in (f"theta0_stack_{k}", f"delta_theta_star_stack_{k}", f"a_stack_{k}")) + (
+        "neg_cos_phi1_star_stack", "a_stack_1", "neg_cos_phi2_star_stack", "a_stack_2", "kt",
+    )
+    optional_params = ("ss_stack_weights", "pseq", "pseq_constraints")
+    dependent_params = ("b_low_stack", "dr_c_low_stack", "b_high_stack", "dr_c_high_stack") + tuple(
+        n for k in (5, 6, 9, 10) for n in (f"b_stack_{k}", f"delta_theta_stack_{k}_c")
+    ) + ("b_neg_cos_phi1_stack", "neg_cos_phi1_c_stack", "b_neg_cos_phi2_stack", "neg_cos_phi2_c_stack", "eps_stack")
+    _derive = staticmethod(_stacking_rna2_derive)
+
+
+class CrossStackingConfigurationRna2(BaseConfiguration):
+    """rna2/cross_stacking.py:17-147: no theta4 block."""
+
+    required_params = ("dr_low_cross", "dr_high_cross", "k_cross", "r0_cross", "dr_c_cross") + tuple(
+        n for k in (1, 2, 3, 7, 8) for n in (f"theta0_cross_{k}", f"delta_theta_star_cross_{k}", f"a_cross_{k}")
+    )
+    dependent_params = ("b_low_cross", "dr_c_low_cross", "b_high_cross", "dr_c_high_cross") + tuple(
+        n for k in (1, 2, 3, 7, 8) for n in (f"b_cross_{k}", f"delta_theta_cross_{k}_c")
+    )
+    _derive = staticmethod(
+        lambda self: _blocks({**_radial_names("cross", "CRST"), **_f4_names("cross", "CRST", (1, 2, 3, 7, 8))},
+                             _derive_with(3, "cross_stacking", self))
+    )
+
+
+class StackingRna2(Stacking):
+    """rna2/stacking.py:179-292: 5' / 3' stacking sites, theta9 / theta10 against the p3 / p5 vectors."""
+
+    model = 3
+
+
+class CrossStackingRna2(CrossStacking):
+    """rna2/cross_stacking.py:150-238."""
+
+    model = 3
 
 
 class Debye(BaseEnergyFunction):

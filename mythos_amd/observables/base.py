@@ -34,6 +34,8 @@ def get_duplex_quartets(n_nucs_per_strand: int) -> torch.Tensor:
 
 
 def _geometry3(geometry: dict, model: int) -> np.ndarray:
+    if model == 3:  # oxRNA2: the third entry is the backbone offset along a3 (rna2/nucleotide.py:56)
+        return np.array([float(geometry["pos_base"]), float(geometry["pos_back_a1"]), float(geometry["pos_back_a3"])])
     if model == 2:
         return np.array([float(geometry["com_to_hb"]), float(geometry["com_to_backbone_x"]), float(geometry["com_to_backbone_y"])])
     return np.array([float(geometry["com_to_hb"]), float(geometry["com_to_backbone"]), 0.0])

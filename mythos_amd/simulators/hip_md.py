@@ -106,6 +106,7 @@ class HipMDSimulator(Simulator):
                              "discrete sequence - reweight the stored frames with the pseq energy function instead")
         geom = next(fn.transform_fn for fn in ef.energy_fns if fn.transform_fn is not None)
         model = geom.model
+        _terms.check_term_models(model, ef.energy_fns)
         sections = {"geometry": geom.params}
         tw = [0.0] * 8
         w_user = ef.weights if ef.weights is not None else torch.ones(len(ef.energy_fns), dtype=torch.float64)

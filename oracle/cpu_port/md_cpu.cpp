@@ -108,7 +108,9 @@ void forces(const Sys& s, const double* c, const double* q, double* e_terms, dou
 }
 
 void forces(const Sys& s, const double* c, const double* q, double* e, double* dc, double* g) {
-  if (s.model == 1) forces<1>(s, c, q, e, dc, g); else forces<2>(s, c, q, e, dc, g);
+  if (s.model == 1) forces<1>(s, c, q, e, dc, g);
+  else if (s.model == 2) forces<2>(s, c, q, e, dc, g);
+  else forces<3>(s, c, q, e, dc, g);
 }
 
 // body-frame torque from the axis gradients: lab torque -sum_k a_k x dU/da_k, projected on the axes
@@ -256,7 +258,7 @@ extern "C" {
 
 void* mythos_cpu_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded, const int32_t* bonded,
                         const double* box, const double* flat, int n_params) {
-  if (n_params != OXP_COUNT || (model != 1 && model != 2) || n <= 0) return nullptr;
+  if (n_params != OXP_COUNT || (model < 1 || model > 3) || n <= 0) return nullptr;
   Sys* s = new Sys();
   s->model = model, s->n = n;
   if (box) s->has_box = true, s->box[0] = box[0], s->box[1] = box[1], s->box[2] = box[2];

@@ -29,7 +29,12 @@ def nucleotide_sites(trajectory, geometry: dict, model: int = 2):
     """(base_sites, back_sites, stack_sites), each (S, N, 3): the site algebra of ``Nucleotide.from_rigid_body``
     (dna1/nucleotide.py:29-53, dna2/nucleotide.py:30-58) with the TOML ``[geometry]`` values."""
     c = trajectory.center
-    a1, a2, _ = axes_from_quaternion(trajectory.orientation.vec)
+    a1, a2, a3 = axes_from_quaternion(trajectory.orientation.vec)
+    if model == 3:  # rna2/nucleotide.py:52-58: backbone site on a1 and a3
+        base = c + float(geometry["pos_base"]) * a1
+        stack = c + float(geometry["pos_stack"]) * a1
+        back = c + float(geometry["pos_back_a1"]) * a1 + float(geometry["pos_back_a3"]) * a3
+        return base, back, stack
     base = c + float(geometry["com_to_hb"]) * a1
     stack = c + float(geometry["com_to_stacking"]) * a1
     if model == 2:

@@ -128,3 +128,54 @@ def read_pair_dat(path, n_blocks=None):
     if cur is not None:
         blocks.append(cur)
     return blocks
+
+
+@functools.lru_cache(maxsize=None)
+def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_000, seed: int = 5):
+    """A system of ``keep`` independent two-nucleotide molecules in random relative poses, selected from ``sample``
+    random draws (with the oracle) so that every angular term of the pair is LIVE in many of them - the golden
+    trajectories visit a narrow part of each term's angular window (both coaxial goldens hold 0 in every stored frame).
+
+    bonded=False: two free nucleotides (unbonded excluded volume, H-bond, cross-stacking, coaxial stacking, Debye);
+    bonded=True: a two-nucleotide strand whose backbone sites are within the FENE well (FENE, bonded excluded volume,
+    stacking).  Returns (topology, center (2 keep, 3), quaternion (2 keep, 4), live-count per term name).
+    """
+    rng = np.random.default_rng(seed + 10 * model + (1 if bonded else 0))
+    m = sample
+    q = rng.standard_normal((2 * m, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    c = np.zeros((2 * m, 3))
+    d = rng.standard_normal((m, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    P = oracle_params(model, salt=1.0 if model == 3 else 0.5)
+    if bonded:
+        a1, a2, a3 = orc.quat_to_axes(torch.as_tensor(q))
+        back = orc.Sites(model, P["geometry"], torch.zeros(2 * m, 3, dtype=torch.float64), a1, a2, a3).back.numpy()
+        r0, delta = float(P["fene"]["r0_backbone"]), float(P["fene"]["delta_backbone"])
+        c[1::2] = back[0::2] - back[1::2] + d * (r0 + rng.uniform(-0.6, 0.6, (m, 1)) * delta)
+    else:
+        c[1::2] = d * rng.uniform(0.3, 1.2, (m, 1))
+    seq = rng.integers(0, 4, 2 * m)
+    seq[1:m:2] = 3 - seq[0:m:2]  # Watson-Crick partners in the first half of the draws: hydrogen bonds need them
+    pairs = torch.as_tensor(np.stack([np.arange(0, 2 * m, 2), np.arange(1, 2 * m, 2)], 1))
+    none = torch.zeros((0, 2), dtype=torch.long)
+    bt, ut = orc.pair_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), torch.as_tensor(seq), torch.ones(2 * m, dtype=torch.long),
+                            pairs if bonded else none, none if bonded else pairs)
+    terms = {k: v.numpy() for k, v in (bt if bonded else ut).items()}
+    radial = terms["bonded_excluded_volume" if bonded else "unbonded_excluded_volume"]
+    angular = ("stacking",) if bonded else ("hydrogen_bonding", "cross_stacking", "coaxial_stacking")
+    ok = np.isfinite(sum(terms.values())) & (radial < 20.0)
+    chosen = []
+    for k in angular:  # an equal share for every angular term, the most strongly live first
+        idx = np.nonzero(ok & (np.abs(terms[k]) > 1e-3))[0]
+        chosen.append(idx[np.argsort(-np.abs(terms[k][idx]))][:: max(1, len(idx) // (keep // len(angular)))][: keep // len(angular)])
+    sel = np.unique(np.concatenate(chosen))
+    rest = np.setdiff1d(np.nonzero(ok)[0], sel)[: keep - len(sel)]
+    sel = np.concatenate([sel, rest])
+    live = {k: int((np.abs(terms[k][sel]) > 1e-3).sum()) for k in terms}
+    side = int(np.ceil(len(sel) ** (1.0 / 3.0)))
+    grid = np.array([[i % side, (i // side) % side, i // (side * side)] for i in range(len(sel))], dtype=np.float64) * 8.0
+    nuc = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1)
+    center = c[nuc] + np.repeat(grid, 2, axis=0)
+    top = topology.from_arrays(seq[nuc].astype(np.int32), [2] * len(sel) if bonded else [1] * (2 * len(sel)))
+    return top, np.ascontiguousarray(center), np.ascontiguousarray(q[nuc]), live

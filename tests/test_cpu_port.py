@@ -22,9 +22,12 @@ from tests import helpers as H
 KT = 296.15 * 0.1 / 300.0
 
 
+SALT = {1: 0.5, 2: 0.5, 3: 1.0}  # rna2 goldens: salt 1.0 (rna2/tests/test_integration.py)
+
+
 def _flat(model, hce):
-    sim, cfg = defaults.default_configs_for(f"dna{model}")
-    d = fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce)
+    sim, cfg = defaults.default_configs_for(H.model_dir(model))
+    d = fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=SALT[model], half_charged_ends=hce)
     from mythos_amd import _lib
 
     return fp.pack_flat(d, _lib.param_names()).numpy()
@@ -37,12 +40,13 @@ def _built():
 
 
 @pytest.mark.parametrize(("model", "name", "hce"), [(1, "simple-helix", False), (2, "simple-helix", False), (2, "simple-coax", False),
-                                                    (2, "simple-helix-half-charged-ends", True)])
+                                                    (2, "simple-helix-half-charged-ends", True),
+                                                    (3, "simple-helix-12bp", False), (3, "simple-coax", False)])
 def test_energies_and_gradients_match_oracle(model, name, hce):
     top, traj, split, _ = H.load_golden(model, name)
     port = cpu_port.CpuPort(model, top.seq, top.is_end, top.bonded_neighbors, _flat(model, hce), box=traj.box_size)
     port.set_pairs(top.unbonded_neighbors)
-    P = H.oracle_params(model, half_charged_ends=hce)
+    P = H.oracle_params(model, half_charged_ends=hce, salt=SALT[model])
     tt = H.topo_tensors(top)
     for f in (0, 41, 99):
         c, q = traj.center[f], traj.quaternions[f]
@@ -59,6 +63,28 @@ def test_energies_and_gradients_match_oracle(model, name, hce):
         np.testing.assert_allclose(gq, gq_ref.numpy(), rtol=0, atol=1e-9 * max(1.0, gq_ref.abs().max().item()))
         tb_ref = orc.quat_grad_to_body_torque(torch.as_tensor(q), gq_ref).numpy()
         np.testing.assert_allclose(tb, tb_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(tb_ref).max()))
+
+
+@pytest.mark.parametrize("model", [1, 2, 3])
+@pytest.mark.parametrize("bonded", [False, True])
+def test_random_dimers_match_oracle(model, bonded):
+    """Every term of the pair templates on random relative poses (tests/helpers.py random_dimers): the golden
+    trajectories hold 0 for the coaxial term in every stored frame, and visit little of the other angular windows."""
+    top, c, q, live = H.random_dimers(model, bonded)
+    assert all(v >= 5 for k, v in live.items()), live
+    pairs = np.arange(top.n_nucleotides).reshape(-1, 2)
+    port = cpu_port.CpuPort(model, top.seq, top.is_end, top.bonded_neighbors, _flat(model, False), box=None)
+    port.set_pairs(np.zeros((0, 2), np.int64) if bonded else pairs)
+    P = H.oracle_params(model, salt=SALT[model])
+    seq, is_end, b, _ = H.topo_tensors(top)
+    u = torch.zeros((0, 2), dtype=torch.long) if bonded else torch.as_tensor(pairs)
+    e, gc, gq, tb = port.energy(c, q)
+    e_ref = orc.energy_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u).numpy()
+    np.testing.assert_allclose(e[: len(e_ref)], e_ref, rtol=1e-12, atol=1e-10)
+    assert (np.abs(e_ref[:3] if bonded else e_ref[3:]) > 0.2).all()  # every term contributes
+    _, gc_ref, gq_ref = orc.energy_and_grads(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u)
+    np.testing.assert_allclose(gc, gc_ref.numpy(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gq, gq_ref.numpy(), rtol=1e-9, atol=1e-9)
 
 
 def test_langevin_steps_match_oracle_on_the_same_random_stream():

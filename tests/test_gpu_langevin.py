@@ -21,11 +21,11 @@ pytestmark = pytest.mark.gpu
 KT = 296.15 * 0.1 / 300.0
 
 
-def _make(model, top, box, dtype, hce=False):
+def _make(model, top, box, dtype, hce=False, salt=0.5):
     from mythos_amd.hip_system import OxdnaSystem
 
-    sim, cfg = defaults.default_configs_for(f"dna{model}")
-    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    sim, cfg = defaults.default_configs_for(H.model_dir(model))
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=salt, half_charged_ends=hce), _lib.param_names())
     s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=dtype)
     s.set_params(flat)
     return s, sim
@@ -35,12 +35,15 @@ def _state(c, q, dtype, dev):
     return torch.as_tensor(c, dtype=dtype, device=dev).contiguous(), torch.as_tensor(q, dtype=dtype, device=dev).contiguous()
 
 
-def test_step_by_step_parity_with_oracle_fp64():
+@pytest.mark.parametrize(("model", "name", "salt"), [(2, "simple-helix", 0.5), (1, "simple-helix", 0.5), (3, "simple-helix-12bp", 1.0),
+                                                     (3, "simple-coax", 1.0)])
+def test_step_by_step_parity_with_oracle_fp64(model, name, salt):
+    """(oxRNA2, model 3: the integrator keeps the backbone site on a1 and a3 - the offsets the frames carry)"""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle
 
-    top, traj, _, _ = H.load_golden(2, "simple-helix")
-    s, sim = _make(2, top, traj.box_size, torch.float64)
+    top, traj, _, _ = H.load_golden(model, name)
+    s, sim = _make(model, top, traj.box_size, torch.float64, salt=salt)
     s.set_neighbors(top.unbonded_neighbors)
     gam_t, gam_r = KT / 2.5, KT / 7.5
     integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.3, 0.8), seed=0x1234ABCD5678)
@@ -50,7 +53,8 @@ def test_step_by_step_parity_with_oracle_fp64():
     n_steps = 6
     tc, tq, et = integ.run(c, q, p, L, n_steps, save_every=1)
     orc = LangevinOracle(
-        2, H.oracle_params(2), H.topo_tensors(top), traj.box_size, 0.005, KT, gam_t, gam_r, 1.0, (1.0, 1.3, 0.8), seed=0x1234ABCD5678
+        model, H.oracle_params(model, salt=salt), H.topo_tensors(top), traj.box_size, 0.005, KT, gam_t, gam_r, 1.0, (1.0, 1.3, 0.8),
+        seed=0x1234ABCD5678
     )
     x, qq, pp, LL = x0, q0, p0, L0
     for k in range(n_steps):

@@ -49,12 +49,12 @@ def _cpu64(traj):
 
 
 @pytest.mark.parametrize(("model", "periodic", "dtype"), [(2, False, torch.float64), (2, True, torch.float64), (1, False, torch.float64),
-                                                         (2, False, torch.float32)])
+                                                         (2, False, torch.float32), (3, False, torch.float64), (3, True, torch.float64)])
 def test_observables_match_the_oracle(model, periodic, dtype):
     bp = 23
     shift = [19.0, 18.5, 17.0] if periodic else None  # the helix crosses the faces of a 20-unit box (unwrapped coordinates)
     top, traj = _thermal_duplex(bp, 7, model=model, seed=3, dtype=dtype, shift=shift)
-    _, cfg = defaults.default_configs_for(f"dna{model}")
+    _, cfg = defaults.default_configs_for(H.model_dir(model))
     disp = space.periodic(20.0)[0] if periodic else space.free()[0]
     quartets = get_duplex_quartets(bp)
     pairs = np.stack([np.arange(bp), 2 * bp - 1 - np.arange(bp)], axis=1)[2:-2]

@@ -185,8 +185,11 @@ def test_default_parameters_and_toml_subset(tmp_path):
     assert e1["stacking"]["eps_stack_base"] == 1.3448 and e2["stacking"]["eps_stack_base"] == 1.3523
     assert abs(e2["coaxial_stacking"]["theta0_coax_1"] - (math.pi - 0.25)) < 1e-12
     assert "debye" in e2 and "debye" not in e1
+    sim3, e3 = defaults.default_configs_for("rna2")  # mythos/input/rna2/default_energy.toml
+    assert e3["fene"]["r0_backbone"] == 0.761070781051 and e3["geometry"]["pos_back_a3"] == 0.2 and "theta0_stack_9" in e3["stacking"]
+    assert "theta0_cross_4" not in e3["cross_stacking"] and sim3["salt_conc"] == 1.0
     with pytest.raises((KeyError, ValueError)):
-        defaults.default_configs_for("rna2")
+        defaults.default_configs_for("na1")
     toml = tmp_path / "p.toml"
     toml.write_text("# comment\n[a]\nx = 1.5\ny = \"pi - 0.25\"\nflag = true\n[b]\nz = [1, 2.0, \"3 * 2\"]\n")
     parsed = defaults.parse_toml(toml)
