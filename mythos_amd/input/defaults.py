@@ -210,6 +210,17 @@ RNA2_ENERGY = {
     "debye": {"q_eff": 1.26, "lambda_factor": 0.3667258, "prefactor_coeff": 0.05404383975812547},
 }
 
+# oxNA (mythos/input/na1/default_energy.toml): the numbers of a DNA-RNA hybrid pair, unbonded terms only, every term in its
+# oxDNA1 functional form; DNA-DNA pairs take DNA2_ENERGY and RNA-RNA pairs RNA2_ENERGY (na1/tests/test_integration.py:104-141)
+NA1_DRH_ENERGY = {
+    "unbonded_excluded_volume": dict(_COMMON_EXC_UNBONDED),
+    "hydrogen_bonding": _hydrogen_bonding(1.5),
+    "cross_stacking": {**_cross_stacking(), "k_cross": 44.535},
+    "coaxial_stacking": {**_coaxial(46.0, PI - 0.60), "cos_phi3_star_coax": -0.65, "a_coax_3p": 2.0, "cos_phi4_star_coax": -0.65,
+                         "a_coax_4p": 2.0},
+    "debye": {"q_eff": 1.26, "lambda_factor": 0.3667258, "prefactor_coeff": 0.05404383975812547},
+}
+
 _SIM_COMMON = {
     "kT": 296.15 * 0.1 / 300.0,
     "dt": 5e-3,
@@ -227,7 +238,7 @@ RNA2_SIMULATION = {**_SIM_COMMON, "salt_conc": 1.0, "half_charged_ends": 0}
 
 
 def default_configs_for(base: str) -> tuple[dict, dict]:
-    """(simulation config, energy config) deep copies; ``base`` is "dna1" or "dna2".
+    """(simulation config, energy config) deep copies; ``base`` is "dna1", "dna2", "rna2" or "na1" (three sets).
 
     Reference: mythos/energy/utils.py:135-148.
     """
@@ -237,7 +248,10 @@ def default_configs_for(base: str) -> tuple[dict, dict]:
         return copy.deepcopy(DNA2_SIMULATION), copy.deepcopy(DNA2_ENERGY)
     if base == "rna2":
         return copy.deepcopy(RNA2_SIMULATION), copy.deepcopy(RNA2_ENERGY)
-    raise ValueError(f"unknown model '{base}' (expected 'dna1', 'dna2' or 'rna2')")
+    if base == "na1":  # three parameter sets: DNA-DNA, RNA-RNA and hybrid pairs (the goldens: salt 0.5, whole end charges)
+        return ({**_SIM_COMMON, "salt_conc": 0.5, "half_charged_ends": 0},
+                {"dna": copy.deepcopy(DNA2_ENERGY), "rna": copy.deepcopy(RNA2_ENERGY), "drh": copy.deepcopy(NA1_DRH_ENERGY)})
+    raise ValueError(f"unknown model '{base}' (expected 'dna1', 'dna2', 'rna2' or 'na1')")
 
 
 # ---------------------------------------------------------------------------------------------

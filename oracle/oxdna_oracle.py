@@ -782,6 +782,114 @@ def pair_terms(model, P, center, quat, seq, is_end, bonded, unbonded, box=None, 
     return bt, ut
 
 
+# ---------------------------------------------------------------------------------------------
+# oxNA (model 4): hybrid DNA / RNA systems, mythos/energy/na1/*.py
+# ---------------------------------------------------------------------------------------------
+NA1_UNBONDED = ("unbonded_excluded_volume", "hydrogen_bonding", "cross_stacking", "coaxial_stacking", "debye")
+
+
+def init_all_na1(cfg_dna: dict, cfg_rna: dict, cfg_drh: dict, kt, salt_conc=0.5, half_charged_ends=False) -> dict:
+    """Three parameter sets, as every na1 ``*Configuration.init_params`` builds them (e.g. na1/hydrogen_bonding.py:215-307):
+    ``dna`` (oxDNA2 sections), ``rna`` (oxRNA2 sections) and ``drh`` (the DNA-RNA hybrid numbers of
+    mythos/input/na1/default_energy.toml, unbonded terms only, all in their oxDNA1 functional form)."""
+    return {
+        "dna": init_all(2, cfg_dna, kt, salt_conc, half_charged_ends),
+        "rna": init_all(3, cfg_rna, kt, salt_conc, half_charged_ends),
+        "drh": {
+            "unbonded_excluded_volume": init_exc_vol(cfg_drh["unbonded_excluded_volume"], with_backbone=True),
+            "hydrogen_bonding": init_hydrogen_bonding(cfg_drh["hydrogen_bonding"]),
+            "cross_stacking": init_cross_stacking(cfg_drh["cross_stacking"]),
+            "coaxial_stacking": init_coaxial(cfg_drh["coaxial_stacking"], 1),
+            "debye": init_debye({**cfg_drh["debye"], "kt": kt, "salt_conc": salt_conc, "half_charged_ends": half_charged_ends}),
+        },
+    }
+
+
+class _MixedSites:
+    """Sites of every nucleotide by its OWN type: ``pairwise_energies(nucleotide.dna, nucleotide.rna, ...)`` of the
+    hybrid branches (na1/hydrogen_bonding.py:336-348 and the other unbonded terms) reads nn_i from the oxDNA2 sites and
+    nn_j from the oxRNA2 sites; for a DNA-DNA or RNA-RNA pair the same table gives both from one model."""
+
+    def __init__(self, dna: Sites, rna: Sites, is_rna):
+        m = is_rna[:, None]
+        self.a1, self.a2, self.a3, self.center = dna.a1, dna.a2, dna.a3, dna.center
+        for name in ("stack", "base", "back"):
+            setattr(self, name, torch.where(m, getattr(rna, name), getattr(dna, name)))
+
+
+def pair_terms_na1(P, center, quat, seq, nt_is_rna, is_end, bonded, unbonded, box=None, axes=None):
+    """Per-pair energies of one frame of a hybrid system.  Bonded pairs: both RNA -> oxRNA2 forms on the oxRNA2 sites,
+    otherwise the oxDNA2 forms on the oxDNA2 sites (na1/fene.py:89-106, bonded_excluded_volume.py:96-116,
+    stacking.py:193-217).  Unbonded pairs: RNA-RNA -> oxRNA2, DNA-DNA -> oxDNA2, DNA-RNA and RNA-DNA -> the ``drh``
+    parameters in the oxDNA1 forms with each nucleotide's own sites (na1/unbonded_excluded_volume.py:140-174,
+    hydrogen_bonding.py:314-362, cross_stacking.py:262-300, coaxial_stacking.py:249-287, debye.py:103-141)."""
+    if axes is None:
+        a1, a2, a3 = quat_to_axes(quat)
+    else:
+        a1, a3 = axes
+        a2 = torch.linalg.cross(a3, a1)
+    sd = Sites(2, P["dna"]["geometry"], center, a1, a2, a3)
+    sr = Sites(3, P["rna"]["geometry"], center, a1, a2, a3)
+    rna = nt_is_rna.bool()
+    disp = make_displacement(box)
+    # every branch is evaluated on ITS pairs only (the reference evaluates all branches on all pairs and selects with
+    # jnp.where; the values are the same, and no unselected branch can put a nan into the gradients)
+    def scatter(total, parts):
+        out = torch.zeros(total, dtype=center.dtype)
+        for idx, val in parts:
+            out = out.index_put((idx,), val)
+        return out
+
+    rna_bond = rna[bonded[:, 0]] & rna[bonded[:, 1]]
+    ir, idn = torch.nonzero(rna_bond)[:, 0], torch.nonzero(~rna_bond)[:, 0]
+    br, bd = bonded[ir], bonded[idn]
+    nb = bonded.shape[0]
+    bt = {
+        "fene": scatter(nb, [(ir, pair_fene(P["rna"]["fene"], sr, br, disp)), (idn, pair_fene(P["dna"]["fene"], sd, bd, disp))]),
+        "bonded_excluded_volume": scatter(nb, [(ir, pair_exc_vol_bonded(P["rna"]["bonded_excluded_volume"], sr, br, disp)),
+                                               (idn, pair_exc_vol_bonded(P["dna"]["bonded_excluded_volume"], sd, bd, disp))]),
+        "stacking": scatter(nb, [(ir, pair_stacking_rna2(P["rna"]["stacking"], sr, seq, br, disp)),
+                                 (idn, pair_stacking(P["dna"]["stacking"], sd, seq, bd, disp))]),
+    }
+    ui, uj = unbonded[:, 0], unbonded[:, 1]
+    both_rna = rna[ui] & rna[uj]
+    both_dna = ~rna[ui] & ~rna[uj]
+    sm = _MixedSites(sd, sr, rna)
+    kinds = (("rna", torch.nonzero(both_rna)[:, 0]), ("dna", torch.nonzero(both_dna)[:, 0]),
+             ("drh", torch.nonzero(~both_rna & ~both_dna)[:, 0]))
+    nu = unbonded.shape[0]
+
+    def three(name, fn):
+        return scatter(nu, [(idx, fn(P[k][name], unbonded[idx], k)) for k, idx in kinds])
+
+    ut = {
+        "unbonded_excluded_volume": three("unbonded_excluded_volume", lambda p, u, k: pair_exc_vol_unbonded(p, sm, u, disp)),
+        "hydrogen_bonding": three("hydrogen_bonding", lambda p, u, k: pair_hydrogen_bonding(p, sm, seq, u, disp)),
+        # cross-stacking: oxDNA form (theta4 factor) for DNA-DNA and the hybrids, oxRNA2 form for RNA-RNA - the parameter
+        # set decides (the oxRNA2 section has no theta4 block)
+        "cross_stacking": three("cross_stacking", lambda p, u, k: pair_cross_stacking(p, sm, u, disp)),
+        # coaxial stacking: the oxDNA2 form (f6) for DNA-DNA, the oxDNA1 form (f5 of cos phi3 / phi4) for RNA-RNA and hybrids
+        "coaxial_stacking": three("coaxial_stacking", lambda p, u, k: pair_coaxial(p, sm, u, disp, 2 if k == "dna" else 1)),
+        "debye": three("debye", lambda p, u, k: pair_debye(p, sm, is_end, u, disp)),
+    }
+    return bt, ut
+
+
+def energy_terms_na1(P, center, quat, seq, nt_is_rna, is_end, bonded, unbonded, box=None, axes=None):
+    """(8,) term energies of a hybrid system, in the oxDNA2 column order."""
+    bt, ut = pair_terms_na1(P, center, quat, seq, nt_is_rna, is_end, bonded, unbonded, box, axes)
+    both = {**bt, **ut}
+    return torch.stack([both[n].sum() for n in TERMS_DNA2])
+
+
+def energy_and_grads_na1(P, center, quat, seq, nt_is_rna, is_end, bonded, unbonded, box=None):
+    c = center.detach().clone().requires_grad_(True)
+    q = quat.detach().clone().requires_grad_(True)
+    u = energy_terms_na1(P, c, q, seq, nt_is_rna, is_end, bonded, unbonded, box).sum()
+    gc, gq = torch.autograd.grad(u, (c, q))
+    return u.detach(), gc, gq
+
+
 def energy_terms(model, P, center, quat, seq, is_end, bonded, unbonded, box=None, axes=None):
     """(n_terms,) tensor in the reference's term order (dna1: 7 terms, dna2: 8).
 

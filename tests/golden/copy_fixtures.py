@@ -28,7 +28,11 @@ CASES = {
     "dna2": ("simple-helix", "simple-coax", "simple-helix-half-charged-ends"),
     # oxRNA2 (reference tests: mythos/energy/rna2/tests/test_integration.py)
     "rna2": ("simple-helix-12bp", "simple-coax"),
+    # oxNA hybrid DNA / RNA (reference tests: mythos/energy/na1/tests/test_integration.py); without pair.dat (0.4 MB each)
+    "na1": ("simple-helix-dna-dna", "simple-helix-rna-rna", "simple-helix-dna-rna", "simple-helix-rna-dna",
+            "simple-coax-dna-dna-dna", "simple-coax-rna-rna-rna", "simple-coax-dna-dna-rna"),
 }
+SKIP = {"na1": ("pair.dat",)}
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
          # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)
          ("dna1", "helix-4bp"): ("sys.top",)}
@@ -47,6 +51,8 @@ def pairs():
     for model, cases in CASES.items():
         for case in cases:
             for name in (*OXDNA_FILES, *EXTRA.get((model, case), ())):
+                if name in SKIP.get(model, ()):
+                    continue
                 src = REF / "test-data" / model / case / name
                 if src.exists():
                     yield src, DST / model / case / name

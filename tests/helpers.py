@@ -42,8 +42,34 @@ TERM_ATOL = {
 
 
 def model_dir(model: int) -> str:
-    """1 -> dna1, 2 -> dna2, 3 -> rna2 (the model numbers of the C ABI)."""
-    return {1: "dna1", 2: "dna2", 3: "rna2"}[model]
+    """1 -> dna1, 2 -> dna2, 3 -> rna2, 4 -> na1 (the model numbers of the C ABI)."""
+    return {1: "dna1", 2: "dna2", 3: "rna2", 4: "na1"}[model]
+
+
+NA1_CASES = ("simple-helix-dna-dna", "simple-helix-rna-rna", "simple-helix-dna-rna", "simple-helix-rna-dna",
+             "simple-coax-dna-dna-dna", "simple-coax-rna-rna-rna", "simple-coax-dna-dna-rna")
+# the tolerances of mythos/energy/na1/tests/test_integration.py (:188,226,267,304,341,378,436,496)
+NA1_TERM_ATOL = {"fene": 1e-6, "bonded_excluded_volume": 1e-6, "stacking": 1e-3, "unbonded_excluded_volume": 1e-6,
+                 "hydrogen_bonding": 1e-4, "cross_stacking": 1e-4, "coaxial_stacking": 1e-6, "debye": 1e-5}
+
+
+@functools.lru_cache(maxsize=None)
+def load_golden_na1(name: str):
+    """oxNA golden: new-format topology (5'->3', ``type=DNA|RNA`` per strand), trajectory read with is_5p_3p=True
+    (na1/tests/test_integration.py:35-45).  -> (topology, trajectory, split energies, is_rna (N,) bool)."""
+    base = GOLDEN / "na1" / name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / "generated.top")
+    traj = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=True)
+    split = np.loadtxt(base / "split_energy.dat", skiprows=1)
+    return top, traj, split, np.asarray(top.nt_type) == int(topology.NucleotideType.RNA)
+
+
+def oracle_params_na1(*, kt=None, salt=0.5, half_charged_ends=False):
+    sim, cfg = defaults.default_configs_for("na1")
+    return orc.init_all_na1(cfg["dna"], cfg["rna"], cfg["drh"], kt=sim["kT"] if kt is None else kt, salt_conc=salt,
+                            half_charged_ends=half_charged_ends)
 
 
 @functools.lru_cache(maxsize=None)

@@ -8,7 +8,9 @@ per term) which the reference ships but does not test.
 
 import numpy as np
 import pytest
+import torch
 
+from oracle import oxdna_oracle as orc
 from tests import helpers as H
 
 CASES = [
@@ -119,3 +121,27 @@ def test_oxrna2_terms_and_total(name):
         np.testing.assert_allclose(np.around(e[:, k], 6), split[:, 1 + k], atol=H.TERM_ATOL[term] + 5e-7, err_msg=term)
     np.testing.assert_allclose(e.sum(1), energy, atol=1e-3)
     assert np.abs(split[:, 3]).max() > 0.5 and np.abs(split[:, 6]).max() > 0.03  # stacking and cross-stacking are live
+
+
+@pytest.mark.parametrize("name", H.NA1_CASES)
+def test_oxna_terms(name):
+    """mythos/energy/na1/tests/test_integration.py:152-496: the eight terms of a hybrid DNA / RNA system (parameter set and
+    functional form by the types of the pair, sites by the type of each nucleotide) against oxDNA's split energies
+    (interaction_type = NA, salt 0.5, whole end charges) at the reference's tolerances."""
+    top, traj, split, is_rna = H.load_golden_na1(name)
+    P = H.oracle_params_na1()
+    seq, is_end, b, u = H.topo_tensors(top)
+    rna = torch.as_tensor(is_rna)
+    e = np.array([orc.energy_terms_na1(P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, rna, is_end, b, u,
+                                       box=traj.box_size).numpy() for f in range(100)]) / top.n_nucleotides
+    for k, term in enumerate(H.SPLIT_COLUMNS[1:9]):
+        if term == "coaxial_stacking" and name == "simple-coax-dna-dna-rna":
+            # the reference leaves this case out: oxNA's standalone code reads the hybrid spring constant as 0
+            # (na1/tests/test_integration.py:404-406)
+            continue
+        np.testing.assert_allclose(np.around(e[:, k], 6), split[:, 1 + k], atol=H.NA1_TERM_ATOL[term] + 5e-7, err_msg=term)
+    assert np.abs(split[:, 3]).max() > 0.5 and np.abs(split[:, 5]).max() > 0.05  # stacking and H-bonds are live
+    if name in ("simple-coax-dna-dna-dna", "simple-coax-rna-rna-rna"):
+        # the coaxial term is live in both nicked duplexes: the oxDNA2 form (f6) and - which no rna2 golden does - the
+        # oxDNA1 form with the oxRNA2 numbers (0.054 and 0.0063 per nucleotide at most)
+        assert np.abs(split[:, 7]).max() > 5e-3
