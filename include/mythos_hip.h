@@ -73,6 +73,12 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
  * Replaces BaseEnergyFunction.__post_init__ topology capture (mythos/energy/base.py:133-140).
  *   model     1 = oxDNA1, 2 = oxDNA2, 3 = oxRNA2 (mythos/energy/rna2/: backbone site on a1 and a3, stacking between the
  *             3' / 5' sites with theta9 / theta10, cross-stacking without theta4, oxDNA1-form coaxial term, Debye-Hueckel)
+ *             4 = oxNA, hybrid DNA / RNA systems (mythos/energy/na1/): every pair takes the parameter vector and the
+ *             functional forms of its kind - DNA-DNA: oxDNA2, RNA-RNA: oxRNA2, DNA-RNA: the hybrid numbers in the oxDNA1
+ *             forms - and every nucleotide the sites of its own type.  Such a system needs
+ *             mythos_oxdna_set_nucleotide_types, takes 3 x mythos_oxdna_param_count() parameters (the oxDNA2, oxRNA2 and
+ *             hybrid vectors one after the other; dU_dparams rows have the same layout), and is evaluated by the energy
+ *             entry points only (no integrator, no structural observables, no probabilistic sequence).
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
  *   bonded    host int32[n_bonded][2] rows (nn_i, nn_j) as mythos/input/topology.py:166-183
@@ -82,8 +88,13 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
                                      const int32_t* bonded, const double* box, int dtype, int device);
 void mythos_oxdna_destroy(mythos_system_t* sys);
 
-/* host double[n_params] in mythos_oxdna_param_name() order; replaces with_params() at the boundary */
+/* host double[n_params] in mythos_oxdna_param_name() order (oxNA: three such vectors); replaces with_params() at the boundary */
 int mythos_oxdna_set_params(mythos_system_t* sys, const double* flat_params, int n_params);
+
+/* oxNA (model 4) only: which nucleotides are RNA - the `nt_type` every na1 *Configuration carries
+ * (mythos/energy/na1/fene.py:22, mythos/input/topology.py NucleotideType; is_rna_pair / is_dna_rna_pair in
+ * mythos/energy/na1/utils.py:9-16).  host uint8[n], 1 = RNA, 0 = DNA. */
+int mythos_oxdna_set_nucleotide_types(mythos_system_t* sys, const uint8_t* is_rna);
 
 /* Probabilistic sequence: replaces `pseq` / `pseq_constraints` of StackingConfiguration and
  * HydrogenBondingConfiguration (mythos/energy/dna1/stacking.py:54-55, 261-287, dna1/hydrogen_bonding.py:94-95, 308-333)

@@ -52,6 +52,7 @@ def load() -> C.CDLL:
         "mythos_oxdna_destroy": (None, [V]),
         "mythos_oxdna_set_params": (C.c_int, [V, c_double_p, C.c_int]),
         "mythos_oxdna_set_pseq": (C.c_int, [V, c_double_p, c_int_p, C.c_int, c_double_p, C.c_int]),
+        "mythos_oxdna_set_nucleotide_types": (C.c_int, [V, c_uint8_p]),
         "mythos_oxdna_set_neighbors": (C.c_int, [V, c_int_p, C.c_int]),
         "mythos_oxdna_build_neighbors": (C.c_int, [V, V, C.c_double, C.c_double, V]),
         "mythos_oxdna_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
@@ -112,6 +113,7 @@ DECLARED_SYMBOLS = (
     "mythos_oxdna_destroy",
     "mythos_oxdna_set_params",
     "mythos_oxdna_set_pseq",
+    "mythos_oxdna_set_nucleotide_types",
     "mythos_oxdna_set_neighbors",
     "mythos_oxdna_build_neighbors",
     "mythos_oxdna_neighbor_stats",

@@ -48,7 +48,7 @@ const char* mythos_oxdna_param_name(int index) {
 mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded,
                                      const int32_t* bonded, const double* box, int dtype, int device) {
   g_last_error.clear();
-  if ((model < 1 || model > 3) || n < 1 || !seq || n_bonded < 0 || (n_bonded > 0 && !bonded) ||
+  if ((model < 1 || model > 4) || n < 1 || !seq || n_bonded < 0 || (n_bonded > 0 && !bonded) ||
       (dtype != MYTHOS_F32 && dtype != MYTHOS_F64) || n >= ROW_ROLE_Q) {
     set_error("mythos_oxdna_create: invalid argument");
     return nullptr;
@@ -90,6 +90,7 @@ mythos_system_t* mythos_oxdna_create(int model, int n, const int32_t* seq, const
     }
     meta[i] = seq[i] | ((is_end && is_end[i]) ? 4 : 0);
   }
+  s->h_meta = meta;
   s->h_partners.assign((size_t)ROW_BONDED_SLOTS * n, -1);
   for (int b = 0; b < n_bonded; ++b) {
     const int i = bonded[2 * b], j = bonded[2 * b + 1];
@@ -148,28 +149,51 @@ void mythos_oxdna_destroy(mythos_system_t* s) {
 }
 
 int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params) {
-  if (!s || !flat || n_params != (int)OXP_COUNT) {
-    set_error("mythos_oxdna_set_params: expected " + std::to_string((int)OXP_COUNT) + " parameters");
+  const int sets = s ? s->param_sets() : 1;
+  const int total = sets * (int)OXP_COUNT;
+  if (!s || !flat || n_params != total) {
+    set_error("mythos_oxdna_set_params: expected " + std::to_string(total) + " parameters" +
+              (sets == 3 ? " (oxNA: the oxDNA2, oxRNA2 and hybrid vectors one after the other)" : ""));
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  for (int k = 0; k < n_params; ++k) {
+  for (int k = 0; k < n_params; ++k)
     if (!std::isfinite(flat[k])) {
-      set_error(std::string("mythos_oxdna_set_params: non-finite value for ") + kParamNames[k]);
+      set_error(std::string("mythos_oxdna_set_params: non-finite value for ") + kParamNames[k % (int)OXP_COUNT]);
       return MYTHOS_ERR_NUMERIC;
     }
+  for (int k = 0; k < (int)OXP_COUNT; ++k) {
     s->pd.v[k] = flat[k];
     s->pf.v[k] = (float)flat[k];
   }
+  s->pd_sets.assign(flat, flat + total);
+  std::vector<float> pf_sets(flat, flat + total);
   // device copies for the MD kernel; a blocking copy after a device-wide sync, so no kernel in flight
   // sees a half-written vector
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
-  if (!s->d_pf) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pf, OXP_COUNT * sizeof(float)));
-  if (!s->d_pd) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pd, OXP_COUNT * sizeof(double)));
+  if (!s->d_pf) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pf, total * sizeof(float)));
+  if (!s->d_pd) MYTHOS_HIP_TRY(hipMalloc((void**)&s->d_pd, total * sizeof(double)));
   MYTHOS_HIP_TRY(hipDeviceSynchronize());
-  MYTHOS_HIP_TRY(hipMemcpy(s->d_pf, s->pf.v, OXP_COUNT * sizeof(float), hipMemcpyHostToDevice));
-  MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd.v, OXP_COUNT * sizeof(double), hipMemcpyHostToDevice));
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_pf, pf_sets.data(), total * sizeof(float), hipMemcpyHostToDevice));
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd_sets.data(), total * sizeof(double), hipMemcpyHostToDevice));
   s->params_set = true;
   ++s->list_epoch;  // cut-offs may have moved: integrators rebuild their list
+  return MYTHOS_OK;
+}
+
+int mythos_oxdna_set_nucleotide_types(mythos_system_t* s, const uint8_t* is_rna) {
+  if (!s || !is_rna) {
+    set_error("mythos_oxdna_set_nucleotide_types: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (s->model != 4) {
+    set_error("mythos_oxdna_set_nucleotide_types: only an oxNA system (model 4) has nucleotide types");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  for (int i = 0; i < s->n; ++i) s->h_meta[i] = (s->h_meta[i] & 7) | (is_rna[i] ? 8 : 0);
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  MYTHOS_HIP_TRY(hipDeviceSynchronize());
+  MYTHOS_HIP_TRY(hipMemcpy(s->d_meta, s->h_meta.data(), s->n * sizeof(int), hipMemcpyHostToDevice));
+  s->types_set = true;
   return MYTHOS_OK;
 }
 
@@ -177,6 +201,10 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
                           int terms) {
   if (!s || terms < 0 || terms > 3 || n_bp < 0 || (terms != 0 && (!marginals || !unit || (n_bp > 0 && !bp_probs)))) {
     set_error("mythos_oxdna_set_pseq: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (s->model == 4 && terms != 0) {
+    set_error("mythos_oxdna_set_pseq: probabilistic sequences are not available for oxNA systems (model 4)");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
@@ -271,8 +299,8 @@ int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat
     set_error("mythos_oxdna_energy: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (!s->params_set || !s->nbrs_set) {
-    set_error("mythos_oxdna_energy: parameters and neighbours must be set first");
+  if (!s->params_set || !s->nbrs_set || (s->model == 4 && !s->types_set)) {
+    set_error("mythos_oxdna_energy: parameters and neighbours (and, for oxNA, nucleotide types) must be set first");
     return MYTHOS_ERR_NOT_READY;
   }
   if (n_frames == 0) return MYTHOS_OK;  // an empty batch (its buffers may be null) is not an error
@@ -292,9 +320,13 @@ int mythos_oxdna_energy_obs(mythos_system_t* s, const void* center, const void* 
     set_error("mythos_oxdna_energy_obs: the observable set was made for another system size, precision or device");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (!s->params_set || !s->nbrs_set) {
-    set_error("mythos_oxdna_energy_obs: parameters and neighbours must be set first");
+  if (!s->params_set || !s->nbrs_set || (s->model == 4 && !s->types_set)) {
+    set_error("mythos_oxdna_energy_obs: parameters and neighbours (and, for oxNA, nucleotide types) must be set first");
     return MYTHOS_ERR_NOT_READY;
+  }
+  if (obs && s->model == 4) {
+    set_error("mythos_oxdna_energy_obs: the structural observables take one site geometry; an oxNA system has two");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   if (n_frames == 0) return MYTHOS_OK;
   MYTHOS_HIP_TRY(hipSetDevice(s->device));

@@ -1288,6 +1288,11 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
     set_error("mythos_langevin_create: invalid argument");
     return nullptr;
   }
+  if (sys->model == 4) {
+    set_error("mythos_langevin_create: oxNA systems (model 4) are evaluated by the energy entry points only; the fused "
+              "step kernel has no hybrid DNA / RNA instantiation");
+    return nullptr;
+  }
   if (hipSetDevice(sys->device) != hipSuccess) {
     set_error("mythos_langevin_create: hipSetDevice failed");
     return nullptr;

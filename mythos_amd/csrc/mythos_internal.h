@@ -83,6 +83,11 @@ struct mythos_system {
   bool params_set = false;
   mythos::OxParams<float> pf;
   mythos::OxParams<double> pd;
+  // oxNA (model 4): three vectors - oxDNA2 (also in pf / pd), oxRNA2, hybrid - one after the other, host and device
+  std::vector<double> pd_sets;
+  int param_sets() const { return model == 4 ? 3 : 1; }
+  bool types_set = false;  // model 4: mythos_oxdna_set_nucleotide_types has run
+  std::vector<int> h_meta;  // seq | is_end << 2 | is_rna << 3, as uploaded to d_meta
   float* d_pf = nullptr;   // the same vectors in device memory (read by the MD kernel as scalar loads)
   double* d_pd = nullptr;
 

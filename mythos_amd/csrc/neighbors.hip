@@ -343,7 +343,8 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   R* ref_a1 = write_refs ? (R*)sys->d_ref_a1 : nullptr;
   const int n = sys->n;
   // classification radius of the leading "close" segment (everything is close until parameters exist)
-  const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
+  // (oxNA systems are evaluated by the energy kernel only, which does not use the segment)
+  const double rcl = (sys->params_set && sys->model != 4) ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
   int* d_close = row_close_of(sys);
   // range of the backbone-backbone terms (excluded volume, and Debye-Hueckel in oxDNA2) for the far segment
   double rbb = rl;

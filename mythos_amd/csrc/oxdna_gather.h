@@ -42,6 +42,7 @@ struct PackedLoader {
     const int m = meta[j];
     o.seq = m & 3;
     o.is_end = (m >> 2) & 1;
+    o.rna = (m >> 3) & 1;
     o.idx = j;
   }
 };
@@ -69,6 +70,7 @@ struct Vec4Loader {
     const int m = meta[j];
     o.seq = m & 3;
     o.is_end = (m >> 2) & 1;
+    o.rna = (m >> 3) & 1;
     o.idx = j;
   }
 };

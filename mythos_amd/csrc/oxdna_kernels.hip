@@ -55,8 +55,10 @@ struct LdsPG {
 #ifndef EN_LB
 #define EN_LB 3
 #endif
-template <typename R, int MODE>
+template <typename R, int MODE, int MODEL = 2>
 constexpr int energy_blocks_per_cu() {
+  // oxNA with parameter partials: eight accumulator copies of three vectors are 50 KB of LDS - two workgroups per CU
+  if (MODEL == 4 && MODE == 2) return 2;
   // fp64: the energy-only mode runs faster at three workgroups per CU with 100 B of scratch than at two without
   // (0.58 -> 0.49 ms on the DiffTRe shape); the gradient modes spill too much for that (0.72 -> 1.43 ms)
   // fp32 forces mode: 128 registers without scratch, so four fit (at three the allocator takes 138 and the call is 18 % slower)
@@ -67,7 +69,7 @@ constexpr int energy_blocks_per_cu() {
 // OBS: the instantiation carries the observables epilogue.  A template parameter, not a run-time branch: the epilogue's
 // fp64 site algebra would otherwise set the register count of every launch (energy-only fp32: 96 -> 128 VGPRs + scratch).
 template <typename R, int MODEL, int MODE, int G, bool SEG, bool OBS>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
-__global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxdna_energy_kernel(
+__global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) void oxdna_energy_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
@@ -81,11 +83,19 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE>())) void oxd
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
+  // (oxNA, MODEL 4: three vectors one after the other - oxDNA2, oxRNA2, hybrid; no probabilistic sequence)
+  const auto P = [&] {
+    if constexpr (MODEL == 4) {
+      using CP = ConstParams<R, false>;
+      return Na1Params<CP>{CP(Pg), CP(Pg + OXP_COUNT), CP(Pg + 2 * OXP_COUNT)};
+    } else {
 #ifdef MYTHOS_EN_NO_PSEQ  // (dev A/B)
-  const ConstParams<R, false> P(Pg);
+      return ConstParams<R, false>(Pg);
 #else
-  const ConstParams<R, true> P(Pg, pseq);
+      return ConstParams<R, true>(Pg, pseq);
 #endif
+    }
+  }();
 
   const int frame = blockIdx.y;
   const int grp = threadIdx.x / G;
@@ -259,22 +269,27 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   const int blocks = (n + PPB - 1) / PPB;
   const int mode = dU_dparams ? 2 : ((dU_dcenter || dU_dquat) ? 1 : 0);
   // frames per chunk bounded by scratch (<= 256 MB of parameter partials) and the 65535 grid.y limit
-  size_t per_frame = (size_t)blocks * (mode == 2 ? OXP_COUNT : T_COUNT) * sizeof(double);
+  const int n_out = sys->param_sets() * (int)OXP_COUNT;  // width of a dU/dparams row
+  size_t per_frame = (size_t)blocks * (mode == 2 ? n_out : T_COUNT) * sizeof(double);
   int chunk = (int)std::min<size_t>(65535, std::max<size_t>(1, (size_t(256) << 20) / per_frame));
   chunk = std::min(chunk, n_frames);
   if (int rc = ensure(sys->d_epart, sys->epart_cap, (size_t)chunk * blocks * T_COUNT)) return rc;
   if (mode == 2)
-    if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * OXP_COUNT)) return rc;
+    if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * n_out)) return rc;
   const R* P = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
   // centre distance beyond which no site pair of two nucleotides is inside any cut-off: the longest range of a term
   // plus twice the farthest site from the centre (with a margin for the rounding of the comparison)
-  const OxParams<double>& Pd = sys->pd;
-  double range = std::max({(double)Pd[NEXC_BACKBONE_RC], (double)Pd[NEXC_BASE_RC], (double)Pd[NEXC_BACK_BASE_RC],
-                           (double)Pd[NEXC_BASE_BACK_RC], (double)Pd[HYDR_RCHIGH], (double)Pd[CRST_RCHIGH], (double)Pd[CXST_RCHIGH]});
-  if (MODEL >= 2) range = std::max(range, (double)Pd[DH_RCUT]);
-  const double reach = std::max({std::hypot((double)Pd[GEO_BACK_A1], MODEL >= 2 ? (double)Pd[GEO_BACK_A2] : 0.0),
-                                 std::fabs((double)Pd[GEO_BASE]), std::fabs((double)Pd[GEO_STACK])});
+  // (oxNA: the largest over its three vectors; the oxRNA2 stacking sites are bonded-only and do not enter)
+  double range = 0.0, reach = 0.0;
+  for (int k = 0; k < sys->param_sets(); ++k) {
+    const double* Pd = sys->param_sets() == 1 ? sys->pd.v : sys->pd_sets.data() + (size_t)k * OXP_COUNT;
+    range = std::max({range, Pd[NEXC_BACKBONE_RC], Pd[NEXC_BASE_RC], Pd[NEXC_BACK_BASE_RC], Pd[NEXC_BASE_BACK_RC], Pd[HYDR_RCHIGH],
+                      Pd[CRST_RCHIGH], Pd[CXST_RCHIGH]});
+    if (MODEL >= 2) range = std::max(range, Pd[DH_RCUT]);
+    reach = std::max({reach, std::hypot(Pd[GEO_BACK_A1], MODEL >= 2 ? Pd[GEO_BACK_A2] : 0.0), std::fabs(Pd[GEO_BASE]),
+                      std::fabs(Pd[GEO_STACK])});
+  }
   const double rnear = (range + 2.0 * reach) * (1.0 + 1e-4) + 1e-4;
   const R rnear2 = R(rnear * rnear);
   PseqView<R> pseq;
@@ -326,7 +341,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
                        e_terms + (size_t)f0 * T_COUNT, (int)T_COUNT);
     if (mode == 2)
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(256), 0, stream, sys->d_pgpart, blocks,
-                         oxp_used<MODEL>(), dU_dparams + (size_t)f0 * OXP_COUNT, (int)OXP_COUNT);
+                         oxp_used<MODEL>(), dU_dparams + (size_t)f0 * n_out, n_out);
     MYTHOS_HIP_TRY(hipGetLastError());
   }
   return 0;
@@ -344,11 +359,17 @@ int oxdna_energy_launch(mythos_system* sys, const void* center, const void* quat
     if (sys->model == 3)
       return launch_typed<float, 3, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
                                        (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
+    if (sys->model == 4)
+      return launch_typed<float, 4, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
+                                       (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
     return launch_typed<float, 2, 8>(sys, (const float*)center, (const float*)quat, n_frames, e_terms,
                                      (float*)dU_dcenter, (float*)dU_dquat, dU_dparams, oset, obs_out, stream);
   }
   if (sys->model == 1)
     return launch_typed<double, 1, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
+                                      (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
+  if (sys->model == 4)
+    return launch_typed<double, 4, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,
                                       (double*)dU_dcenter, (double*)dU_dquat, dU_dparams, oset, obs_out, stream);
   if (sys->model == 3)
     return launch_typed<double, 3, 8>(sys, (const double*)center, (const double*)quat, n_frames, e_terms,

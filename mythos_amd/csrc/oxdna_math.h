@@ -25,7 +25,7 @@ enum OxParamIndex : int {
 constexpr int OXP_COUNT_DNA = GEO_STACK3_A1;
 template <int MODEL>
 constexpr int oxp_used() {
-  return MODEL == 3 ? (int)OXP_COUNT : OXP_COUNT_DNA;
+  return MODEL == 4 ? 3 * (int)OXP_COUNT : (MODEL == 3 ? (int)OXP_COUNT : OXP_COUNT_DNA);  // oxNA: three vectors
 }
 
 // The flat parameter vector on the host (and, for the Debye / cut-off helpers, as a plain array).

@@ -41,6 +41,7 @@ struct Nuc {
   int seq;
   int is_end;
   int idx;  // nucleotide index: read only where the parameter accessor carries a probabilistic sequence
+  int rna;  // oxNA (MODEL 4): the nucleotide is RNA (topology nt_type); not read by the other instantiations
 };
 
 // axes from an (un-normalised) quaternion, mythos/energy/utils.py:18-36
@@ -173,11 +174,114 @@ __device__ __forceinline__ R f3_site_pair(const PT& P, int ie, const F3P<R>& fp,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Where the sites of the two nucleotides of an UNBONDED pair are.  UniGeo: both nucleotides have the geometry of the
+// one model (what every instantiation but oxNA uses; it compiles to the site algebra written out by hand).
+// HybGeo: oxNA's DNA-RNA pairs (mythos/energy/na1/nucleotide.py:12-78 + the (nucleotide.dna, nucleotide.rna) argument
+// pairs of the hybrid branches, e.g. na1/hydrogen_bonding.py:336-348): each nucleotide has the sites of its OWN type -
+// oxDNA2 offsets with the backbone on a1 / a2, or oxRNA2 offsets with the backbone on a1 / a3 - chosen per lane.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int MODEL>
+struct UniGeo {
+  static constexpr int BX = back_axis<MODEL>();
+  R st, ba, k1, k2;
+  template <class PT>
+  __device__ __forceinline__ explicit UniGeo(const PT& P)
+      : st(P[GEO_STACK]), ba(P[GEO_BASE]), k1(P[GEO_BACK_A1]), k2((MODEL >= 2) ? P[GEO_BACK_A2] : R(0)) {}
+  __device__ __forceinline__ V3<R> back_back(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return site_disp<BX>(dco, s, o, k1, k2, k1, k2); }
+  __device__ __forceinline__ V3<R> back_base(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return site_disp<BX>(dco, s, o, k1, k2, ba, R(0)); }
+  __device__ __forceinline__ V3<R> base_back(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return site_disp<BX>(dco, s, o, ba, R(0), k1, k2); }
+  __device__ __forceinline__ V3<R> base_base(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return site_disp(dco, s, o, ba, R(0), ba, R(0)); }
+  __device__ __forceinline__ V3<R> stack_stack(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return site_disp(dco, s, o, st, R(0), st, R(0)); }
+  __device__ __forceinline__ void acc_back(SelfGrad<R>& sg, V3<R> gd) const { acc_self_site<BX>(sg, gd, k1, k2); }
+  __device__ __forceinline__ void acc_base(SelfGrad<R>& sg, V3<R> gd) const { acc_self_site(sg, gd, ba, R(0)); }
+  __device__ __forceinline__ void acc_stack(SelfGrad<R>& sg, V3<R> gd) const { acc_self_site(sg, gd, st, R(0)); }
+};
+
+template <typename R>
+struct HybGeo {
+  R st_s, ba_s, k1_s, k2_s, st_o, ba_o, k1_o, k2_o;
+  bool s3, o3;  // the second backbone coefficient multiplies a3 (RNA) instead of a2 (DNA)
+  template <class PT>
+  __device__ __forceinline__ HybGeo(const PT& Pd, const PT& Pr, bool s_rna, bool o_rna) : s3(s_rna), o3(o_rna) {
+    const R st_d = Pd[GEO_STACK], ba_d = Pd[GEO_BASE], k1_d = Pd[GEO_BACK_A1], k2_d = Pd[GEO_BACK_A2];
+    const R st_r = Pr[GEO_STACK], ba_r = Pr[GEO_BASE], k1_r = Pr[GEO_BACK_A1], k2_r = Pr[GEO_BACK_A2];
+    st_s = s_rna ? st_r : st_d, ba_s = s_rna ? ba_r : ba_d, k1_s = s_rna ? k1_r : k1_d, k2_s = s_rna ? k2_r : k2_d;
+    st_o = o_rna ? st_r : st_d, ba_o = o_rna ? ba_r : ba_d, k1_o = o_rna ? k1_r : k1_d, k2_o = o_rna ? k2_r : k2_d;
+  }
+  __device__ __forceinline__ V3<R> disp(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o, R als, R bes, R alo, R beo) const {
+    V3<R> d = dco;
+    axpy(d, alo, o.a1);
+    axpy(d, beo, o3 ? o.a3 : o.a2);
+    axpy(d, -als, s.a1);
+    axpy(d, -bes, s3 ? s.a3 : s.a2);
+    return d;
+  }
+  __device__ __forceinline__ V3<R> back_back(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, k1_s, k2_s, k1_o, k2_o); }
+  __device__ __forceinline__ V3<R> back_base(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, k1_s, k2_s, ba_o, R(0)); }
+  __device__ __forceinline__ V3<R> base_back(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, ba_s, R(0), k1_o, k2_o); }
+  __device__ __forceinline__ V3<R> base_base(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, ba_s, R(0), ba_o, R(0)); }
+  __device__ __forceinline__ V3<R> stack_stack(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, st_s, R(0), st_o, R(0)); }
+  __device__ __forceinline__ void acc_back(SelfGrad<R>& sg, V3<R> gd) const {
+    axpy(sg.dc, R(-1), gd);
+    axpy(sg.g1, -k1_s, gd);
+    axpy(sg.g2, s3 ? R(0) : -k2_s, gd);
+    axpy(sg.g3, s3 ? -k2_s : R(0), gd);
+  }
+  __device__ __forceinline__ void acc_base(SelfGrad<R>& sg, V3<R> gd) const { acc_self_site(sg, gd, ba_s, R(0)); }
+  __device__ __forceinline__ void acc_stack(SelfGrad<R>& sg, V3<R> gd) const { acc_self_site(sg, gd, st_s, R(0)); }
+};
+
+// one radial f3 site pair of an unbonded pair; SITE: which of self's sites d starts from (0 backbone, 1 base)
+template <typename R, bool GRAD, class PG, int SITE, class PT, class GEO>
+__device__ __forceinline__ R f3_site_pair_geo(const PT& P, int ie, const F3P<R>& fp, V3<R> d, R tw, SelfGrad<R>& sg, PG& pg,
+                                              const GEO& geo) {
+  const R r = m_sqrt(dot(d, d));
+  const FD<R> v = f3_eval(r, P[ie], fp);
+  if constexpr (GRAD)
+    if (v.d != R(0)) {
+      if constexpr (SITE == 0) geo.acc_back(sg, (tw * v.d / r) * d); else geo.acc_base(sg, (tw * v.d / r) * d);
+    }
+  f3_pgrad(r, P[ie], ie, fp, tw, pg);
+  return v.f;
+}
+
+// oxNA: the three parameter vectors of a hybrid system, one after the other in device memory (DNA-DNA pairs: the oxDNA2
+// vector; RNA-RNA: the oxRNA2 vector; DNA-RNA: the hybrid numbers in the oxDNA1 forms), and a parameter-gradient sink
+// that files a partial under its vector.
+template <class PT>
+struct Na1Params {
+  static constexpr bool indexed = false;
+  static constexpr bool has_pseq = false;
+  PT dna, rna, drh;
+};
+template <class PG>
+struct OffsetPG {
+  static constexpr bool on = PG::on;
+  PG& pg;
+  int base;
+  template <typename R>
+  __device__ __forceinline__ void add(int idx, R v) const {
+    pg.add(base + idx, v);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
 // bonded pair: FENE + bonded excluded volume + stacking.   role_p: self is nn_i of the bond.
 // ------------------------------------------------------------------------------------------------
 template <typename R, int MODEL, bool GRAD, class PG, class PT>
 __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                             bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  if constexpr (MODEL == 4) {
+    // oxNA (na1/fene.py:89-106, bonded_excluded_volume.py:96-116, stacking.py:193-217): a bond between two RNA
+    // nucleotides is an oxRNA2 bond; any other bond is evaluated as an oxDNA2 bond on the oxDNA2 sites
+    if (s.rna && o.rna) {
+      OffsetPG<PG> opg{pg, (int)OXP_COUNT};
+      bonded_pair<R, 3, GRAD, OffsetPG<PG>>(P.rna, s, o, dco, role_p, wgt, e, sg, opg);
+    } else {
+      OffsetPG<PG> opg{pg, 0};
+      bonded_pair<R, 2, GRAD, OffsetPG<PG>>(P.dna, s, o, dco, role_p, wgt, e, sg, opg);
+    }
+  } else {
   constexpr int BX = back_axis<MODEL>();
   const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
   const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
@@ -373,6 +477,7 @@ __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const 
       acc_self_site(sg, gdb, g_d1, R(0));
     }
   }
+  }  // MODEL != 4
 }
 
 // radial supports of the angular unbonded terms: H-bond / cross-stacking act on the base-base
@@ -391,23 +496,19 @@ __device__ __forceinline__ bool cxst_support(const PT& P, R r) {
 // angular terms (H-bond, cross-stacking, coaxial stacking) can be non-zero for this pair.
 // role_p: self is op_i of the ordered pair.
 // ------------------------------------------------------------------------------------------------
-template <typename R, int MODEL, bool GRAD, class PG, class PT>
-__device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
-                                                bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
-  const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
-  constexpr int BX = back_axis<MODEL>();
-
+template <typename R, int MODEL, bool GRAD, class PG, class PT, class GEO>
+__device__ __forceinline__ bool unbonded_radial_geo(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco, bool role_p, R wgt,
+                                                    R* __restrict__ e, SelfGrad<R>& sg, PG& pg, const GEO& geo) {
   // ---- backbone-backbone: excluded volume and (dna2) Debye-Hueckel share the distance
   {
-    const V3<R> d = site_disp<BX>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+    const V3<R> d = geo.back_back(dco, s, o);
     const R r = m_sqrt(dot(d, d));
     const F3P<R> fp = f3_params<R>(P, NEXC_BACKBONE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     R dVdr = P[TW_NEXC] * v.d;
     f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
-    if constexpr (MODEL >= 2) {  // oxDNA2 and oxRNA2 carry the Debye-Hueckel term
+    if constexpr (MODEL >= 2) {  // oxDNA2, oxRNA2 and the oxNA hybrid pairs carry the Debye-Hueckel term
       const FD<R> dh = debye_eval(r, P);
       R mult = R(1);
       if (P[DH_HALF_CHARGED_ENDS] != R(0)) mult = (s.is_end ? R(0.5) : R(1)) * (o.is_end ? R(0.5) : R(1));
@@ -416,34 +517,63 @@ __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, co
       debye_pgrad(r, P, P[TW_DH] * mult, pg);
     }
     if constexpr (GRAD)
-      if (dVdr != R(0)) acc_self_site<BX>(sg, (dVdr / r) * d, g_k1, g_k2);
+      if (dVdr != R(0)) geo.acc_back(sg, (dVdr / r) * d);
   }
   // ---- self backbone - other base ("back_p - base_q" if self is p) and self base - other backbone
   {
-    R en = f3_site_pair<R, GRAD, PG, BX>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
-                                         site_disp<BX>(dco, s, o, g_k1, g_k2, g_ba, R(0)), g_k1, g_k2, P[TW_NEXC], sg, pg);
-    en += f3_site_pair<R, GRAD, PG>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
-                                    site_disp<BX>(dco, s, o, g_ba, R(0), g_k1, g_k2), g_ba, R(0), P[TW_NEXC], sg, pg);
+    R en = f3_site_pair_geo<R, GRAD, PG, 0>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BACK_BASE_RSTAR, NEXC_BASE_BACK_RSTAR),
+                                            geo.back_base(dco, s, o), P[TW_NEXC], sg, pg, geo);
+    en += f3_site_pair_geo<R, GRAD, PG, 1>(P, NEXC_EPS, f3_params_sel<R>(P, role_p, NEXC_BASE_BACK_RSTAR, NEXC_BACK_BASE_RSTAR),
+                                           geo.base_back(dco, s, o), P[TW_NEXC], sg, pg, geo);
     e[T_NEXC] += wgt * en;
   }
   // ---- base-base excluded volume
   bool angular;
   {
-    const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
+    const V3<R> d = geo.base_base(dco, s, o);
     const R r = m_sqrt(dot(d, d));
     const F3P<R> fp = f3_params<R>(P, NEXC_BASE_RSTAR);
     const FD<R> v = f3_eval(r, P[NEXC_EPS], fp);
     e[T_NEXC] += wgt * v.f;
     f3_pgrad(r, P[NEXC_EPS], NEXC_EPS, fp, P[TW_NEXC], pg);
     if constexpr (GRAD)
-      if (v.d != R(0)) acc_self_site(sg, (P[TW_NEXC] * v.d / r) * d, g_ba, R(0));
+      if (v.d != R(0)) geo.acc_base(sg, (P[TW_NEXC] * v.d / r) * d);
     angular = hb_crst_support(P, r);
   }
   {
-    const V3<R> d = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
+    const V3<R> d = geo.stack_stack(dco, s, o);
     angular = angular || cxst_support(P, m_sqrt(dot(d, d)));
   }
   return angular;
+}
+
+// Which parameter vector and functional form an unbonded oxNA pair takes (na1/unbonded_excluded_volume.py:140-174 and
+// the other unbonded terms): both RNA -> oxRNA2, both DNA -> oxDNA2, one of each -> the hybrid numbers in the oxDNA1
+// forms (cross-stacking with theta4, coaxial stacking with f5 of cos phi3 / phi4) plus Debye-Hueckel: "MODEL 4" below.
+#define MYTHOS_NA1_UNBONDED(FN, ...)                                                                       \
+  if (s.rna && o.rna) {                                                                                    \
+    OffsetPG<PG> opg{pg, (int)OXP_COUNT};                                                                  \
+    const UniGeo<R, 3> geo(P.rna);                                                                         \
+    return FN<R, 3, GRAD, OffsetPG<PG> __VA_ARGS__>(P.rna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
+  }                                                                                                        \
+  if (!s.rna && !o.rna) {                                                                                  \
+    OffsetPG<PG> opg{pg, 0};                                                                               \
+    const UniGeo<R, 2> geo(P.dna);                                                                         \
+    return FN<R, 2, GRAD, OffsetPG<PG> __VA_ARGS__>(P.dna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
+  }                                                                                                        \
+  OffsetPG<PG> opg{pg, 2 * (int)OXP_COUNT};                                                                \
+  const HybGeo<R> geo(P.dna, P.rna, s.rna != 0, o.rna != 0);                                               \
+  return FN<R, 4, GRAD, OffsetPG<PG> __VA_ARGS__>(P.drh, s, o, dco, role_p, wgt, e, sg, opg, geo);
+
+template <typename R, int MODEL, bool GRAD, class PG, class PT>
+__device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                                bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  if constexpr (MODEL == 4) {
+    MYTHOS_NA1_UNBONDED(unbonded_radial_geo)
+  } else {
+    const UniGeo<R, MODEL> geo(P);
+    return unbonded_radial_geo<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg, geo);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,18 +587,14 @@ __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, co
 // TERMS selects which terms are compiled in: 1 = H-bond, 2 = cross-stacking, 4 = coaxial stacking.  The MD
 // kernel instantiates the three separately so that each wavefront of its angular pass runs one term on a
 // homogeneous work list; the energy path uses all three (7).
-template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT>
-__device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
-                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
-  const R g_st = P[GEO_STACK], g_ba = P[GEO_BASE], g_k1 = P[GEO_BACK_A1];
-  const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
-  constexpr int BX = back_axis<MODEL>();
-  constexpr bool kCoaxF5 = MODEL != 2;  // dna1-style coaxial term, f5(cos phi3) f5(cos phi4): oxDNA1 and oxRNA2 (rna2/tests/test_integration.py:258-287)
-  (void)g_st;
-  (void)g_k1;
-  (void)g_k2;
+template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT, class GEO>
+__device__ __forceinline__ bool unbonded_angular_geo(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco, bool role_p, R wgt,
+                                                     R* __restrict__ e, SelfGrad<R>& sg, PG& pg, const GEO& geo) {
+  // dna1-style coaxial term, f5(cos phi3) f5(cos phi4): oxDNA1, oxRNA2 (rna2/tests/test_integration.py:258-287) and the
+  // oxNA hybrid pairs (na1/coaxial_stacking.py:272-284)
+  constexpr bool kCoaxF5 = MODEL != 2;
   if constexpr ((TERMS & 3) != 0) {
-    const V3<R> d = site_disp(dco, s, o, g_ba, R(0), g_ba, R(0));
+    const V3<R> d = geo.base_base(dco, s, o);
     const R r = m_sqrt(dot(d, d));
     V3<R> gd{R(0), R(0), R(0)};
     bool any = false;
@@ -601,15 +727,15 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
       }
     }
     if constexpr (GRAD)
-      if (any) acc_self_site(sg, gd, g_ba, R(0));
+      if (any) geo.acc_base(sg, gd);
   }
   // ---- coaxial stacking on the stacking sites.  Reference: dr = stack_q - stack_p,
   //      theta5 = acos(a3p.n), theta6 = acos(-a3q.n); self/other cosines a3s.n and -a3o.n.
   if constexpr ((TERMS & 4) != 0) {
-    const V3<R> d = site_disp(dco, s, o, g_st, R(0), g_st, R(0));
+    const V3<R> d = geo.stack_stack(dco, s, o);
     const R r = m_sqrt(dot(d, d));
     const FD<R> F2 = f2_eval(r, P, CXST_RLOW);
-    if (F2.f == R(0) && F2.d == R(0)) return;
+    if (F2.f == R(0) && F2.d == R(0)) return true;
     const R ir = R(1) / r;
     const V3<R> n = ir * d;
     const R c4 = dot(s.a3, o.a3);
@@ -621,13 +747,13 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
     const F4P<R> ps = f4_params_sel<R>(P, role_p, CXST_TH5_T0, CXST_TH6_T0);
     const F4P<R> po = f4_params_sel<R>(P, role_p, CXST_TH6_T0, CXST_TH5_T0);
     const FD<R> A4 = f4_eval(t4.f, p4);
-    if (A4.f == R(0)) return;
+    if (A4.f == R(0)) return true;
     const FD<R> Sa = f4_eval(ts.f, ps), Sb = f4_eval(R(kPi) - ts.f, ps);
     const R Hs = Sa.f + Sb.f;
-    if (Hs == R(0)) return;
+    if (Hs == R(0)) return true;
     const FD<R> Oa = f4_eval(to.f, po), Ob = f4_eval(R(kPi) - to.f, po);
     const R Ho = Oa.f + Ob.f;
-    if (Ho == R(0)) return;
+    if (Ho == R(0)) return true;
     const FD<R> A1a = f4_eval(t1.f, p1);
     FD<R> A1b;
     R dH1;
@@ -639,7 +765,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
       dH1 = A1a.d + A1b.d;
     }
     const R H1 = A1a.f + A1b.f;
-    if (H1 == R(0)) return;
+    if (H1 == R(0)) return true;
     R phi = R(1);
     FD<R> Bs{R(1), R(0)}, Bo{R(1), R(0)};
     R xs = R(0), xo = R(0), irb = R(0);
@@ -648,7 +774,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
     if constexpr (kCoaxF5) {
       // cos(phi3) = n.(nb x a1q), cos(phi4) = n.(nb x a1p): both vectors flip with the role, the
       // triple product does not.
-      const V3<R> db = site_disp<BX>(dco, s, o, g_k1, g_k2, g_k1, g_k2);
+      const V3<R> db = geo.back_back(dco, s, o);
       irb = m_rsqrt(dot(db, db));
       nb = irb * db;
       xs = dot(n, cross(nb, s.a1));
@@ -658,7 +784,7 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
       Bs = f5_eval(xs, qs);
       Bo = f5_eval(xo, qo);
       phi = Bs.f * Bo.f;
-      if (phi == R(0)) return;
+      if (phi == R(0)) return true;
     }
     const R ang = A4.f * H1 * Hs * Ho;
     e[T_CXST] += wgt * F2.f * ang * phi;
@@ -705,10 +831,22 @@ __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, c
         V3<R> gdb{R(0), R(0), R(0)};
         axpy(gdb, irb, gnb);
         axpy(gdb, -irb * dot(gnb, nb), nb);
-        acc_self_site<BX>(sg, gdb, g_k1, g_k2);
+        geo.acc_back(sg, gdb);
       }
-      acc_self_site(sg, gd, g_st, R(0));
+      geo.acc_stack(sg, gd);
     }
+  }
+  return true;
+}
+
+template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT>
+__device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
+                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
+  if constexpr (MODEL == 4) {
+    [&]() -> bool { MYTHOS_NA1_UNBONDED(unbonded_angular_geo, , TERMS) }();
+  } else {
+    const UniGeo<R, MODEL> geo(P);
+    unbonded_angular_geo<R, MODEL, GRAD, PG, TERMS>(P, s, o, dco, role_p, wgt, e, sg, pg, geo);
   }
 }
 

@@ -128,20 +128,22 @@ def _pairs_2xP(unbonded, n: int) -> np.ndarray:
     return np.ascontiguousarray(u, dtype=np.int32)
 
 
-def _get_system(model, seq, is_end, bonded, unbonded, box, dtype, device):
+def _get_system(model, seq, is_end, bonded, unbonded, box, dtype, device, is_rna=None):
     from mythos_amd.hip_system import OxdnaSystem
 
     seq = np.ascontiguousarray(seq, dtype=np.int32)
     bonded = np.ascontiguousarray(bonded, dtype=np.int32)
     is_end_b = None if is_end is None else np.ascontiguousarray(is_end, dtype=np.uint8)
+    is_rna_b = None if is_rna is None else np.ascontiguousarray(is_rna, dtype=np.uint8)
     key = (
         model, seq.tobytes(), bonded.tobytes(), None if is_end_b is None else is_end_b.tobytes(),
         None if box is None else tuple(np.asarray(box, dtype=np.float64).tolist()), dtype, str(device),
+        None if is_rna_b is None else is_rna_b.tobytes(),
     )
     entry = _SYSTEMS.get(key)
     if entry is None:
-        entry = {"sys": OxdnaSystem(model, seq, is_end_b, bonded, box=box, dtype=dtype, device=device), "pairs": None, "flat": None,
-                 "pseq": None}
+        entry = {"sys": OxdnaSystem(model, seq, is_end_b, bonded, box=box, dtype=dtype, device=device, is_rna=is_rna_b), "pairs": None,
+                 "flat": None, "pseq": None}
         _SYSTEMS[key] = entry
         if len(_SYSTEMS) > 16:
             _SYSTEMS.pop(next(iter(_SYSTEMS)))
@@ -517,6 +519,8 @@ class ComposedEnergyFunction(EnergyFunction):
         from mythos_amd.energy import terms as _terms
 
         _terms.check_term_models(model, self.energy_fns)
+        if model == 4:
+            return self._evaluate_na1(body, geom)
         sections = {"geometry": geom.params}
         term_w = [0.0] * 8
         cols = []
@@ -555,6 +559,49 @@ class ComposedEnergyFunction(EnergyFunction):
             total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         finally:
             entry["observe"] = None
+        return total, terms, cols
+
+    def _evaluate_na1(self, body: RigidBody, geom):
+        """oxNA (mythos/energy/na1/): every term carries three parameter sets and the types of the nucleotides; the
+        kernels take three flat vectors - oxDNA2, oxRNA2, hybrid - and ``is_rna``."""
+        from mythos_amd.energy import terms as _terms
+
+        first = self.energy_fns[0]
+        sets = {which: {"geometry": geom.params[which]} if which in geom.params else {} for which in fp.NA1_SETS}
+        term_w, cols = [0.0] * 8, []
+        w_user = self.weights if self.weights is not None else torch.ones(len(self.energy_fns), dtype=torch.float64)
+        kt = salt = hce = nt_type = None
+        for fn, w in zip(self.energy_fns, w_user):
+            k = TERM_ORDER.index(fn.term)
+            if k in cols:
+                raise ValueError(f"term '{fn.term}' appears twice in one composed energy function")
+            for which, sec in fn.params.sections().items():
+                sets[which][fn.term] = sec
+            term_w[k] = float(w)
+            cols.append(k)
+            t = np.asarray(_np(fn.params["nt_type"]))
+            if nt_type is not None and not np.array_equal(nt_type, t):
+                raise ValueError("the terms of an oxNA energy function carry different nt_type arrays")
+            nt_type = t
+            if "kt" in fn.params and kt is None:
+                kt = fn.params["kt"]
+            if fn.term == "debye":
+                salt, hce = fn.params["salt_conc"], bool(fn.params["half_charged_ends"])
+        _terms.fill_missing_sections_na1(sets)
+        named = fp.derive_flat_na1(sets["dna"], sets["rna"], sets["drh"], kt=_terms.default_kt() if kt is None else kt,
+                                   salt_conc=0.5 if salt is None else salt, half_charged_ends=False if hce is None else hce,
+                                   term_weights=term_w)
+        flat = fp.pack_flat_na1(named, _lib.param_names())
+        center, quat = body.center, body.orientation.vec
+        if nt_type.shape != (int(_np(first.seq).shape[0]),):
+            raise ValueError("nt_type must have one entry per nucleotide")
+        from mythos_amd.input.topology import NucleotideType
+
+        entry = _get_system(4, _np(first.seq), _np(first.is_end) if first.is_end is not None else None, _np(first.bonded_neighbors),
+                            first.unbonded_neighbors, getattr(first.displacement_fn, "box", None), center.dtype, center.device,
+                            is_rna=nt_type == int(NucleotideType.RNA))
+        entry["observe"] = None
+        total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         return total, terms, cols
 
     def compute_terms(self, body: RigidBody) -> torch.Tensor:

@@ -269,6 +269,26 @@ def derive_flat(
     return out
 
 
+NA1_SETS = ("dna", "rna", "drh")  # order of the three vectors of an oxNA system (model 4 of the C ABI)
+NA1_UNBONDED_SECTIONS = ("unbonded_excluded_volume", "hydrogen_bonding", "cross_stacking", "coaxial_stacking", "debye")
+
+
+def derive_flat_na1(sections_dna: dict, sections_rna: dict, sections_drh: dict, *, kt, salt_conc=0.5, half_charged_ends=False,
+                    term_weights=None) -> dict[str, dict[str, torch.Tensor]]:
+    """The three flat vectors of a hybrid DNA / RNA system (mythos/energy/na1/*.py): ``dna`` - DNA-DNA pairs, the oxDNA2
+    sections in the oxDNA2 forms; ``rna`` - RNA-RNA pairs, oxRNA2; ``drh`` - DNA-RNA pairs: the five unbonded sections of
+    mythos/input/na1/default_energy.toml in their oxDNA1 forms (cross-stacking with theta4, coaxial stacking with f5 of
+    cos phi3 / phi4, Debye-Hueckel).  The hybrid kernels read the bonded entries and the geometry of neither: those
+    places of the ``drh`` vector are filled from the oxRNA2 sections, which have the same form."""
+    kw = dict(kt=kt, salt_conc=salt_conc, half_charged_ends=half_charged_ends, term_weights=term_weights)
+    drh = {**{k: v for k, v in sections_rna.items() if k not in NA1_UNBONDED_SECTIONS}, **{k: sections_drh[k] for k in NA1_UNBONDED_SECTIONS}}
+    return {"dna": derive_flat(2, sections_dna, **kw), "rna": derive_flat(3, sections_rna, **kw), "drh": derive_flat(3, drh, **kw)}
+
+
+def pack_flat_na1(named3: dict, names: list[str]) -> torch.Tensor:
+    return torch.cat([pack_flat(named3[k], names) for k in NA1_SETS])
+
+
 def pack_flat(named: dict[str, torch.Tensor], names: list[str]) -> torch.Tensor:
     """Stack into the order the C ABI reports (mythos_oxdna_param_name)."""
     missing = [n for n in names if n not in named]

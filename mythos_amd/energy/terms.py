@@ -61,6 +61,11 @@ MODEL_NAMES = {1: "dna1", 2: "dna2", 3: "rna2"}  # the model numbers of the C AB
 def check_term_models(model: int, energy_fns) -> None:
     """The site geometry decides which instantiation of the kernels runs; a term class written for another functional
     form must not be evaluated by it silently."""
+    if model == 4 or any(fn.model == 4 for fn in energy_fns):
+        if model != 4 or any(fn.model != 4 for fn in energy_fns):
+            raise ValueError("the oxNA terms (mythos_amd.energy.na1) and the oxNA geometry (HybridNucleotide) go together: "
+                             "every term of the composed function must be an na1 term")
+        return
     if any(fn.model > model for fn in energy_fns):
         raise ValueError("an oxDNA2-only term (Debye / dna2 stacking / dna2 coaxial) needs the oxDNA2 geometry, an oxRNA2 "
                          "term (rna2 stacking / cross-stacking) the oxRNA2 geometry")
@@ -70,6 +75,15 @@ def check_term_models(model: int, energy_fns) -> None:
                 raise ValueError(f"the oxRNA2 geometry needs the rna2 {fn.term} term (mythos_amd.energy.rna2), got an oxDNA one")
             if fn.term == "coaxial_stacking" and fn.model != 1:
                 raise ValueError("oxRNA2 uses the oxDNA1 form of the coaxial term (dna1.CoaxialStacking)")
+
+
+def fill_missing_sections_na1(sets: dict) -> None:
+    """oxNA: the three sets of sections (DNA-DNA, RNA-RNA, hybrid); whatever a composed function does not carry comes from
+    the defaults (weight 0, so it only has to be well-formed)."""
+    _, cfg = defaults.default_configs_for("na1")
+    for which, sections in cfg.items():
+        for sec, vals in sections.items():
+            sets[which].setdefault(sec, vals)
 
 
 def fill_missing_sections(model: int, sections: dict) -> None:

@@ -46,7 +46,7 @@ def _dtype_code(dtype: torch.dtype) -> int:
 class OxdnaSystem:
     """One oxDNA system on one GPU."""
 
-    def __init__(self, model: int, seq, is_end, bonded, box=None, dtype=torch.float32, device=None):
+    def __init__(self, model: int, seq, is_end, bonded, box=None, dtype=torch.float32, device=None, is_rna=None):
         lib = _lib.load()
         if _lib.device_count() == 0 or not torch.cuda.is_available():
             raise _lib.MythosHipError("no HIP device visible: the mythos_amd HIP path has no CPU fallback")
@@ -75,7 +75,15 @@ class OxdnaSystem:
         if not self._h:
             raise _lib.MythosHipError(f"mythos_oxdna_create: {_lib.last_error()}")
         self._lib = lib
-        self.n_params = lib.mythos_oxdna_param_count()
+        # oxNA (model 4): three vectors - oxDNA2, oxRNA2, hybrid - one after the other; dU/dparams rows likewise
+        self.n_params = lib.mythos_oxdna_param_count() * (3 if self.model == 4 else 1)
+        if self.model == 4:
+            if is_rna is None:
+                raise ValueError("an oxNA system (model 4) needs is_rna, the type of every nucleotide")
+            t = np.ascontiguousarray(is_rna, dtype=np.uint8)
+            if t.shape != (self.n,):
+                raise ValueError(f"is_rna must have shape ({self.n},)")
+            _lib.check(lib.mythos_oxdna_set_nucleotide_types(self._h, t.ctypes.data_as(_lib.c_uint8_p)), "set_nucleotide_types")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -30,6 +30,7 @@ def load() -> C.CDLL:
         lib.mythos_cpu_create.restype = V
         lib.mythos_cpu_create.argtypes = [C.c_int, C.c_int, _ip, C.POINTER(C.c_uint8), C.c_int, _ip, _dp, _dp, C.c_int]
         lib.mythos_cpu_destroy.argtypes = [V]
+        lib.mythos_cpu_set_types.argtypes = [V, C.POINTER(C.c_uint8)]
         lib.mythos_cpu_destroy.restype = None
         lib.mythos_cpu_threads.restype = C.c_int
         lib.mythos_cpu_set_threads.argtypes = [C.c_int]
@@ -51,7 +52,7 @@ def _d(a):
 class CpuPort:
     """One oxDNA system on the host.  ``flat``: the parameter vector of the C ABI (mythos_oxdna_param_name order)."""
 
-    def __init__(self, model, seq, is_end, bonded, flat, box=None):
+    def __init__(self, model, seq, is_end, bonded, flat, box=None, is_rna=None):
         lib = load()
         seq = np.ascontiguousarray(seq, dtype=np.int32)
         self.n = int(seq.shape[0])
@@ -65,6 +66,9 @@ class CpuPort:
         if not self._h:
             raise ValueError("mythos_cpu_create: invalid arguments (parameter vector length, model)")
         self._lib = lib
+        if is_rna is not None:  # oxNA (model 4; flat = the oxDNA2, oxRNA2 and hybrid vectors one after the other)
+            t = np.ascontiguousarray(is_rna, dtype=np.uint8)
+            lib.mythos_cpu_set_types(self._h, t.ctypes.data_as(C.POINTER(C.c_uint8)))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -38,7 +38,8 @@ struct Sys {
   bool has_box = false;
   double box[3] = {0, 0, 0};
   OxParams<double> P;
-  std::vector<int> meta;      // seq | is_end << 2
+  Na1Params<OxParams<double>> P4;  // model 4 (oxNA): the oxDNA2, oxRNA2 and hybrid vectors
+  std::vector<int> meta;      // seq | is_end << 2 | is_rna << 3
   std::vector<int> partners;  // [n][4], slot parity = role (odd: self is nn_i)
   std::vector<int> row_ptr, row;  // CSR of unbonded neighbours, entry = j | kRoleQ if self is op_j
   std::vector<double> ref;    // centres the list was built from
@@ -60,7 +61,14 @@ inline Nuc<double> load(const Sys& s, const double* c, const double* q, int j) {
   quat_axes(q[4 * j], q[4 * j + 1], q[4 * j + 2], q[4 * j + 3], o.a1, o.a2, o.a3);
   o.seq = s.meta[j] & 3;
   o.is_end = (s.meta[j] >> 2) & 1;
+  o.rna = (s.meta[j] >> 3) & 1;
+  o.idx = j;
   return o;
+}
+
+template <int MODEL>
+inline const auto& params_for(const Sys& s) {
+  if constexpr (MODEL == 4) return s.P4; else return s.P;
 }
 
 // energy terms (8, summed over threads in a fixed order), and per nucleotide dU/dcentre + axis gradients
@@ -86,12 +94,12 @@ void forces(const Sys& s, const double* c, const double* q, double* e_terms, dou
         const int j = s.partners[4 * i + k];
         if (j < 0) continue;
         const Nuc<double>& o = nuc[j];
-        bonded_pair<double, MODEL, true, NoPG>(s.P, self, o, min_image(o.c - self.c, s), (k & 1) == 1, 0.5, e, sg, pg);
+        bonded_pair<double, MODEL, true, NoPG>(params_for<MODEL>(s), self, o, min_image(o.c - self.c, s), (k & 1) == 1, 0.5, e, sg, pg);
       }
       for (int t = s.row_ptr[i]; t < s.row_ptr[i + 1]; ++t) {
         const int entry = s.row[t];
         const Nuc<double>& o = nuc[entry & kIndexMask];
-        unbonded_pair<double, MODEL, true, NoPG>(s.P, self, o, min_image(o.c - self.c, s), (entry & kRoleQ) == 0, 0.5, e, sg, pg);
+        unbonded_pair<double, MODEL, true, NoPG>(params_for<MODEL>(s), self, o, min_image(o.c - self.c, s), (entry & kRoleQ) == 0, 0.5, e, sg, pg);
       }
       for (int k = 0; k < T_COUNT; ++k) et[k] += e[k];
       dc[3 * i] = sg.dc.x, dc[3 * i + 1] = sg.dc.y, dc[3 * i + 2] = sg.dc.z;
@@ -110,7 +118,8 @@ void forces(const Sys& s, const double* c, const double* q, double* e_terms, dou
 void forces(const Sys& s, const double* c, const double* q, double* e, double* dc, double* g) {
   if (s.model == 1) forces<1>(s, c, q, e, dc, g);
   else if (s.model == 2) forces<2>(s, c, q, e, dc, g);
-  else forces<3>(s, c, q, e, dc, g);
+  else if (s.model == 3) forces<3>(s, c, q, e, dc, g);
+  else forces<4>(s, c, q, e, dc, g);
 }
 
 // body-frame torque from the axis gradients: lab torque -sum_k a_k x dU/da_k, projected on the axes
@@ -258,11 +267,14 @@ extern "C" {
 
 void* mythos_cpu_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded, const int32_t* bonded,
                         const double* box, const double* flat, int n_params) {
-  if (n_params != OXP_COUNT || (model < 1 || model > 3) || n <= 0) return nullptr;
+  if (model < 1 || model > 4 || n_params != (model == 4 ? 3 : 1) * OXP_COUNT || n <= 0) return nullptr;
   Sys* s = new Sys();
   s->model = model, s->n = n;
   if (box) s->has_box = true, s->box[0] = box[0], s->box[1] = box[1], s->box[2] = box[2];
   for (int k = 0; k < OXP_COUNT; ++k) s->P.v[k] = flat[k];
+  if (model == 4)
+    for (int k = 0; k < OXP_COUNT; ++k)
+      s->P4.dna.v[k] = flat[k], s->P4.rna.v[k] = flat[OXP_COUNT + k], s->P4.drh.v[k] = flat[2 * OXP_COUNT + k];
   s->meta.resize(n);
   for (int i = 0; i < n; ++i) s->meta[i] = (seq[i] & 3) | ((is_end && is_end[i]) ? 4 : 0);
   s->partners.assign(4 * (size_t)n, -1);
@@ -278,6 +290,12 @@ void* mythos_cpu_create(int model, int n, const int32_t* seq, const uint8_t* is_
 }
 
 void mythos_cpu_destroy(void* h) { delete (Sys*)h; }
+
+// oxNA: which nucleotides are RNA (topology nt_type)
+void mythos_cpu_set_types(void* h, const uint8_t* is_rna) {
+  Sys& s = *(Sys*)h;
+  for (int i = 0; i < s.n; ++i) s.meta[i] = (s.meta[i] & 7) | (is_rna[i] ? 8 : 0);
+}
 
 int mythos_cpu_threads(void) { return omp_get_max_threads(); }
 void mythos_cpu_set_threads(int t) { omp_set_num_threads(t > 0 ? t : 1); }

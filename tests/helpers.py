@@ -165,6 +165,8 @@ def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_0
     bonded=False: two free nucleotides (unbonded excluded volume, H-bond, cross-stacking, coaxial stacking, Debye);
     bonded=True: a two-nucleotide strand whose backbone sites are within the FENE well (FENE, bonded excluded volume,
     stacking).  Returns (topology, center (2 keep, 3), quaternion (2 keep, 4), live-count per term name).
+    model 4 (oxNA): every nucleotide is DNA or RNA at random (``topology.nt_type``), so the unbonded dimers cover DNA-DNA,
+    RNA-RNA, DNA-RNA and RNA-DNA pairs - the hybrid coaxial term has no usable golden (na1/tests/test_integration.py:404).
     """
     rng = np.random.default_rng(seed + 10 * model + (1 if bonded else 0))
     m = sample
@@ -173,11 +175,28 @@ def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_0
     c = np.zeros((2 * m, 3))
     d = rng.standard_normal((m, 3))
     d /= np.linalg.norm(d, axis=1, keepdims=True)
-    P = oracle_params(model, salt=1.0 if model == 3 else 0.5)
+    is_rna = np.zeros(2 * m, dtype=bool)
+    if model == 4:
+        P = oracle_params_na1()
+        is_rna = rng.integers(0, 2, 2 * m).astype(bool)
+        if bonded:  # a strand has one type (a chimeric bond is evaluated as DNA: one in eight dimers keeps mixed types)
+            same = rng.random(m) < 0.875
+            is_rna[1::2] = np.where(same, is_rna[0::2], is_rna[1::2])
+    else:
+        P = oracle_params(model, salt=1.0 if model == 3 else 0.5)
     if bonded:
         a1, a2, a3 = orc.quat_to_axes(torch.as_tensor(q))
-        back = orc.Sites(model, P["geometry"], torch.zeros(2 * m, 3, dtype=torch.float64), a1, a2, a3).back.numpy()
-        r0, delta = float(P["fene"]["r0_backbone"]), float(P["fene"]["delta_backbone"])
+        zero = torch.zeros(2 * m, 3, dtype=torch.float64)
+        if model == 4:
+            both = (is_rna[0::2] & is_rna[1::2]).repeat(2)[:, None]
+            back = np.where(both, orc.Sites(3, P["rna"]["geometry"], zero, a1, a2, a3).back.numpy(),
+                            orc.Sites(2, P["dna"]["geometry"], zero, a1, a2, a3).back.numpy())
+            fene = [P["rna" if r else "dna"]["fene"] for r in (False, True)]
+            r0 = np.where(both[0::2], float(fene[1]["r0_backbone"]), float(fene[0]["r0_backbone"]))
+            delta = float(fene[0]["delta_backbone"])
+        else:
+            back = orc.Sites(model, P["geometry"], zero, a1, a2, a3).back.numpy()
+            r0, delta = float(P["fene"]["r0_backbone"]), float(P["fene"]["delta_backbone"])
         c[1::2] = back[0::2] - back[1::2] + d * (r0 + rng.uniform(-0.6, 0.6, (m, 1)) * delta)
     else:
         c[1::2] = d * rng.uniform(0.3, 1.2, (m, 1))
@@ -185,8 +204,12 @@ def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_0
     seq[1:m:2] = 3 - seq[0:m:2]  # Watson-Crick partners in the first half of the draws: hydrogen bonds need them
     pairs = torch.as_tensor(np.stack([np.arange(0, 2 * m, 2), np.arange(1, 2 * m, 2)], 1))
     none = torch.zeros((0, 2), dtype=torch.long)
-    bt, ut = orc.pair_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), torch.as_tensor(seq), torch.ones(2 * m, dtype=torch.long),
-                            pairs if bonded else none, none if bonded else pairs)
+    if model == 4:
+        bt, ut = orc.pair_terms_na1(P, torch.as_tensor(c), torch.as_tensor(q), torch.as_tensor(seq), torch.as_tensor(is_rna),
+                                    torch.ones(2 * m, dtype=torch.long), pairs if bonded else none, none if bonded else pairs)
+    else:
+        bt, ut = orc.pair_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), torch.as_tensor(seq), torch.ones(2 * m, dtype=torch.long),
+                                pairs if bonded else none, none if bonded else pairs)
     terms = {k: v.numpy() for k, v in (bt if bonded else ut).items()}
     radial = terms["bonded_excluded_volume" if bonded else "unbonded_excluded_volume"]
     angular = ("stacking",) if bonded else ("hydrogen_bonding", "cross_stacking", "coaxial_stacking")
@@ -204,4 +227,11 @@ def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_0
     nuc = np.stack([2 * sel, 2 * sel + 1], 1).reshape(-1)
     center = c[nuc] + np.repeat(grid, 2, axis=0)
     top = topology.from_arrays(seq[nuc].astype(np.int32), [2] * len(sel) if bonded else [1] * (2 * len(sel)))
+    if model == 4:
+        import dataclasses
+
+        nt = np.where(is_rna[nuc], int(topology.NucleotideType.RNA), int(topology.NucleotideType.DNA)).astype(np.int32)
+        top = dataclasses.replace(top, nt_type=nt)
+        kinds = is_rna[nuc].reshape(-1, 2)
+        live["pairs dna-dna / rna-rna / hybrid"] = (int((~kinds).all(1).sum()), int(kinds.all(1).sum()), int((kinds[:, 0] != kinds[:, 1]).sum()))
     return top, np.ascontiguousarray(center), np.ascontiguousarray(q[nuc]), live

@@ -65,26 +65,68 @@ def test_energies_and_gradients_match_oracle(model, name, hce):
         np.testing.assert_allclose(tb, tb_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(tb_ref).max()))
 
 
-@pytest.mark.parametrize("model", [1, 2, 3])
+@pytest.mark.parametrize("model", [1, 2, 3, 4])
 @pytest.mark.parametrize("bonded", [False, True])
 def test_random_dimers_match_oracle(model, bonded):
     """Every term of the pair templates on random relative poses (tests/helpers.py random_dimers): the golden
-    trajectories hold 0 for the coaxial term in every stored frame, and visit little of the other angular windows."""
+    trajectories hold 0 for the coaxial term in every stored frame, and visit little of the other angular windows.
+    Model 4 (oxNA): random DNA / RNA types, so all four kinds of pair - the hybrid coaxial term has no golden."""
     top, c, q, live = H.random_dimers(model, bonded)
-    assert all(v >= 5 for k, v in live.items()), live
+    assert all(v >= 5 for k, v in live.items() if not k.startswith("pairs")), live
     pairs = np.arange(top.n_nucleotides).reshape(-1, 2)
-    port = cpu_port.CpuPort(model, top.seq, top.is_end, top.bonded_neighbors, _flat(model, False), box=None)
-    port.set_pairs(np.zeros((0, 2), np.int64) if bonded else pairs)
-    P = H.oracle_params(model, salt=SALT[model])
     seq, is_end, b, _ = H.topo_tensors(top)
     u = torch.zeros((0, 2), dtype=torch.long) if bonded else torch.as_tensor(pairs)
+    ct, qt = torch.as_tensor(c), torch.as_tensor(q)
+    if model == 4:
+        is_rna = np.asarray(top.nt_type) == 2
+        assert min(live["pairs dna-dna / rna-rna / hybrid"]) >= 30
+        port = cpu_port.CpuPort(4, top.seq, top.is_end, top.bonded_neighbors, _flat_na1(), box=None, is_rna=is_rna)
+        P = H.oracle_params_na1()
+        e_ref = orc.energy_terms_na1(P, ct, qt, seq, torch.as_tensor(is_rna), is_end, b, u).numpy()
+        _, gc_ref, gq_ref = orc.energy_and_grads_na1(P, ct, qt, seq, torch.as_tensor(is_rna), is_end, b, u)
+    else:
+        port = cpu_port.CpuPort(model, top.seq, top.is_end, top.bonded_neighbors, _flat(model, False), box=None)
+        P = H.oracle_params(model, salt=SALT[model])
+        e_ref = orc.energy_terms(model, P, ct, qt, seq, is_end, b, u).numpy()
+        _, gc_ref, gq_ref = orc.energy_and_grads(model, P, ct, qt, seq, is_end, b, u)
+    port.set_pairs(np.zeros((0, 2), np.int64) if bonded else pairs)
     e, gc, gq, tb = port.energy(c, q)
-    e_ref = orc.energy_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u).numpy()
     np.testing.assert_allclose(e[: len(e_ref)], e_ref, rtol=1e-12, atol=1e-10)
     assert (np.abs(e_ref[:3] if bonded else e_ref[3:]) > 0.2).all()  # every term contributes
-    _, gc_ref, gq_ref = orc.energy_and_grads(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u)
     np.testing.assert_allclose(gc, gc_ref.numpy(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(gq, gq_ref.numpy(), rtol=1e-9, atol=1e-9)
+
+
+def _flat_na1():
+    from mythos_amd import _lib
+
+    sim, cfg = defaults.default_configs_for("na1")
+    named = fp.derive_flat_na1(cfg["dna"], cfg["rna"], cfg["drh"], kt=sim["kT"], salt_conc=0.5, half_charged_ends=False)
+    return fp.pack_flat_na1(named, _lib.param_names()).numpy()
+
+
+@pytest.mark.parametrize("name", H.NA1_CASES)
+def test_oxna_energies_and_gradients_match_oracle(name):
+    """The oxNA instantiation of the pair templates (parameter vector and form by the types of the pair, sites by the type
+    of each nucleotide) against the oracle on the reference's seven hybrid goldens: energies per term, forces, dU/dq."""
+    top, traj, split, is_rna = H.load_golden_na1(name)
+    port = cpu_port.CpuPort(4, top.seq, top.is_end, top.bonded_neighbors, _flat_na1(), box=traj.box_size, is_rna=is_rna)
+    port.set_pairs(top.unbonded_neighbors)
+    P = H.oracle_params_na1()
+    seq, is_end, b, u = H.topo_tensors(top)
+    rna = torch.as_tensor(is_rna)
+    for f in (0, 41, 99):
+        c, q = traj.center[f], traj.quaternions[f]
+        e, gc, gq, tb = port.energy(c, q)
+        e_ref = orc.energy_terms_na1(P, torch.as_tensor(c), torch.as_tensor(q), seq, rna, is_end, b, u, box=traj.box_size).numpy()
+        np.testing.assert_allclose(e, e_ref, rtol=0, atol=1e-10)
+        for k, term in enumerate(H.SPLIT_COLUMNS[1:9]):
+            if term == "coaxial_stacking" and name == "simple-coax-dna-dna-rna":
+                continue  # oxNA's standalone code has the hybrid spring constant at 0 (na1/tests/test_integration.py:404-406)
+            assert abs(e[k] / top.n_nucleotides - split[f, 1 + k]) <= H.NA1_TERM_ATOL[term] + 5e-7, term
+        _, gc_ref, gq_ref = orc.energy_and_grads_na1(P, torch.as_tensor(c), torch.as_tensor(q), seq, rna, is_end, b, u, box=traj.box_size)
+        np.testing.assert_allclose(gc, gc_ref.numpy(), rtol=0, atol=1e-9 * max(1.0, gc_ref.abs().max().item()))
+        np.testing.assert_allclose(gq, gq_ref.numpy(), rtol=0, atol=1e-9 * max(1.0, gq_ref.abs().max().item()))
 
 
 def test_langevin_steps_match_oracle_on_the_same_random_stream():

@@ -188,8 +188,10 @@ def test_default_parameters_and_toml_subset(tmp_path):
     sim3, e3 = defaults.default_configs_for("rna2")  # mythos/input/rna2/default_energy.toml
     assert e3["fene"]["r0_backbone"] == 0.761070781051 and e3["geometry"]["pos_back_a3"] == 0.2 and "theta0_stack_9" in e3["stacking"]
     assert "theta0_cross_4" not in e3["cross_stacking"] and sim3["salt_conc"] == 1.0
+    sim4, e4 = defaults.default_configs_for("na1")  # three sets: oxDNA2, oxRNA2, mythos/input/na1/default_energy.toml
+    assert set(e4) == {"dna", "rna", "drh"} and e4["drh"]["hydrogen_bonding"]["eps_hb"] == 1.5 and "fene" not in e4["drh"]
     with pytest.raises((KeyError, ValueError)):
-        defaults.default_configs_for("na1")
+        defaults.default_configs_for("dna3")
     toml = tmp_path / "p.toml"
     toml.write_text("# comment\n[a]\nx = 1.5\ny = \"pi - 0.25\"\nflag = true\n[b]\nz = [1, 2.0, \"3 * 2\"]\n")
     parsed = defaults.parse_toml(toml)
