@@ -100,13 +100,37 @@ __device__ __forceinline__ void drift(R* x, R* q, const R* p, R* L, R h, const L
 constexpr int kMdBlock = 256;
 constexpr int kMdG = 8;                    // lanes per nucleotide
 constexpr int kMdPPB = kMdBlock / kMdG;    // nucleotides per workgroup
-constexpr int kMdItems = 16;               // flagged unbonded neighbours per nucleotide (phase 2) the stepping kernel has room for
+#ifndef MYTHOS_MD_ITEMS  // (dev A/B: scripts/build_variant.sh)
+#define MYTHOS_MD_ITEMS 16
+#endif
+#ifndef MYTHOS_MD_F64_BLOCKS  // workgroups per CU the register allocator is asked to make room for, by variant
+#define MYTHOS_MD_F64_BLOCKS 3
+#endif
+#ifndef MYTHOS_MD_F64S_BLOCKS
+#define MYTHOS_MD_F64S_BLOCKS 2
+#endif
+#ifndef MYTHOS_MD_F32_BLOCKS
+#define MYTHOS_MD_F32_BLOCKS 3
+#endif
+#ifndef MYTHOS_MD_F32S_BLOCKS
+#define MYTHOS_MD_F32S_BLOCKS 2
+#endif
+constexpr int kMdItems = MYTHOS_MD_ITEMS;  // flagged unbonded neighbours per nucleotide (phase 2) the stepping kernel has room for
 // ... and the variant a run falls back to when a nucleotide has more (see md_step_kernel): 32, or what the 160 KB of LDS
 // leave for the fp64 energy-trace instantiation, whose result rows carry the 8 term energies as well
 template <typename R, bool SAVE>
 constexpr int md_items_big() {
   return (sizeof(R) == 8 && SAVE) ? 22 : 32;
 }
+// Result rows (one per evaluated bonded slot / angular item) come out of ONE pool per workgroup, handed out by a prefix
+// sum over the 32 nucleotides' counts: a duplex uses 2 + ~5 rows per nucleotide, a fixed 4 + 16 per nucleotide was two
+// thirds empty and its 33 KB (fp32) / 66 KB (fp64) of LDS decided how many workgroups a CU holds.  A workgroup whose
+// nucleotides need more rows than the pool has aborts the launch like one whose work lists are too short (ITEMS), and
+// the run goes on with the big instantiation, whose pool is the full 32 x (4 + ITEMS).
+#ifndef MYTHOS_MD_POOL  // (dev A/B)
+#define MYTHOS_MD_POOL 320
+#endif
+constexpr int kMdPool = MYTHOS_MD_POOL;
 constexpr int kTraceWidth = T_COUNT + 2;   // 8 energy terms + KE_trans + KE_rot
 
 // Expanded per-nucleotide state of one time level ("frame"), written by the kernel that
@@ -221,8 +245,8 @@ __device__ __forceinline__ void md_pin(T& v) {
 // variant allows (fp32 stepping 43 KB; the trace and fp64 variants carry wider result rows)
 template <typename R, bool SAVE, int ITEMS>
 constexpr int md_blocks_per_cu() {
-  if (ITEMS > kMdItems) return sizeof(R) == 4 ? (SAVE ? 1 : 2) : 1;  // result rows of 36 slots: 64 - 100 KB (fp32), 125 - 150 KB (fp64) of LDS
-  return sizeof(R) == 4 ? (SAVE ? 2 : 3) : (SAVE ? 1 : 2);
+  if (ITEMS > kMdItems) return sizeof(R) == 4 ? (SAVE ? 1 : 2) : 1;  // a pool of 32 x 36 rows: 64 - 100 KB (fp32), 125 - 150 KB (fp64) of LDS
+  return sizeof(R) == 4 ? (SAVE ? MYTHOS_MD_F32S_BLOCKS : MYTHOS_MD_F32_BLOCKS) : (SAVE ? MYTHOS_MD_F64S_BLOCKS : MYTHOS_MD_F64_BLOCKS);
 }
 
 // ITEMS: result rows per nucleotide for the angular work lists.  16 is enough for any duplex, junction or origami
@@ -254,9 +278,11 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
   // result rows, [nucleotide][slot][RW] with the nucleotide stride padded to an odd word count: the 32
   // nucleotides' rows then start in 32 different banks (20 x 13 = 260 words would alias p and p + 8)
-  constexpr int kResStride = (kSlots * RW) | 1;
-  __shared__ R res_flat[PPB * kResStride];
-  auto res_row = [&](int pp, int slot) -> R* { return res_flat + pp * kResStride + slot * RW; };
+  constexpr int kPool = (ITEMS > kMdItems) ? PPB * kSlots : kMdPool;  // rows of the workgroup's pool (see kMdPool)
+  static_assert(kPool >= PPB * ROW_BONDED_SLOTS, "the pool holds at least the bonded rows");
+  __shared__ R res_flat[kPool * RW];
+  __shared__ int row_base[4][PPB + 1];  // per WAVEFRONT (like item_pre): first pool row of every nucleotide
+  auto pool_row = [&](int row) -> R* { return res_flat + row * RW; };
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
   const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
@@ -534,20 +560,29 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     // exclusive prefix of the 32 per-nucleotide counts of this wavefront's list, so the list is dense over the
     // workgroup; every wavefront scans for itself (5 DPP-free shuffle steps) instead of meeting at a second barrier
     const int pw = threadIdx.x >> 6;
+    // rows 2, 3 (second-bond slots) exist only in systems with circular strands
+    const int n_bonded_rows = extra_bonds ? ROW_BONDED_SLOTS : 2;
     {
       const int l = threadIdx.x & 63;
       int inc = (l < PPB) ? item_cnt[lst][l] : 0;
+      // ... and of the rows every nucleotide takes from the result pool: its bonded slots, then its two work lists
+      int rows_inc = (l < PPB) ? n_bonded_rows + item_cnt[0][l] + item_cnt[1][l] : 0;
 #pragma unroll
       for (int o = 1; o < PPB; o <<= 1) {
         const int u = __shfl_up(inc, o, 64);
-        if (l >= o) inc += u;
+        const int v = __shfl_up(rows_inc, o, 64);
+        if (l >= o) inc += u, rows_inc += v;
       }
-      if (l < PPB) item_pre[pw][l + 1] = inc;
-      if (l == 0) item_pre[pw][0] = 0;
+      if (l < PPB) item_pre[pw][l + 1] = inc, row_base[pw][l + 1] = rows_inc;
+      if (l == 0) item_pre[pw][0] = 0, row_base[pw][0] = 0;
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    const int n_list = item_pre[pw][PPB];
+    // more rows than the pool holds (every wavefront computes the same number): nothing of the angular pass is
+    // evaluated or folded, the launch is marked as not counting and the host goes on with the big instantiation
+    const bool pool_over = row_base[pw][PPB] > kPool;
+    if (pool_over && threadIdx.x == 0) atomicMax(flags + 3, k_index + 1);
+    const int n_list = pool_over ? 0 : item_pre[pw][PPB];
     const int half = (n_list + 1) >> 1;
     const int q_lo = wave == 2 ? half : 0;                      // this wavefront's slice [q_lo, q_hi) of the list
     const int q_hi = wave == 1 ? half : n_list;
@@ -555,7 +590,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     const int n_sweeps = (n_total + 63) / 64;
     // bonded wave: one sweep over slots 0 / 1 of the 32 nucleotides, and a second over slots 2 / 3 only in
     // systems with circular strands (a ring's two ends carry a second bond in one role)
-    const int my_sweeps = bonded_wave ? ((ablate & 16) ? 0 : (extra_bonds ? 2 : 1)) : ((ablate & 8) ? 0 : n_sweeps);
+    const int my_sweeps = bonded_wave ? (((ablate & 16) || pool_over) ? 0 : (extra_bonds ? 2 : 1)) : ((ablate & 8) ? 0 : n_sweeps);
     for (int sweep = 0; sweep < ((ablate & 2) ? 0 : my_sweeps); ++sweep) {
       int p, idx, sl;
       bool active;
@@ -575,13 +610,13 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
         p = lo;
         const int k = q - item_pre[pw][lo];
         sl = active ? items[lst][p][k] : -1;  // for these waves sl carries the row entry itself
-        // result row: bonded 0..3, then the nucleotide's H-bond, cross-stacking and coaxial items
-        idx = ROW_BONDED_SLOTS + k + (lst >= 1 ? item_cnt[0][p] : 0);
+        // result row: the bonded slots, then the nucleotide's H-bond, cross-stacking and coaxial items
+        idx = n_bonded_rows + k + (lst >= 1 ? item_cnt[0][p] : 0);
       }
       const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
       const int entry = bonded_wave ? rows[(size_t)ip * row_stride + sl] : sl;
-      R* out_r = res_row(p, idx);
+      R* out_r = pool_row(row_base[pw][p] + idx);
       SelfGrad<R> g;
       g.dc = g.g1 = g.g2 = g.g3 = V3<R>{R(0), R(0), R(0)};
       R ee[T_COUNT];
@@ -659,12 +694,14 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   //      site gradients, and reduces over its 8 lanes in a fixed order
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
-  if (valid) {
-    const int total = ROW_BONDED_SLOTS + item_cnt[0][grp] + item_cnt[1][grp];
-    const int skip = extra_bonds ? 0 : 2;  // rows 2, 3 (second-bond slots) exist only in systems with circular strands
-    for (int u = lane; u < total - skip; u += G) {
-      const int t = (u < 2) ? u : u + skip;
-      const R* rr = res_row(grp, t);
+  // (any wavefront's copy of row_base: they are identical, and complete since the barrier above)
+  const int fw = threadIdx.x >> 6;
+  const int rb = row_base[fw][grp];
+  const bool pool_ok = row_base[fw][PPB] <= kPool;
+  if (valid && pool_ok) {
+    const int total = row_base[fw][grp + 1] - rb;
+    for (int u = lane; u < total; u += G) {
+      const R* rr = pool_row(rb + u);
       sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
       sg.g1 = sg.g1 + V3<R>{rr[3], rr[4], rr[5]};
       sg.g2 = sg.g2 + V3<R>{rr[6], rr[7], rr[8]};
@@ -698,7 +735,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   // lane: the integrator is ~0.6 k instructions per lane whatever the lane count, and run by lane 0 of
   // every group it occupied all four SIMDs at 1/8 lane use
   if (lane == 0) {
-    R* fr = res_row(grp, 0);
+    R* fr = pool_row(pool_ok ? rb : grp * 2);  // (pool exhausted: the launch does not count; any free row will do)
     fr[0] = sg.dc.x, fr[1] = sg.dc.y, fr[2] = sg.dc.z;
     fr[3] = sg.g1.x, fr[4] = sg.g1.y, fr[5] = sg.g1.z;
     fr[6] = sg.g2.x, fr[7] = sg.g2.y, fr[8] = sg.g2.z;
@@ -718,7 +755,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
       self.a1 = V3<R>{ms[3], ms[4], ms[5]};
       self.a3 = V3<R>{ms[6], ms[7], ms[8]};
       self.a2 = cross(self.a3, self.a1);
-      const R* fr = res_row(il, 0);
+      const R* fr = pool_row(row_base[fw][PPB] <= kPool ? row_base[fw][il] : il * 2);
       sg.dc = V3<R>{fr[0], fr[1], fr[2]};
       sg.g1 = V3<R>{fr[3], fr[4], fr[5]};
       sg.g2 = V3<R>{fr[6], fr[7], fr[8]};

@@ -343,3 +343,58 @@ def test_a_crowded_nucleotide_makes_the_step_rerun_with_wider_work_lists():
         integ2.run(cc, qc, pc, Lc, 3)
     # what comes back is the last state that counted (dt = 1e-9: indistinguishable from the start in fp32 digits)
     assert torch.isfinite(cc).all() and (cc - before).abs().max() < 1e-2 and integ2.step <= 3
+
+
+def test_a_crowded_workgroup_exhausts_the_row_pool_and_the_step_reruns():
+    """The result rows of the angular pass come out of one pool per workgroup (320 rows in the stepping instantiation:
+    a duplex takes 2 + ~5 per nucleotide).  32 unbonded nucleotides in a ball of radius 1: no nucleotide has more than 16
+    partners inside an angular range (so no work list is too short), but together they need 388 rows - the launch
+    aborts on the pool, the run repeats the step with the big instantiation, and the trajectory equals the oracle's."""
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+    from mythos_amd import _lib
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.input import defaults, topology
+    from oracle import oxdna_oracle as orc
+    from oracle.langevin_oracle import LangevinOracle
+
+    rng = np.random.default_rng(6)
+    n, radius, pts = 32, 1.0, []
+    while len(pts) < n:
+        v = rng.uniform(-radius, radius, 3)
+        if np.linalg.norm(v) <= radius and all(np.linalg.norm(v - w) >= 0.27 for w in pts):
+            pts.append(v)
+    c0 = np.array(pts)
+    q0 = rng.standard_normal((n, 4))
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    sim, cfg = defaults.default_configs_for("dna2")
+    named = fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=False)
+    # the premise, counted the way the radial pass flags entries: base-base distance inside the H-bond or cross-stacking
+    # support (list 0), stacking-site distance inside the coaxial support (list 1)
+    a1 = orc.quat_to_axes(torch.as_tensor(q0))[0].numpy()
+    g = cfg["geometry"]
+    db = np.linalg.norm((c0 + g["com_to_hb"] * a1)[:, None] - (c0 + g["com_to_hb"] * a1)[None], axis=-1) + 9.0 * np.eye(n)
+    ds = np.linalg.norm((c0 + g["com_to_stacking"] * a1)[:, None] - (c0 + g["com_to_stacking"] * a1)[None], axis=-1) + 9.0 * np.eye(n)
+    v = lambda k: float(named[k])  # noqa: E731
+    n0 = (((db > v("HYDR_RCLOW")) & (db < v("HYDR_RCHIGH"))) | ((db > v("CRST_RCLOW")) & (db < v("CRST_RCHIGH")))).sum(1)
+    n1 = ((ds > v("CXST_RCLOW")) & (ds < v("CXST_RCHIGH"))).sum(1)
+    assert (n0 + n1).max() <= 16 and (2 + n0 + n1).sum() > 320
+
+    flat = fp.pack_flat(named, _lib.param_names())
+    kT, dt = 296.15 * 0.1 / 300.0, 1e-9
+    top = topology.from_arrays(np.arange(n) % 4, [1] * n)
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=torch.float64)
+    s.set_params(flat)
+    s.set_neighbors(top.unbonded_neighbors)
+    integ = LangevinIntegrator(s, dt=dt, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5, seed=3)
+    c = torch.as_tensor(c0, device=s.device).contiguous()
+    q = torch.as_tensor(q0, device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    tc, tq, et = integ.run(c, q, p, L, 3, save_every=1)
+    assert integ.last_recoveries() == 1 and integ.step == 3
+    lo = LangevinOracle(2, H.oracle_params(2), H.topo_tensors(top), None, dt, kT, kT / 2.5, kT / 7.5, 1.0, (1.0, 1.0, 1.0), seed=3)
+    for k in range(3):
+        x, qq, pp, LL, u = lo.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=1e-11, atol=1e-12)
+        assert abs(et[k, :8].sum().item() - u) <= 1e-9 * abs(u)
+    np.testing.assert_allclose(p.cpu().numpy(), pp, rtol=1e-8, atol=1e-9 * np.abs(pp).max())
