@@ -278,11 +278,18 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   __shared__ R rad_lds[PPB][7];  // radial-pass site gradients (backbone, base) of each nucleotide
   // result rows, [nucleotide][slot][RW] with the nucleotide stride padded to an odd word count: the 32
   // nucleotides' rows then start in 32 different banks (20 x 13 = 260 words would alias p and p + 8)
-  constexpr int kPool = (ITEMS > kMdItems) ? PPB * kSlots : kMdPool;  // rows of the workgroup's pool (see kMdPool)
+  // fp64: rows out of the workgroup's pool (see kMdPool).  fp32 keeps a fixed block of kSlots rows per nucleotide: its
+  // LDS never decided the residency (2.9 workgroups per CU at 12 kbp), and the pool's second prefix scan and base-row
+  // look-ups cost it 1.2 % (61.3 k against 62.1 k steps/s, A/B on one box).
+  constexpr bool kPooled = sizeof(R) == 8;
+  constexpr int kPool = (ITEMS > kMdItems || !kPooled) ? PPB * kSlots : kMdPool;
   static_assert(kPool >= PPB * ROW_BONDED_SLOTS, "the pool holds at least the bonded rows");
-  __shared__ R res_flat[kPool * RW];
-  __shared__ int row_base[4][PPB + 1];  // per WAVEFRONT (like item_pre): first pool row of every nucleotide
+  __shared__ R res_flat[kPool * RW + (kPooled ? 0 : PPB)];
+  __shared__ int row_base[kPooled ? 4 : 1][PPB + 1];  // per WAVEFRONT (like item_pre): first pool row of every nucleotide
+  // fixed layout: the nucleotide stride padded to an odd word count, so the 32 nucleotides' blocks start in 32 banks
+  constexpr int kFixedStride = (kSlots * RW) | 1;
   auto pool_row = [&](int row) -> R* { return res_flat + row * RW; };
+  auto fixed_row = [&](int pp, int slot) -> R* { return res_flat + pp * kFixedStride + slot * RW; };
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
   const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
@@ -565,22 +572,29 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
     {
       const int l = threadIdx.x & 63;
       int inc = (l < PPB) ? item_cnt[lst][l] : 0;
-      // ... and of the rows every nucleotide takes from the result pool: its bonded slots, then its two work lists
-      int rows_inc = (l < PPB) ? n_bonded_rows + item_cnt[0][l] + item_cnt[1][l] : 0;
+      // ... and (pooled rows) of the rows every nucleotide takes from the result pool: its bonded slots, then its two lists
+      int rows_inc = (kPooled && l < PPB) ? n_bonded_rows + item_cnt[0][l] + item_cnt[1][l] : 0;
 #pragma unroll
       for (int o = 1; o < PPB; o <<= 1) {
         const int u = __shfl_up(inc, o, 64);
-        const int v = __shfl_up(rows_inc, o, 64);
-        if (l >= o) inc += u, rows_inc += v;
+        if (l >= o) inc += u;
+        if constexpr (kPooled) {
+          const int v = __shfl_up(rows_inc, o, 64);
+          if (l >= o) rows_inc += v;
+        }
       }
-      if (l < PPB) item_pre[pw][l + 1] = inc, row_base[pw][l + 1] = rows_inc;
-      if (l == 0) item_pre[pw][0] = 0, row_base[pw][0] = 0;
+      if (l < PPB) item_pre[pw][l + 1] = inc;
+      if (l == 0) item_pre[pw][0] = 0;
+      if constexpr (kPooled) {
+        if (l < PPB) row_base[pw][l + 1] = rows_inc;
+        if (l == 0) row_base[pw][0] = 0;
+      }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     // more rows than the pool holds (every wavefront computes the same number): nothing of the angular pass is
     // evaluated or folded, the launch is marked as not counting and the host goes on with the big instantiation
-    const bool pool_over = row_base[pw][PPB] > kPool;
+    const bool pool_over = kPooled && row_base[kPooled ? pw : 0][PPB] > kPool;
     if (pool_over && threadIdx.x == 0) atomicMax(flags + 3, k_index + 1);
     const int n_list = pool_over ? 0 : item_pre[pw][PPB];
     const int half = (n_list + 1) >> 1;
@@ -616,7 +630,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
       const int ip = bid * PPB + p;
       if (!active || ip >= n) continue;
       const int entry = bonded_wave ? rows[(size_t)ip * row_stride + sl] : sl;
-      R* out_r = pool_row(row_base[pw][p] + idx);
+      R* out_r = kPooled ? pool_row(row_base[kPooled ? pw : 0][p] + idx) : fixed_row(p, idx);
       SelfGrad<R> g;
       g.dc = g.g1 = g.g2 = g.g3 = V3<R>{R(0), R(0), R(0)};
       R ee[T_COUNT];
@@ -695,13 +709,14 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   SelfGrad<R> sg;
   sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
   // (any wavefront's copy of row_base: they are identical, and complete since the barrier above)
-  const int fw = threadIdx.x >> 6;
-  const int rb = row_base[fw][grp];
-  const bool pool_ok = row_base[fw][PPB] <= kPool;
+  const int fw = kPooled ? (int)(threadIdx.x >> 6) : 0;
+  const int rb = kPooled ? row_base[fw][grp] : 0;
+  const bool pool_ok = !kPooled || row_base[fw][PPB] <= kPool;
+  const int n_bonded_fold = extra_bonds ? ROW_BONDED_SLOTS : 2;  // rows 2, 3 exist only in systems with circular strands
   if (valid && pool_ok) {
-    const int total = row_base[fw][grp + 1] - rb;
+    const int total = kPooled ? row_base[fw][grp + 1] - rb : n_bonded_fold + item_cnt[0][grp] + item_cnt[1][grp];
     for (int u = lane; u < total; u += G) {
-      const R* rr = pool_row(rb + u);
+      const R* rr = kPooled ? pool_row(rb + u) : fixed_row(grp, u);
       sg.dc = sg.dc + V3<R>{rr[0], rr[1], rr[2]};
       sg.g1 = sg.g1 + V3<R>{rr[3], rr[4], rr[5]};
       sg.g2 = sg.g2 + V3<R>{rr[6], rr[7], rr[8]};
@@ -735,7 +750,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   // lane: the integrator is ~0.6 k instructions per lane whatever the lane count, and run by lane 0 of
   // every group it occupied all four SIMDs at 1/8 lane use
   if (lane == 0) {
-    R* fr = pool_row(pool_ok ? rb : grp * 2);  // (pool exhausted: the launch does not count; any free row will do)
+    R* fr = kPooled ? pool_row(pool_ok ? rb : grp * 2) : fixed_row(grp, 0);  // (pool exhausted: the launch does not count; any free row will do)
     fr[0] = sg.dc.x, fr[1] = sg.dc.y, fr[2] = sg.dc.z;
     fr[3] = sg.g1.x, fr[4] = sg.g1.y, fr[5] = sg.g1.z;
     fr[6] = sg.g2.x, fr[7] = sg.g2.y, fr[8] = sg.g2.z;
@@ -755,7 +770,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
       self.a1 = V3<R>{ms[3], ms[4], ms[5]};
       self.a3 = V3<R>{ms[6], ms[7], ms[8]};
       self.a2 = cross(self.a3, self.a1);
-      const R* fr = pool_row(row_base[fw][PPB] <= kPool ? row_base[fw][il] : il * 2);
+      const R* fr = kPooled ? pool_row(row_base[fw][PPB] <= kPool ? row_base[fw][il] : il * 2) : fixed_row(il, 0);
       sg.dc = V3<R>{fr[0], fr[1], fr[2]};
       sg.g1 = V3<R>{fr[3], fr[4], fr[5]};
       sg.g2 = V3<R>{fr[6], fr[7], fr[8]};

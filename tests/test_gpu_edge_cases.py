@@ -347,8 +347,8 @@ def test_a_crowded_nucleotide_makes_the_step_rerun_with_wider_work_lists():
 
 def test_a_crowded_workgroup_exhausts_the_row_pool_and_the_step_reruns():
     """The result rows of the angular pass come out of one pool per workgroup (320 rows in the stepping instantiation:
-    a duplex takes 2 + ~5 per nucleotide).  32 unbonded nucleotides in a ball of radius 1: no nucleotide has more than 16
-    partners inside an angular range (so no work list is too short), but together they need 388 rows - the launch
+    a duplex takes 2 + ~5 per nucleotide).  32 unbonded nucleotides in a ball of radius 0.9: no nucleotide has more than 14
+    partners inside an angular range (so no work list is too short), but together they need 350 rows - the launch
     aborts on the pool, the run repeats the step with the big instantiation, and the trajectory equals the oracle's."""
     from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
     from mythos_amd import _lib
@@ -357,8 +357,8 @@ def test_a_crowded_workgroup_exhausts_the_row_pool_and_the_step_reruns():
     from oracle import oxdna_oracle as orc
     from oracle.langevin_oracle import LangevinOracle
 
-    rng = np.random.default_rng(6)
-    n, radius, pts = 32, 1.0, []
+    rng = np.random.default_rng(21)
+    n, radius, pts = 32, 0.9, []
     while len(pts) < n:
         v = rng.uniform(-radius, radius, 3)
         if np.linalg.norm(v) <= radius and all(np.linalg.norm(v - w) >= 0.27 for w in pts):
@@ -368,20 +368,22 @@ def test_a_crowded_workgroup_exhausts_the_row_pool_and_the_step_reruns():
     q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
     sim, cfg = defaults.default_configs_for("dna2")
     named = fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=False)
-    # the premise, counted the way the radial pass flags entries: base-base distance inside the H-bond or cross-stacking
-    # support (list 0), stacking-site distance inside the coaxial support (list 1)
+    # the premise, counted the way the radial pass flags entries: base-base distance inside the cross-stacking support, or
+    # inside the H-bond support for a Watson-Crick pair (list 0); stacking-site distance inside the coaxial support (list 1)
     a1 = orc.quat_to_axes(torch.as_tensor(q0))[0].numpy()
     g = cfg["geometry"]
     db = np.linalg.norm((c0 + g["com_to_hb"] * a1)[:, None] - (c0 + g["com_to_hb"] * a1)[None], axis=-1) + 9.0 * np.eye(n)
     ds = np.linalg.norm((c0 + g["com_to_stacking"] * a1)[:, None] - (c0 + g["com_to_stacking"] * a1)[None], axis=-1) + 9.0 * np.eye(n)
     v = lambda k: float(named[k])  # noqa: E731
-    n0 = (((db > v("HYDR_RCLOW")) & (db < v("HYDR_RCHIGH"))) | ((db > v("CRST_RCLOW")) & (db < v("CRST_RCHIGH")))).sum(1)
+    seq = np.arange(n) % 4
+    wc = (seq[:, None] + seq[None]) == 3
+    n0 = (((db > v("HYDR_RCLOW")) & (db < v("HYDR_RCHIGH")) & wc) | ((db > v("CRST_RCLOW")) & (db < v("CRST_RCHIGH")))).sum(1)
     n1 = ((ds > v("CXST_RCLOW")) & (ds < v("CXST_RCHIGH"))).sum(1)
-    assert (n0 + n1).max() <= 16 and (2 + n0 + n1).sum() > 320
+    assert (n0 + n1).max() <= 14 and (2 + n0 + n1).sum() >= 340
 
     flat = fp.pack_flat(named, _lib.param_names())
     kT, dt = 296.15 * 0.1 / 300.0, 1e-9
-    top = topology.from_arrays(np.arange(n) % 4, [1] * n)
+    top = topology.from_arrays(seq, [1] * n)
     s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=torch.float64)
     s.set_params(flat)
     s.set_neighbors(top.unbonded_neighbors)
