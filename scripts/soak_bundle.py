@@ -44,7 +44,7 @@ for blk in range(n_steps // block):
     _, _, et = integ.run(c, q, p, L, block, save_every=block)
     e = et[-1].cpu().numpy()
     mx, mean = s.neighbor_stats()
-    print(f"step {block * (blk + 1):7d}  U/N {e[:8].sum() / n:8.4f}  T_kin/T {e[8:].sum() / (3 * n * kT):6.4f}  HB/N {e[3] / n:7.4f}"
+    print(f"step {block * (blk + 1):7d}  U/N {e[:8].sum() / n:8.4f}  T_kin/T {e[8:].sum() / (3 * n * kT):6.4f}  HB/N {e[4] / n:7.4f}"
           f"  rows mean {mean:.1f} max {mx}", flush=True)
 assert torch.isfinite(c).all()
 print("soak ok")

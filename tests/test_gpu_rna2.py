@@ -56,6 +56,26 @@ def test_single_term_matches_split_energy(name, mod, cls, cfg_cls, section, extr
     #  on random dimers instead, test_gpu_oxdna_energy.py::test_random_dimers)
 
 
+@pytest.mark.parametrize(("weights", "use_pseq"), [(torch.zeros(4, 4, dtype=torch.float64), False), (None, True)])
+def test_stacking_with_zero_weights_and_with_a_one_hot_probabilistic_sequence(weights, use_pseq):
+    """rna2/tests/test_integration.py:137-176, the second and third parametrisation: all-zero sequence weights give zero,
+    and a probabilistic sequence that is the discrete one (one-hot, no base-pair constraints) gives the discrete energy."""
+    from mythos_amd.input.sequence_constraints import dseq_to_pseq, from_bps
+
+    top, traj, split, _ = H.load_golden(3, HELIX)
+    default_params = rna2.default_configs()[1]
+    extra = {} if weights is None else {"ss_stack_weights": weights}
+    energy_config = rna2.StackingConfiguration(**(default_params["stacking"] | {"kt": KT}), **extra)
+    energy_fn = rna2.Stacking(displacement_fn=space.periodic(20.0)[0], transform_fn=rna2.default_transform_fn(), topology=top,
+                              params=energy_config.init_params())
+    if use_pseq:
+        sc = from_bps(top.n_nucleotides, bps=np.zeros((0, 2), dtype=np.int32))
+        energy_fn = energy_fn.with_params(pseq=dseq_to_pseq(top.seq, sc), pseq_constraints=sc)
+    energy = np.around(energy_fn.map(_states(traj)).cpu().numpy() / top.n_nucleotides, 6)
+    want = split[:, H.SPLIT_COLUMNS.index("stacking")] * (0.0 if weights is not None else 1.0)
+    np.testing.assert_allclose(energy, want, atol=1e-6 + 5e-7)
+
+
 @pytest.mark.parametrize("name", [HELIX, COAX])
 def test_total_energy_and_gradients_of_the_default_function(name):
     top, traj, _, energy = H.load_golden(3, name)
