@@ -110,6 +110,20 @@ int mythos_oxdna_set_nucleotide_types(mythos_system_t* sys, const uint8_t* is_rn
 int mythos_oxdna_set_pseq(mythos_system_t* sys, const double* marginals, const int32_t* unit, int n_bp,
                           const double* bp_probs, int terms);
 
+/* dU/d(sequence distribution): what jax.grad of the reference's energy function returns for the `pseq` leaves
+ * (compute_seq_dep_weight is differentiable in them, mythos/energy/utils.py:45-132).  The energy call with parameter
+ * partials, plus, per frame,
+ *   dU_dmarginals  device double[n_frames][n][4]        dU/d(marginal base probabilities) through the pairs whose two
+ *                                                        nucleotides are independent (different units)
+ *   dU_dbp         device double[n_frames][max(n_bp,1)][4]  dU/d(type probabilities) through the pairs that ARE a
+ *                                                        constrained base pair
+ * in the layout mythos_oxdna_set_pseq took; the host carries them to the reference's (unpaired, base-pair) arrays - a
+ * paired nucleotide's marginal is a sum of its pair's type probabilities.  Accumulated with fp64 atomics: equal to
+ * rounding between runs, not bit for bit.  Needs mythos_oxdna_set_pseq with terms != 0. */
+int mythos_oxdna_energy_dpseq(mythos_system_t* sys, const void* center, const void* quat, int n_frames, double* e_terms,
+                              void* dU_dcenter, void* dU_dquat, double* dU_dparams, double* dU_dmarginals, double* dU_dbp,
+                              mythos_stream_t stream);
+
 /* Unbonded pair list, reference semantics (NoNeighborList.idx, simulators/jax_md/utils.py:48-67):
  * host int32[n_pairs][2], rows (op_i, op_j) in that role order.  Converted to per-nucleotide rows. */
 int mythos_oxdna_set_neighbors(mythos_system_t* sys, const int32_t* pairs, int n_pairs);

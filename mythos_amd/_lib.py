@@ -58,6 +58,7 @@ def load() -> C.CDLL:
         "mythos_oxdna_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
         "mythos_oxdna_energy": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V]),
         "mythos_oxdna_energy_obs": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V, V, V]),
+        "mythos_oxdna_energy_dpseq": (C.c_int, [V, V, V, C.c_int, V, V, V, V, V, V, V]),
         "mythos_observables_create": (V, [C.c_int, C.c_int, c_double_p, c_double_p, C.c_int, c_int_p, C.c_int, c_int_p, C.c_int, C.c_int, C.c_int]),
         "mythos_observables_destroy": (None, [V]),
         "mythos_observables_width": (C.c_int, [V]),
@@ -119,6 +120,7 @@ DECLARED_SYMBOLS = (
     "mythos_oxdna_neighbor_stats",
     "mythos_oxdna_energy",
     "mythos_oxdna_energy_obs",
+    "mythos_oxdna_energy_dpseq",
     "mythos_observables_create",
     "mythos_observables_destroy",
     "mythos_observables_width",

@@ -249,6 +249,7 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
   }
   MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_unit, unit, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
   s->pseq_terms = terms;
+  s->ps_n_bp = n_bp;
   return MYTHOS_OK;
 }
 
@@ -307,6 +308,26 @@ int mythos_oxdna_energy(mythos_system_t* s, const void* center, const void* quat
   MYTHOS_HIP_TRY(hipSetDevice(s->device));
   return oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams, nullptr, nullptr,
                              (hipStream_t)stream);
+}
+
+int mythos_oxdna_energy_dpseq(mythos_system_t* s, const void* center, const void* quat, int n_frames, double* e_terms,
+                              void* dU_dcenter, void* dU_dquat, double* dU_dparams, double* dU_dmarginals, double* dU_dbp,
+                              mythos_stream_t stream) {
+  if (!s || n_frames < 0 || (n_frames > 0 && (!center || !quat || !e_terms || !dU_dparams || !dU_dmarginals || !dU_dbp))) {
+    set_error("mythos_oxdna_energy_dpseq: invalid argument (dU_dparams and both distribution-gradient buffers are required)");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->params_set || !s->nbrs_set || s->pseq_terms == 0) {
+    set_error("mythos_oxdna_energy_dpseq: parameters, neighbours and a probabilistic sequence (mythos_oxdna_set_pseq) must be set first");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  if (n_frames == 0) return MYTHOS_OK;
+  MYTHOS_HIP_TRY(hipSetDevice(s->device));
+  s->ps_gmarg = dU_dmarginals, s->ps_gbp = dU_dbp;
+  const int rc = oxdna_energy_launch(s, center, quat, n_frames, e_terms, dU_dcenter, dU_dquat, dU_dparams, nullptr, nullptr,
+                                     (hipStream_t)stream);
+  s->ps_gmarg = s->ps_gbp = nullptr;
+  return rc;
 }
 
 int mythos_oxdna_energy_obs(mythos_system_t* s, const void* center, const void* quat, int n_frames, double* e_terms,

@@ -97,6 +97,9 @@ struct mythos_system {
   void* d_ps_bp = nullptr;    // [max(n_bp, 1)][4] real: base-pair type probabilities
   int ps_bp_cap = 0;
   int pseq_terms = 0;         // bit 0 stacking, bit 1 hydrogen bonding
+  int ps_n_bp = 0;            // constrained base pairs of the distribution
+  double* ps_gmarg = nullptr; // caller's dU/d(marginals) and dU/d(type probabilities) buffers, set for the duration of
+  double* ps_gbp = nullptr;   // one mythos_oxdna_energy_dpseq call
 
   // energy-pass scratch
   double* d_epart = nullptr;  // [frames_chunk][blocks][8]

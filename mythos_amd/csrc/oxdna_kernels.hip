@@ -58,7 +58,7 @@ struct LdsPG {
 template <typename R, int MODE, int MODEL = 2>
 constexpr int energy_blocks_per_cu() {
   // oxNA with parameter partials: eight accumulator copies of three vectors are 50 KB of LDS - two workgroups per CU
-  if (MODEL == 4 && MODE == 2) return 2;
+  if (MODEL == 4 && MODE >= 2) return 2;
   // fp64: the energy-only mode runs faster at three workgroups per CU with 100 B of scratch than at two without
   // (0.58 -> 0.49 ms on the DiffTRe shape); the gradient modes spill too much for that (0.72 -> 1.43 ms)
   // fp32 forces mode: 128 registers without scratch, so four fit (at three the allocator takes 138 and the call is 18 % slower)
@@ -68,7 +68,9 @@ constexpr int energy_blocks_per_cu() {
 // SEG: rows longer than the LDS lists are walked in segments (gather_row)
 // OBS: the instantiation carries the observables epilogue.  A template parameter, not a run-time branch: the epilogue's
 // fp64 site algebra would otherwise set the register count of every launch (energy-only fp32: 96 -> 128 VGPRs + scratch).
-template <typename R, int MODEL, int MODE, int G, bool SEG, bool OBS>  // MODE 0 energy, 1 +gradients, 2 +parameter partials
+// MODE 0 energy, 1 + gradients, 2 + parameter partials, 3 + dU/d(sequence distribution) (mythos_oxdna_energy_dpseq: its
+// own instantiation - as run-time branches of MODE 2 the atomics cost the ordinary dU/dtheta call 1.3 - 1.5 % in fp64)
+template <typename R, int MODEL, int MODE, int G, bool SEG, bool OBS>
 __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) void oxdna_energy_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   __shared__ double e_lds[PPB][T_COUNT];
   extern __shared__ int item_lds[];  // [PPB][2][list_cap]: per group, the near and the angular entries of a row segment (gather_row)
   constexpr int kPgStride = pg_stride<MODEL>(), kPgUsed = oxp_used<MODEL>();
-  __shared__ double pg_lds[MODE == 2 ? kPgCopies * kPgStride : 1];
+  __shared__ double pg_lds[MODE >= 2 ? kPgCopies * kPgStride : 1];
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
@@ -92,7 +94,11 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
 #ifdef MYTHOS_EN_NO_PSEQ  // (dev A/B)
       return ConstParams<R, false>(Pg);
 #else
-      return ConstParams<R, true>(Pg, pseq);
+      PseqView<R> ps = pseq;
+      if constexpr (MODE == 3) {  // the gradient buffers of this frame
+        ps.gmarg += (size_t)blockIdx.y * n * 4, ps.gbp += (size_t)blockIdx.y * ps.bp_rows * 4;
+      }
+      return ConstParams<R, true, MODE == 3>(Pg, ps);
 #endif
     }
   }();
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   const int i = blockIdx.x * PPB + grp;
   const size_t fo = (size_t)frame * n;
 
-  if constexpr (MODE == 2) {
+  if constexpr (MODE >= 2) {
     for (int k = threadIdx.x; k < kPgCopies * kPgStride; k += kBlock) pg_lds[k] = 0.0;
   }
   __syncthreads();
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
         ld.load(ip, sp, qp);
         ld.load(entry & ROW_INDEX_MASK, other, q4);
         const V3<R> dco = min_image(other.c - sp.c, box);
-        if constexpr (MODE == 2) {
+        if constexpr (MODE >= 2) {
           LdsPG pg{pg_lds + pg_copy_of(threadIdx.x) * kPgStride};
           bonded_pair<R, MODEL, GRAD, LdsPG>(P, sp, other, dco, (slot & 1) == 1, R(0.5), eb, sb, pg);
         } else {
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   if (i < n) {
     Nuc<R> self;
     ld.load(i, self, qs);
-    if constexpr (MODE == 2) {
+    if constexpr (MODE >= 2) {
       LdsPG pg{pg_lds + pg_copy_of(threadIdx.x) * kPgStride};
       gather_row<R, MODEL, GRAD, LdsPG, G, false, SEG>(P, ld, box, rows, row_stride, row_len[i], i, self, lane, e, sg, pg, item_lds + (size_t)grp * 2 * list_cap, rnear2, list_cap);
     } else {
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
     for (int g = 0; g < PPB; ++g) s += e_lds[g][threadIdx.x];
     e_part[bo * T_COUNT + threadIdx.x] = s;
   }
-  if constexpr (MODE == 2) {
+  if constexpr (MODE >= 2) {
     for (int k = threadIdx.x; k < kPgUsed; k += kBlock) {
       double s = 0.0;
 #pragma unroll
@@ -267,14 +273,15 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   constexpr int PPB = kBlock / G;
   const int n = sys->n;
   const int blocks = (n + PPB - 1) / PPB;
-  const int mode = dU_dparams ? 2 : ((dU_dcenter || dU_dquat) ? 1 : 0);
+  const bool dpseq = dU_dparams && sys->pseq_terms != 0 && sys->ps_gmarg != nullptr;  // mythos_oxdna_energy_dpseq
+  const int mode = dU_dparams ? (dpseq ? 3 : 2) : ((dU_dcenter || dU_dquat) ? 1 : 0);
   // frames per chunk bounded by scratch (<= 256 MB of parameter partials) and the 65535 grid.y limit
   const int n_out = sys->param_sets() * (int)OXP_COUNT;  // width of a dU/dparams row
-  size_t per_frame = (size_t)blocks * (mode == 2 ? n_out : T_COUNT) * sizeof(double);
+  size_t per_frame = (size_t)blocks * (mode >= 2 ? n_out : T_COUNT) * sizeof(double);
   int chunk = (int)std::min<size_t>(65535, std::max<size_t>(1, (size_t(256) << 20) / per_frame));
   chunk = std::min(chunk, n_frames);
   if (int rc = ensure(sys->d_epart, sys->epart_cap, (size_t)chunk * blocks * T_COUNT)) return rc;
-  if (mode == 2)
+  if (mode >= 2)
     if (int rc = ensure(sys->d_pgpart, sys->pgpart_cap, (size_t)chunk * blocks * n_out)) return rc;
   const R* P = device_params_of<R>(sys);
   const BoxT<R> box = make_box<R>(sys);
@@ -314,10 +321,17 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     const R* q = quat + (size_t)f0 * n * 4;
     R* gc = dU_dcenter ? dU_dcenter + (size_t)f0 * n * 3 : nullptr;
     R* gq = dU_dquat ? dU_dquat + (size_t)f0 * n * 4 : nullptr;
+    if (mode == 3) {
+      pseq.bp_rows = std::max(sys->ps_n_bp, 1);
+      pseq.gmarg = sys->ps_gmarg + (size_t)f0 * n * 4;
+      pseq.gbp = sys->ps_gbp + (size_t)f0 * pseq.bp_rows * 4;
+      MYTHOS_HIP_TRY(hipMemsetAsync(pseq.gmarg, 0, (size_t)nf * n * 4 * sizeof(double), stream));
+      MYTHOS_HIP_TRY(hipMemsetAsync(pseq.gbp, 0, (size_t)nf * pseq.bp_rows * 4 * sizeof(double), stream));
+    }
     // the epilogue rides on the energy-only and the dU/dtheta launches (what a DiffTRe evaluation issues); a forces
     // launch with observables is followed by the stand-alone observables kernel instead (rare, and it keeps the
     // forces instantiation at four workgroups per CU)
-    const bool fuse = obs.width > 0 && mode != 1;
+    const bool fuse = obs.width > 0 && mode != 1 && mode != 3;
     auto launch = [&](auto mode_tag, auto seg_tag, auto obs_tag) {
       hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, decltype(mode_tag)::value, G, decltype(seg_tag)::value, decltype(obs_tag)::value>),
                          grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q, sys->d_meta, sys->d_rows,
@@ -331,6 +345,9 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     using F = std::false_type;
     if (mode == 0) { if (fuse) by_seg(std::integral_constant<int, 0>{}, T{}); else by_seg(std::integral_constant<int, 0>{}, F{}); }
     else if (mode == 1) by_seg(std::integral_constant<int, 1>{}, F{});
+    else if (mode == 3) {
+      if constexpr (MODEL != 4) by_seg(std::integral_constant<int, 3>{}, F{});  // (oxNA systems take no sequence distribution)
+    }
     else { if (fuse) by_seg(std::integral_constant<int, 2>{}, T{}); else by_seg(std::integral_constant<int, 2>{}, F{}); }
     if (obs.width > 0 && !fuse) {
       MYTHOS_HIP_TRY(hipGetLastError());
@@ -339,7 +356,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     MYTHOS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
                        e_terms + (size_t)f0 * T_COUNT, (int)T_COUNT);
-    if (mode == 2)
+    if (mode >= 2)
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(256), 0, stream, sys->d_pgpart, blocks,
                          oxp_used<MODEL>(), dU_dparams + (size_t)f0 * n_out, n_out);
     MYTHOS_HIP_TRY(hipGetLastError());

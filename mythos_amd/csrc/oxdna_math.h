@@ -33,6 +33,7 @@ template <typename R>
 struct OxParams {
   static constexpr bool indexed = false;
   static constexpr bool has_pseq = false;
+  static constexpr bool has_pseq_grad = false;
   R v[OXP_COUNT];
   __host__ __device__ __forceinline__ R operator[](int i) const { return v[i]; }
 };
@@ -54,11 +55,17 @@ struct PseqView {
   const int* unit = nullptr; // [n] 2 * base pair + position inside it, or -1 for an unpaired nucleotide
   const R* bp = nullptr;     // [n_bp][4] probability of the types AT, TA, GC, CG per constrained base pair
   int terms = 0;             // bit 0: stacking weights are expectations, bit 1: hydrogen-bonding weights are
+  // dU/d(distribution), accumulated with the parameter partials when asked for (mythos_oxdna_energy_dpseq): one frame's
+  // [n][4] and [bp_rows][4] doubles, fp64 atomics (the order of the additions is not fixed)
+  double* gmarg = nullptr;
+  double* gbp = nullptr;
+  int bp_rows = 0;
 };
-template <typename R, bool PSEQ = false>
+template <typename R, bool PSEQ = false, bool PSEQ_GRAD = false>
 struct ConstParams {
   static constexpr bool indexed = false;
   static constexpr bool has_pseq = PSEQ;  // the MD kernel compiles without the branch (and its registers)
+  static constexpr bool has_pseq_grad = PSEQ_GRAD;  // dU/d(distribution) accumulated too (PseqView::gmarg / gbp are set)
   typedef const R __attribute__((address_space(4))) * cptr;
   cptr p;
   PseqView<R> ps;

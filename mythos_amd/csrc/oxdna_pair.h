@@ -110,6 +110,14 @@ __device__ __forceinline__ void seq_weight_pgrad(const PT& P, int base, int term
         pg.add(base + (fwd ? 12 : 3), scale * b[1]);
         pg.add(base + (fwd ? 9 : 6), scale * b[2]);
         pg.add(base + (fwd ? 6 : 9), scale * b[3]);
+        if constexpr (PT::has_pseq_grad) {  // dU/d(type probabilities): the weight is linear in them; half per visit of the pair
+          double* g = P.ps.gbp + 4 * (up >> 1);
+          const double h = 0.5 * double(scale);
+          atomicAdd(g + 0, h * double(fwd ? P[base + 3] : P[base + 12]));
+          atomicAdd(g + 1, h * double(fwd ? P[base + 12] : P[base + 3]));
+          atomicAdd(g + 2, h * double(fwd ? P[base + 9] : P[base + 6]));
+          atomicAdd(g + 3, h * double(fwd ? P[base + 6] : P[base + 9]));
+        }
         return;
       }
       const R* mp = P.ps.marg + 4 * p.idx;
@@ -118,6 +126,19 @@ __device__ __forceinline__ void seq_weight_pgrad(const PT& P, int base, int term
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) pg.add(base + 4 * a + b, scale * mp[a] * mq[b]);
+      if constexpr (PT::has_pseq_grad) {  // dU/d(marginals): w = sum_ab mp[a] mq[b] T[a][b] is bilinear; half per visit of the pair
+        const double h = 0.5 * double(scale);
+        double* gp = P.ps.gmarg + 4 * p.idx;
+        double* gq = P.ps.gmarg + 4 * q.idx;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          R sp = R(0), sq = R(0);
+#pragma unroll
+          for (int b = 0; b < 4; ++b) sp += mq[b] * P[base + 4 * a + b], sq += mp[b] * P[base + 4 * b + a];
+          atomicAdd(gp + a, h * double(sp));
+          atomicAdd(gq + a, h * double(sq));
+        }
+      }
       return;
     }
   }
@@ -252,6 +273,7 @@ template <class PT>
 struct Na1Params {
   static constexpr bool indexed = false;
   static constexpr bool has_pseq = false;
+  static constexpr bool has_pseq_grad = false;
   PT dna, rna, drh;
 };
 template <class PG>

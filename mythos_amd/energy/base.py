@@ -178,6 +178,20 @@ def pseq_request(energy_fns):
     return None if found is None else (*found, terms)
 
 
+def pseq_tensors(energy_fns):
+    """(marginals, base-pair type probabilities) as differentiable functions of the ``pseq`` a term carries, if that
+    pseq holds tensors that require a gradient (sequence design: d<U>/d(distribution)); None otherwise."""
+    from mythos_amd.input.sequence_constraints import kernel_tables_torch
+
+    for fn in energy_fns:
+        if fn.term in ("stacking", "hydrogen_bonding") and "pseq" in fn.params and fn.params["pseq"] is not None:
+            pseq = fn.params["pseq"]
+            if any(isinstance(a, torch.Tensor) and a.requires_grad for a in pseq):
+                return kernel_tables_torch(pseq, fn.params["pseq_constraints"])
+            return None
+    return None
+
+
 def _apply_pseq(entry, request) -> None:
     tag = None if request is None else (request[3], *(a.tobytes() for a in request[:3]))
     if entry["pseq"] != tag:
@@ -231,7 +245,10 @@ class _EnergyOp(torch.autograd.Function):
     """(center, quat, flat) -> (weighted total per frame, raw term energies)."""
 
     @staticmethod
-    def forward(ctx, center, quat, flat, entry, weights):
+    def forward(ctx, center, quat, flat, entry, weights, marg=None, bp=None):
+        """``marg`` (N, 4), ``bp`` (max(n_bp, 1), 4): the probabilistic sequence the system was given, as differentiable
+        tensors - passed only when a gradient with respect to the distribution is wanted (the values the kernel reads
+        are the ones ``_apply_pseq`` uploaded)."""
         system = entry["sys"]
         flat_np = flat.detach().cpu().to(torch.float64)
         tag = flat_np.numpy().tobytes()
@@ -240,8 +257,14 @@ class _EnergyOp(torch.autograd.Function):
             entry["flat"] = tag
         need_x = center.requires_grad or quat.requires_grad
         need_p = flat.requires_grad
+        need_s = marg is not None and (marg.requires_grad or bp.requires_grad)
         fuse = entry.get("observe")  # (ObservableSet, [observables]) for this call, set by _evaluate
-        if fuse is not None and center.dim() == 3:
+        gm = gb = None
+        if need_s:
+            e, gc, gq, gp, gm, gb = system.energy(center.detach(), quat.detach(), grads=need_x, param_grads=True, pseq_grads=True)
+            if not need_p:
+                gp = None
+        elif fuse is not None and center.dim() == 3:
             from mythos_amd.observables.base import remember_fused
 
             cd, qd = center.detach().contiguous(), quat.detach().contiguous()
@@ -255,16 +278,16 @@ class _EnergyOp(torch.autograd.Function):
             e = e[None]
         w = torch.as_tensor(weights, dtype=torch.float64, device=e.device)
         total = e @ w
-        ctx.save_for_backward(*(t for t in (gc, gq, gp) if t is not None))
-        ctx.flags = (need_x, need_p, single, flat.device, flat.dtype)
+        ctx.save_for_backward(*(t for t in (gc, gq, gp, gm, gb) if t is not None))
+        ctx.flags = (need_x, need_p, single, flat.device, flat.dtype, need_s)
         ctx.mark_non_differentiable(e)
         return (total[0] if single else total), (e[0] if single else e)
 
     @staticmethod
     def backward(ctx, g_total, _g_terms):
-        need_x, need_p, single, fdev, fdt = ctx.flags
+        need_x, need_p, single, fdev, fdt, need_s = ctx.flags
         saved = list(ctx.saved_tensors)
-        gc = gq = gf = None
+        gc = gq = gf = g_marg = g_bp = None
         if need_x:
             dc_, dq_ = saved[0], saved[1]
             saved = saved[2:]
@@ -275,7 +298,13 @@ class _EnergyOp(torch.autograd.Function):
             dp = saved[0]
             gf = (dp * g_total.to(dp.dtype)) if single else (dp * g_total.to(dp.dtype)[:, None]).sum(0)
             gf = gf.to(device=fdev, dtype=fdt)
-        return gc, gq, gf, None, None
+            saved = saved[1:]
+        if need_s:
+            dm, db = saved[0], saved[1]
+            w = g_total.to(dm.dtype)
+            g_marg = ((dm * w) if single else (dm * w[:, None, None]).sum(0)).cpu()
+            g_bp = ((db * w) if single else (db * w[:, None, None]).sum(0)).cpu()
+        return gc, gq, gf, None, None, g_marg, g_bp
 
 
 # ---------------------------------------------------------------------------------------------
@@ -555,8 +584,13 @@ class ComposedEnergyFunction(EnergyFunction):
         if getattr(self, "observables", None) and center.dim() == 3 and center.device.type == "cuda":
             oset, served = _fused_observables(self.observables, int(center.shape[1]), center.dtype, center.device)
             entry["observe"] = None if oset is None else (oset, served)
+        pseq_leaves = pseq_tensors(self.energy_fns)
         try:
-            total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
+            if pseq_leaves is not None:
+                entry["observe"] = None  # the distribution gradient comes from its own entry point, without the epilogue
+                total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w, *pseq_leaves)
+            else:
+                total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         finally:
             entry["observe"] = None
         return total, terms, cols

@@ -75,6 +75,7 @@ class OxdnaSystem:
         if not self._h:
             raise _lib.MythosHipError(f"mythos_oxdna_create: {_lib.last_error()}")
         self._lib = lib
+        self._pseq_n_bp = 0
         # oxNA (model 4): three vectors - oxDNA2, oxRNA2, hybrid - one after the other; dU/dparams rows likewise
         self.n_params = lib.mythos_oxdna_param_count() * (3 if self.model == 4 else 1)
         if self.model == 4:
@@ -115,6 +116,7 @@ class OxdnaSystem:
         if marg.shape != (self.n, 4) or unit.shape != (self.n,):
             raise ValueError(f"marginals must be ({self.n}, 4) and unit ({self.n},)")
         n_bp = int(unit.max() // 2 + 1) if (unit >= 0).any() else 0
+        self._pseq_n_bp = n_bp
         if bp.shape[0] < n_bp:
             raise ValueError("bp_probs has fewer rows than the base pairs named in unit")
         _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, marg.ctypes.data_as(_lib.c_double_p), unit.ctypes.data_as(_lib.c_int_p),
@@ -151,12 +153,13 @@ class OxdnaSystem:
             raise ValueError(f"{name} must have trailing shape {tail}, got {tuple(t.shape)}")
         return t.contiguous()
 
-    def energy(self, center, quat, *, grads=False, param_grads=False, observables=None):
+    def energy(self, center, quat, *, grads=False, param_grads=False, observables=None, pseq_grads=False):
         """Term energies (F, 8) [float64] and optionally dU/dcenter, dU/dquat, dU/dflat.
 
         ``center`` (F, N, 3) or (N, 3); ``quat`` likewise with 4.  ``observables``: an
         ``mythos_amd.observables.ObservableSet`` evaluated in the epilogue of the same launch; its (F, width) rows are
-        then returned as a fifth value.
+        then returned as a fifth value.  ``pseq_grads`` (with ``param_grads``, after ``set_pseq``): also
+        dU/d(marginals) (F, N, 4) and dU/d(base-pair type probabilities) (F, max(n_bp, 1), 4), as a fifth and sixth value.
         """
         single = center.dim() == 2
         c = self._check(center, (self.n, 3), "center")
@@ -170,6 +173,21 @@ class OxdnaSystem:
         gc = torch.empty_like(c) if grads else None
         gq = torch.empty_like(q) if grads else None
         gp = torch.empty((nf, self.n_params), dtype=torch.float64, device=self.device) if param_grads else None
+        if pseq_grads:
+            if not param_grads or observables is not None:
+                raise ValueError("pseq_grads comes with param_grads and without fused observables")
+            gm = torch.empty((nf, self.n, 4), dtype=torch.float64, device=self.device)
+            gb = torch.empty((nf, max(self._pseq_n_bp, 1), 4), dtype=torch.float64, device=self.device)
+            _lib.check(
+                self._lib.mythos_oxdna_energy_dpseq(
+                    self._h, _lib.ptr(c), _lib.ptr(q), nf, _lib.ptr(e), _lib.ptr(gc), _lib.ptr(gq), _lib.ptr(gp), _lib.ptr(gm),
+                    _lib.ptr(gb), _stream(self.device),
+                ),
+                "energy_dpseq",
+            )
+            if single:
+                return e[0], (gc[0] if grads else None), (gq[0] if grads else None), gp[0], gm[0], gb[0]
+            return e, gc, gq, gp, gm, gb
         if observables is None:
             _lib.check(
                 self._lib.mythos_oxdna_energy(

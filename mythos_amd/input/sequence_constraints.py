@@ -169,3 +169,29 @@ def kernel_tables(pseq, sc: SequenceConstraints):
             for t in range(N_BP_TYPES):
                 marg[idx, BP_IDXS[t, w]] += bp[b, t]
     return marg, unit, np.ascontiguousarray(bp[: max(sc.n_bp, 1)] if sc.n_bp > 0 else np.zeros((1, 4)))
+
+
+def kernel_tables_torch(pseq, sc: SequenceConstraints):
+    """The (marginals, base-pair type probabilities) of ``kernel_tables`` as torch functions of the two pseq arrays, so
+    that dU/d(marginals) and dU/d(type probabilities) from the kernel flow back to them by autograd: an unpaired
+    nucleotide's marginal IS its row; a paired nucleotide's marginal sums its pair's type probabilities."""
+    import torch
+
+    up, bp = (torch.as_tensor(a, dtype=torch.float64) for a in pseq)
+    n = sc.n_nucleotides
+    sel_up = torch.zeros((n, max(sc.n_unpaired, 1)), dtype=torch.float64)
+    sel_bp = torch.zeros((n, N_NT, max(sc.n_bp, 1), N_BP_TYPES), dtype=torch.float64)
+    for idx in range(n):
+        if sc.is_unpaired[idx]:
+            sel_up[idx, int(sc.idx_to_unpaired_idx[idx])] = 1.0
+        else:
+            b, w = (int(v) for v in sc.idx_to_bp_idx[idx])
+            for t in range(N_BP_TYPES):
+                sel_bp[idx, int(BP_IDXS[t, w]), b, t] = 1.0
+    marg = torch.zeros((n, N_NT), dtype=torch.float64)
+    if sc.n_unpaired > 0:
+        marg = marg + sel_up[:, : sc.n_unpaired] @ up
+    if sc.n_bp > 0:
+        marg = marg + torch.einsum("iabt,bt->ia", sel_bp[:, :, : sc.n_bp], bp[: sc.n_bp])
+    bp_rows = bp[: sc.n_bp] if sc.n_bp > 0 else torch.zeros((1, N_BP_TYPES), dtype=torch.float64)
+    return marg, bp_rows

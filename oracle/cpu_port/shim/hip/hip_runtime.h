@@ -16,3 +16,9 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 #define __sinf sinf
 #define __cosf cosf
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32); }
+// (named by a branch of the templates that only the GPU's dU/d(sequence distribution) instantiation compiles)
+static inline double atomicAdd(double* p, double v) {
+  const double old = *p;
+  *p += v;
+  return old;
+}

@@ -119,6 +119,49 @@ def test_energies_forces_and_parameter_gradients_match_the_oracle():
     assert abs(tm[2] - tf[2]) < 1e-12 and abs(tm[4] - td[4]) < 1e-12 and abs(tm[2] - td[2]) > 1e-3
 
 
+@pytest.mark.parametrize("model", [2, 1])
+def test_gradient_with_respect_to_the_distribution(model):
+    """dU/d(pseq) - what jax.grad of the reference's energy function returns for the two pseq arrays (sequence design):
+    the kernel's dU/d(marginals) and dU/d(type probabilities) (mythos_oxdna_energy_dpseq), carried to the (unpaired,
+    base-pair) arrays by autograd, against the oracle's autograd through compute_seq_dep_weight.  Unpaired-unpaired,
+    unpaired-paired, same-pair and different-pair contacts all occur; frames and a parameter gradient ride along."""
+    top, traj, _, _ = H.load_golden(model, "simple-helix")
+    mod = dna2 if model == 2 else dna1
+    disp, _ = space.periodic(traj.box_size)
+    n = top.n_nucleotides
+    sc = scm.from_bps(n, np.array([[1, 14], [2, 13], [5, 10], [7, 8]]))
+    rng = np.random.default_rng(11)
+
+    def dist(rows):
+        a = rng.random((rows, 4)) + 0.05
+        return a / a.sum(1, keepdims=True)
+
+    up0, bp0, w_st, w_hb = dist(sc.n_unpaired), dist(sc.n_bp), rng.random((4, 4)) + 0.5, rng.random((4, 4)) + 0.2
+    frames = [4, 33, 61]
+    st = _states(traj, frames, torch.float64)
+    up_h, bp_h = (torch.tensor(a, requires_grad=True) for a in (up0, bp0))
+    a_h = torch.tensor(6.0, dtype=torch.float64, requires_grad=True)
+    ef = mod.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(ss_stack_weights=w_st, ss_hb_weights=w_hb)
+    u_h = ef.with_params({"a_stack": a_h}, pseq=(up_h, bp_h), pseq_constraints=sc).map(st)
+    coef = torch.tensor([1.0, -0.5, 2.0], dtype=torch.float64, device=u_h.device)  # frames weigh differently: the backward pass scales per frame
+    g_h = torch.autograd.grad((u_h * coef).sum(), [up_h, bp_h, a_h])
+    up_o, bp_o = (torch.tensor(a, requires_grad=True) for a in (up0, bp0))
+    a_o = torch.tensor(6.0, dtype=torch.float64, requires_grad=True)
+    P = H.oracle_params(model, half_charged_ends=True, overrides={
+        "stacking": {"ss_stack_weights": w_st, "a_stack": a_o, "pseq": (up_o, bp_o), "pseq_constraints": sc},
+        "hydrogen_bonding": {"ss_hb_weights": w_hb, "pseq": (up_o, bp_o), "pseq_constraints": sc}})
+    tt = H.topo_tensors(top)
+    u_o = torch.stack([orc.energy(model, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), *tt, traj.box_size) for f in frames])
+    np.testing.assert_allclose(u_h.detach().cpu().numpy(), u_o.detach().numpy(), rtol=1e-10)
+    g_o = torch.autograd.grad((u_o * coef.cpu()).sum(), [up_o, bp_o, a_o])
+    for name, a, b in zip(("unpaired", "base pairs", "a_stack"), g_h, g_o):
+        assert b.abs().max().item() > 1e-3, name
+        assert (a.cpu() - b).abs().max().item() <= 1e-9 * max(1.0, b.abs().max().item()), (name, a, b)
+    # no gradient asked for the distribution: the ordinary entry point serves the call, same energies
+    u_plain = ef.with_params(pseq=(up0, bp0), pseq_constraints=sc).map(st)
+    assert torch.equal(u_plain, u_h.detach())
+
+
 def test_dynamics_refuse_a_sequence_distribution():
     from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
     from mythos_amd.simulators.neighbors import NoNeighborList

@@ -179,3 +179,33 @@ def test_expected_energy_equals_brute_force_enumeration(term):
     want = sum(prob * term_energy(P_d, torch.as_tensor(seq)) for seq, prob in enumerate_sequences(sc, up, bp))
     assert np.abs(want).max() > 1e-3
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+
+
+def test_differentiable_kernel_tables_equal_the_plain_ones():
+    """kernel_tables_torch: the same marginals and base-pair rows as kernel_tables, and their Jacobian is the 0 / 1
+    incidence the chain rule of dU/d(pseq) needs (a paired nucleotide's marginal sums its pair's type probabilities)."""
+    import torch
+
+    from mythos_amd.input import sequence_constraints as scm
+
+    sc = scm.from_bps(8, np.array([[0, 7], [2, 5]]))
+    rng = np.random.default_rng(0)
+    up = rng.random((sc.n_unpaired, 4))
+    bp = rng.random((2, 4))
+    m, unit, b = scm.kernel_tables((up, bp), sc)
+    up_t, bp_t = torch.tensor(up, requires_grad=True), torch.tensor(bp, requires_grad=True)
+    mt, bt = scm.kernel_tables_torch((up_t, bp_t), sc)
+    np.testing.assert_array_equal(mt.detach().numpy(), m)
+    np.testing.assert_array_equal(bt.detach().numpy(), b)
+    w = torch.tensor(rng.random(m.shape))
+    g_up, g_bp = torch.autograd.grad((mt * w).sum(), [up_t, bp_t])
+    for k, idx in enumerate(sc.unpaired):
+        np.testing.assert_allclose(g_up[k].numpy(), w[idx].numpy())
+    # type t of pair k puts probability on base BP_IDXS[t][0] of its first member and BP_IDXS[t][1] of its second
+    for k, (i, j) in enumerate(sc.bps):
+        for t in range(4):
+            assert abs(float(g_bp[k, t]) - float(w[i, scm.BP_IDXS[t, 0]] + w[j, scm.BP_IDXS[t, 1]])) < 1e-15
+    sc0 = scm.from_bps(4, np.zeros((0, 2), dtype=np.int32))
+    m0, _, b0 = scm.kernel_tables((np.eye(4), np.zeros((1, 4))), sc0)
+    mt0, bt0 = scm.kernel_tables_torch((torch.eye(4, dtype=torch.float64), torch.zeros(1, 4)), sc0)
+    assert np.array_equal(mt0.numpy(), m0) and bt0.shape == b0.shape
