@@ -891,12 +891,22 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS>())) voi
   }
 }
 
-__global__ void reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
-  const int k = threadIdx.x;
-  if (k >= kTraceWidth) return;
+// 256 threads = 16 columns (10 used) x 16 groups of workgroup partials, the group sums added in a fixed order (one thread
+// per column was a chain of n_blocks dependent loads: 110 us per saved step at 12 kbp)
+__global__ __launch_bounds__(256) void reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
+  __shared__ double acc[16][17];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
   double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * kTraceWidth + k];
-  if (out) out[k] = s;
+  if (k < kTraceWidth)
+    for (int b = g; b < n_blocks; b += 16) s += part[(size_t)b * kTraceWidth + k];
+  acc[g][k] = s;
+  __syncthreads();
+  if (g == 0 && k < kTraceWidth && out) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += acc[j][k];
+    out[k] = t;
+  }
 }
 
 // ------------------------------------------------------------------ packed (N,3)/(N,4) <-> frame
@@ -1024,6 +1034,10 @@ struct mythos_sim {
   static constexpr int kMaxSamples = 16;
   int timing_samples = 0;  // dispatches per run timed with their own event pair (set_timing; ~8 us each)
   hipEvent_t sa[kMaxSamples] = {}, sb[kMaxSamples] = {};
+  // oxNA (model 4), unfused path: packed state + gradients of the energy kernel + list reference (see unfused_*)
+  void *u_c = nullptr, *u_q = nullptr, *u_p = nullptr, *u_l = nullptr, *u_gc = nullptr, *u_gq = nullptr, *u_ref = nullptr;
+  double* u_e = nullptr;  // [8] term energies of the last force evaluation + [2] kinetic energies
+  bool u_forces_valid = false;
   double last_avg_ms = 0;     // (ev1 - ev0) / launches: includes rebuilds and inter-kernel gaps
   double last_kernel_ms = 0;  // mean over the sampled single-launch intervals
   int last_launches = 0;
@@ -1228,7 +1242,7 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       if (sampled) ea = sim->sa[samples], eb = sim->sb[samples], ++samples;
       if (save) {
         if (sim->items_big) launch(T{}, BigS{}, ea, eb); else launch(T{}, Small{}, ea, eb);
-        hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
+        hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
                            e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
       } else {
         if (sim->items_big) launch(F{}, BigN{}, ea, eb); else launch(F{}, Small{}, ea, eb);
@@ -1330,6 +1344,222 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
   return MYTHOS_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// oxNA (model 4): the UNFUSED path.  The fused step kernel has no hybrid instantiation (its hand-written radial pass and
+// per-role work lists would need the three-way dispatch of oxdna_pair.h); a hybrid system is advanced by two launches
+// per step instead - the energy kernel's forces instantiation (dU/dcentre, dU/dquaternion of the packed state), then
+// this integrator kernel, one thread per nucleotide: the same B A O A | B map, Philox stream and free-rotor drift as
+// md_step_kernel's integrator (shared device functions), so a trajectory is held to the same oracle.
+// The list: static rows (mythos_oxdna_set_neighbors), or the integrator's policy - rows of range r_cut + skin rebuilt
+// every rebuild_every steps from the centres; the host looks at the skin flag at every rebuild (it synchronises there
+// anyway) and a violation is an error (no halt-and-resume on this path): shorten the interval or widen the skin.
+// ------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void unfused_integrate_kernel(int n, const LangevinConst<R> K, R* __restrict__ c, R* __restrict__ q, R* __restrict__ p,
+                                         R* __restrict__ L, const R* __restrict__ gc, const R* __restrict__ gq, R kick_close,
+                                         int do_step, uint64_t seed, uint64_t step, const R* __restrict__ ref, R site_reach,
+                                         int* __restrict__ flags, R* __restrict__ traj_c, R* __restrict__ traj_q,
+                                         double* __restrict__ ke /* [2], atomics; null: not wanted */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double ke_t = 0.0, ke_r = 0.0;
+  if (i < n) {
+    R x[3] = {c[3 * i], c[3 * i + 1], c[3 * i + 2]};
+    R qs[4] = {q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]};
+    R pp[3] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]}, LL[3] = {L[3 * i], L[3 * i + 1], L[3 * i + 2]};
+    const R F[3] = {-gc[3 * i], -gc[3 * i + 1], -gc[3 * i + 2]};
+    const R g0 = gq[4 * i], g1 = gq[4 * i + 1], g2 = gq[4 * i + 2], g3 = gq[4 * i + 3];
+    // body torque from the quaternion gradient: tau_k = -1/2 (P_k q) . dU/dq (NO_SQUISH permutations)
+    const R tb[3] = {R(-0.5) * (-qs[1] * g0 + qs[0] * g1 + qs[3] * g2 - qs[2] * g3),
+                     R(-0.5) * (-qs[2] * g0 - qs[3] * g1 + qs[0] * g2 + qs[1] * g3),
+                     R(-0.5) * (-qs[3] * g0 + qs[2] * g1 - qs[1] * g2 + qs[0] * g3)};
+    const R kc = kick_close * K.dt;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pp[k] += kc * F[k], LL[k] += kc * tb[k];
+    if (ke) {
+      ke_t = 0.5 * double(K.inv_mass) * (double(pp[0]) * pp[0] + double(pp[1]) * pp[1] + double(pp[2]) * pp[2]);
+      ke_r = 0.5 * (double(K.inv_inertia[0]) * LL[0] * LL[0] + double(K.inv_inertia[1]) * LL[1] * LL[1] +
+                    double(K.inv_inertia[2]) * LL[2] * LL[2]);
+    }
+    if (traj_c) traj_c[3 * i] = x[0], traj_c[3 * i + 1] = x[1], traj_c[3 * i + 2] = x[2];
+    if (traj_q) traj_q[4 * i] = qs[0], traj_q[4 * i + 1] = qs[1], traj_q[4 * i + 2] = qs[2], traj_q[4 * i + 3] = qs[3];
+    if (do_step) {
+      R z[6];
+      normals6(seed, (uint32_t)i, step, 0u, z);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pp[k] += K.half_dt * F[k], LL[k] += K.half_dt * tb[k];
+      drift(x, qs, pp, LL, K.half_dt, K);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) pp[k] = K.c1_t * pp[k] + K.c2_t * z[k], LL[k] = K.c1_r * LL[k] + K.c2_r[k] * z[3 + k];
+      drift(x, qs, pp, LL, K.half_dt, K);
+      const R inv = m_rsqrt(qs[0] * qs[0] + qs[1] * qs[1] + qs[2] * qs[2] + qs[3] * qs[3]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) qs[k] *= inv;
+      if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
+      if (ref != nullptr) {
+        // no site may have moved more than skin / 2 since the build: |d site| <= |d centre| + sum_k |coef_k| |d a_k|
+        // (site_reach bounds the sum of the offset coefficients of any site in either geometry)
+        V3<R> a1, a2, a3;
+        quat_axes(qs[0], qs[1], qs[2], qs[3], a1, a2, a3);
+        const R* rr = ref + 12 * (size_t)i;
+        const V3<R> dx{x[0] - rr[0], x[1] - rr[1], x[2] - rr[2]};
+        const V3<R> d1{a1.x - rr[3], a1.y - rr[4], a1.z - rr[5]}, d2{a2.x - rr[6], a2.y - rr[7], a2.z - rr[8]},
+            d3{a3.x - rr[9], a3.y - rr[10], a3.z - rr[11]};
+        const R da = m_sqrt(fmax(dot(d1, d1), fmax(dot(d2, d2), dot(d3, d3))));
+        const R moved = m_sqrt(dot(dx, dx)) + site_reach * da;
+        if (moved * moved > K.skin_half_sq) atomicOr(flags + 1, 1);
+      }
+      c[3 * i] = x[0], c[3 * i + 1] = x[1], c[3 * i + 2] = x[2];
+      q[4 * i] = qs[0], q[4 * i + 1] = qs[1], q[4 * i + 2] = qs[2], q[4 * i + 3] = qs[3];
+    }
+    p[3 * i] = pp[0], p[3 * i + 1] = pp[1], p[3 * i + 2] = pp[2];
+    L[3 * i] = LL[0], L[3 * i + 1] = LL[1], L[3 * i + 2] = LL[2];
+  }
+  if (ke) {  // one atomic pair per wavefront
+    for (int o = 32; o > 0; o >>= 1) ke_t += __shfl_down(ke_t, o, 64), ke_r += __shfl_down(ke_r, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(ke, ke_t), atomicAdd(ke + 1, ke_r);
+  }
+}
+
+// list reference of the unfused path: centre and the three axes at build time
+template <typename R>
+__global__ void unfused_ref_kernel(int n, const R* __restrict__ c, const R* __restrict__ q, R* __restrict__ ref) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3<R> a1, a2, a3;
+  quat_axes(q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3], a1, a2, a3);
+  R* rr = ref + 12 * (size_t)i;
+  rr[0] = c[3 * i], rr[1] = c[3 * i + 1], rr[2] = c[3 * i + 2];
+  rr[3] = a1.x, rr[4] = a1.y, rr[5] = a1.z, rr[6] = a2.x, rr[7] = a2.y, rr[8] = a2.z, rr[9] = a3.x, rr[10] = a3.y, rr[11] = a3.z;
+}
+
+__global__ void unfused_trace_kernel(const double* __restrict__ e, double* __restrict__ row) {
+  if (threadIdx.x < kTraceWidth) row[threadIdx.x] = e[threadIdx.x];
+}
+
+template <typename R>
+static int unfused_alloc(mythos_sim* sim) {
+  if (sim->u_c) return 0;
+  const size_t n = (size_t)sim->sys->n;
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_c, 3 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_q, 4 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_p, 3 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_l, 3 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_gc, 3 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_gq, 4 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc(&sim->u_ref, 12 * n * sizeof(R)));
+  MYTHOS_HIP_TRY(hipMalloc((void**)&sim->u_e, kTraceWidth * sizeof(double)));
+  return 0;
+}
+
+template <typename R>
+static int unfused_load(mythos_sim* sim, const R* c, const R* q, const R* p, const R* l, hipStream_t st) {
+  if (int rc = unfused_alloc<R>(sim)) return rc;
+  const size_t n = (size_t)sim->sys->n;
+  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->u_c, c, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->u_q, q, 4 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->u_p, p, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(sim->u_l, l, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  sim->resident = true;
+  sim->list_valid = false;
+  sim->since_build = 0;
+  sim->u_forces_valid = false;
+  return 0;
+}
+
+template <typename R>
+static int unfused_store(mythos_sim* sim, R* c, R* q, R* p, R* l, hipStream_t st) {
+  const size_t n = (size_t)sim->sys->n;
+  MYTHOS_HIP_TRY(hipMemcpyAsync(c, sim->u_c, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(q, sim->u_q, 4 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(p, sim->u_p, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  MYTHOS_HIP_TRY(hipMemcpyAsync(l, sim->u_l, 3 * n * sizeof(R), hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+template <typename R>
+static int unfused_advance(mythos_sim* sim, int n_steps, int save_every, R* traj_c, R* traj_q, double* e_trace, hipStream_t st) {
+  mythos_system* sys = sim->sys;
+  const int n = sys->n, tb = (n + 255) / 256;
+  const LangevinConst<R> K = make_const<R>(sim);
+  R *c = (R*)sim->u_c, *q = (R*)sim->u_q, *p = (R*)sim->u_p, *l = (R*)sim->u_l, *gc = (R*)sim->u_gc, *gq = (R*)sim->u_gq;
+  R* ref = (R*)sim->u_ref;
+  const bool dynamic = sim->rebuild_every > 0;
+  sim->last_recoveries = 0;
+  // the sum of the offset coefficients of the farthest site, over both geometries (bounds a site's motion under rotation)
+  double reach = 0.0;
+  for (int k = 0; k < 2; ++k) {
+    const double* P = sys->pd_sets.data() + (size_t)k * OXP_COUNT;
+    reach = std::max({reach, std::fabs(P[GEO_BACK_A1]) + std::fabs(P[GEO_BACK_A2]), std::fabs(P[GEO_BASE]), std::fabs(P[GEO_STACK]),
+                      std::fabs(P[GEO_STACK3_A1]) + std::fabs(P[GEO_STACK3_A2]), std::fabs(P[GEO_STACK5_A1]) + std::fabs(P[GEO_STACK5_A2])});
+  }
+  auto build = [&]() -> int {
+    if (int rc = rows_build_until_fit(sys, c, false, sim->r_cut, sim->skin, nullptr, nullptr, false, true, st)) return rc;
+    hipLaunchKernelGGL(unfused_ref_kernel<R>, dim3(tb), dim3(256), 0, st, n, (const R*)c, (const R*)q, ref);
+    sim->since_build = 0;
+    sim->list_valid = true;
+    sim->list_epoch = ++sys->list_epoch;
+    return 0;
+  };
+  auto forces = [&]() -> int {
+    return oxdna_energy_launch(sys, c, q, 1, sim->u_e, gc, gq, nullptr, nullptr, nullptr, st);
+  };
+  auto check_flags = [&](const char* when) -> int {
+    int fl[2] = {0, 0};
+    MYTHOS_HIP_TRY(hipMemcpyAsync(fl, sim->d_flags, sizeof(fl), hipMemcpyDeviceToHost, st));
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+    MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, 2 * sizeof(int), st));
+    if (fl[0] & 2) {
+      sim->resident = false;
+      set_error(std::string("mythos_langevin_run (oxNA, unfused): NaN in the state ") + when);
+      return MYTHOS_ERR_NUMERIC;
+    }
+    if (fl[1] != 0) {
+      sim->resident = false;
+      set_error("mythos_langevin_run (oxNA, unfused): a site moved more than skin / 2 between two list rebuilds; shorten "
+                "rebuild_every or widen the skin (this path does not halt and resume)");
+      return MYTHOS_ERR_OVERFLOW;
+    }
+    return 0;
+  };
+  MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, mythos_sim::kCtlWords * sizeof(int), st));
+  if (!sim->list_valid) sim->u_forces_valid = false;  // parameters or rows were replaced since the last force evaluation
+  if (dynamic && !sim->list_valid)
+    if (int rc = build()) return rc;
+  if (!sim->u_forces_valid) {
+    if (int rc = forces()) return rc;
+    sim->u_forces_valid = true;
+  }
+  int saved = 0;
+  for (int k = 0; k <= n_steps; ++k) {
+    // launch k: close the kick of step k - 1 (the forces at x_k are in gc / gq), record x_k, then step k -> k + 1
+    const bool do_step = k < n_steps;
+    const bool save = save_every > 0 && k > 0 && k % save_every == 0;
+    if (k == 0 && !do_step) break;  // zero steps: nothing to close
+    R* tc = (save && traj_c) ? traj_c + (size_t)saved * n * 3 : nullptr;
+    R* tq = (save && traj_q) ? traj_q + (size_t)saved * n * 4 : nullptr;
+    double* ke = save ? sim->u_e + T_COUNT : nullptr;
+    if (save) MYTHOS_HIP_TRY(hipMemsetAsync(sim->u_e + T_COUNT, 0, 2 * sizeof(double), st));
+    hipLaunchKernelGGL(unfused_integrate_kernel<R>, dim3(tb), dim3(256), 0, st, n, K, c, q, p, l, (const R*)gc, (const R*)gq,
+                       R(k > 0 ? 0.5 : 0.0), do_step ? 1 : 0, sim->seed, (uint64_t)(sim->step + k), dynamic ? (const R*)ref : nullptr,
+                       R(reach), sim->d_flags, tc, tq, ke);
+    if (save) {
+      if (e_trace) hipLaunchKernelGGL(unfused_trace_kernel, dim3(1), dim3(64), 0, st, (const double*)sim->u_e, e_trace + (size_t)saved * kTraceWidth);
+      ++saved;
+    }
+    if (!do_step) break;
+    ++sim->since_build;
+    if (dynamic && sim->since_build >= sim->rebuild_every) {
+      if (int rc = check_flags("before a list rebuild")) return rc;
+      if (int rc = build()) return rc;
+    }
+    if (int rc = forces()) return rc;
+  }
+  MYTHOS_HIP_TRY(hipGetLastError());
+  if (int rc = check_flags("at the end of the run")) return rc;
+  sim->step += n_steps;
+  return 0;
+}
+
 }  // namespace mythos
 
 extern "C" {
@@ -1338,11 +1568,6 @@ mythos_sim_t* mythos_langevin_create(mythos_system_t* sys, double dt, double kT,
                                      double mass, const double* inertia, uint64_t seed) {
   if (!sys || !(dt > 0) || !(kT >= 0) || gamma_t < 0 || gamma_r < 0 || !(mass > 0)) {
     set_error("mythos_langevin_create: invalid argument");
-    return nullptr;
-  }
-  if (sys->model == 4) {
-    set_error("mythos_langevin_create: oxNA systems (model 4) are evaluated by the energy entry points only; the fused "
-              "step kernel has no hybrid DNA / RNA instantiation");
     return nullptr;
   }
   if (hipSetDevice(sys->device) != hipSuccess) {
@@ -1389,6 +1614,8 @@ void mythos_langevin_destroy(mythos_sim_t* s) {
   for (int k = 0; k < 2; ++k)
     for (int a = 0; a < mythos_sim::kFrameArrays; ++a)
       if (s->frame[k][a]) (void)hipFree(s->frame[k][a]);
+  for (void* u : {s->u_c, s->u_q, s->u_p, s->u_l, s->u_gc, s->u_gq, s->u_ref, (void*)s->u_e})
+    if (u) (void)hipFree(u);
   if (s->keep_hi) (void)hipFree(s->keep_hi);
   if (s->keep_lo) (void)hipFree(s->keep_lo);
   if (s->d_flags) (void)hipFree(s->d_flags);
@@ -1450,6 +1677,10 @@ int md_ready(mythos_sim_t* s, const char* who) {
     set_error(std::string(who) + ": the system carries a probabilistic sequence (mythos_oxdna_set_pseq); dynamics need a discrete one");
     return MYTHOS_ERR_NOT_READY;
   }
+  if (sys->model == 4 && !sys->types_set) {
+    set_error(std::string(who) + ": an oxNA system needs its nucleotide types (mythos_oxdna_set_nucleotide_types)");
+    return MYTHOS_ERR_NOT_READY;
+  }
   MYTHOS_HIP_TRY(hipSetDevice(sys->device));
   if (s->rebuild_every > 0 && sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
@@ -1462,6 +1693,9 @@ int md_ready(mythos_sim_t* s, const char* who) {
 
 int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
   mythos_system* sys = s->sys;
+  if (sys->model == 4)  // oxNA: the unfused path
+    return sys->dtype == MYTHOS_F32 ? unfused_load<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+                                    : unfused_load<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (sys->dtype == MYTHOS_F32)
     return sys->model == 1   ? load_typed<float, 1>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
            : sys->model == 2 ? load_typed<float, 2>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
@@ -1473,6 +1707,9 @@ int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st)
 
 int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
   mythos_system* sys = s->sys;
+  if (sys->model == 4)
+    return sys->dtype == MYTHOS_F32 ? unfused_advance<float>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
+                                    : unfused_advance<double>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
   if (sys->dtype == MYTHOS_F32)
     return sys->model == 1   ? advance_typed<float, 1>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
            : sys->model == 2 ? advance_typed<float, 2>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
@@ -1483,6 +1720,9 @@ int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq,
 }
 
 int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
+  if (s->sys->model == 4)
+    return s->sys->dtype == MYTHOS_F32 ? unfused_store<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+                                       : unfused_store<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (s->sys->dtype == MYTHOS_F32) return store_typed<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
   return store_typed<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
 }

@@ -284,12 +284,22 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   }
 }
 
-__global__ void mm_reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
-  const int k = threadIdx.x;
-  if (k >= kMmTrace || !out) return;
+// 256 threads = 16 columns x 16 groups of workgroup partials, the group sums added in a fixed order (as langevin.hip's)
+__global__ __launch_bounds__(256) void mm_reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
+  static_assert(kMmTrace <= 16, "one column per trace entry");
+  __shared__ double acc[16][17];
+  const int k = threadIdx.x & 15, g = threadIdx.x >> 4;
   double s = 0.0;
-  for (int b = 0; b < n_blocks; ++b) s += part[(size_t)b * kMmTrace + k];
-  out[k] = s;
+  if (k < kMmTrace)
+    for (int b = g; b < n_blocks; b += 16) s += part[(size_t)b * kMmTrace + k];
+  acc[g][k] = s;
+  __syncthreads();
+  if (g == 0 && k < kMmTrace && out) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += acc[j][k];
+    out[k] = t;
+  }
 }
 
 template <typename R>
@@ -696,7 +706,7 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k
       if (save) {
         hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
-        hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(64), 0, st, sim->d_epart, blocks,
+        hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
                            e_trace ? e_trace + (size_t)sidx * kMmTrace : nullptr);
       } else if (sampled) {
         hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],

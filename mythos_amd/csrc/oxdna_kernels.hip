@@ -242,9 +242,38 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   }
 }
 
-// out[frame][k] = sum_b part[frame][b][k] for k < width, fixed order; 0 for width <= k < out_width
-__global__ void reduce_partials_kernel(const double* __restrict__ part, int n_blocks, int width,
-                                       double* __restrict__ out, int out_width) {
+// out[frame][k] = sum_b part[frame][b][k] for k < width; 0 for width <= k < out_width.  Grid (frames, ceil(out_width / 16)),
+// 256 threads = 16 columns x 16 groups of workgroup partials: every thread adds the partials b = group, group + 16, ...
+// of its column, then the 16 group sums are added in a fixed order.  (One thread per column walking all n_blocks
+// partials - the first version - is a chain of n_blocks dependent loads: 110 us for the 750 workgroups of a 24 000-nt
+// frame, four times the energy kernel itself; harmless only in the DiffTRe shape of many frames and two workgroups.)
+constexpr int kReduceCols = 16, kReduceGroups = 16;
+__global__ __launch_bounds__(kReduceCols * kReduceGroups) void reduce_partials_kernel(const double* __restrict__ part, int n_blocks,
+                                                                                  int width, double* __restrict__ out, int out_width) {
+  __shared__ double acc[kReduceGroups][kReduceCols + 1];
+  const int frame = blockIdx.x;
+  const int kk = threadIdx.x % kReduceCols, g = threadIdx.x / kReduceCols;
+  const int k = blockIdx.y * kReduceCols + kk;
+  double s = 0.0;
+  if (k < width) {
+    const double* p = part + (size_t)frame * n_blocks * width + k;
+    for (int b = g; b < n_blocks; b += kReduceGroups) s += p[(size_t)b * width];
+  }
+  acc[g][kk] = s;
+  __syncthreads();
+  if (g == 0 && k < out_width) {
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < kReduceGroups; ++j) t += acc[j][kk];
+    out[(size_t)frame * out_width + k] = t;
+  }
+}
+
+// The same sums for few workgroups per frame (the DiffTRe shape: thousands of frames, two workgroups each): one thread
+// per column, the partials added in index order - there the grouped kernel above would launch sixteen workgroups per
+// frame to add two numbers each (dU/dtheta call +2 % fp64, +7 % fp32).
+__global__ void reduce_partials_few_kernel(const double* __restrict__ part, int n_blocks, int width, double* __restrict__ out,
+                                           int out_width) {
   const int frame = blockIdx.x;
   for (int k = threadIdx.x; k < out_width; k += blockDim.x) {
     double s = 0.0;
@@ -254,6 +283,15 @@ __global__ void reduce_partials_kernel(const double* __restrict__ part, int n_bl
     }
     out[(size_t)frame * out_width + k] = s;
   }
+}
+
+static void reduce_partials_launch(const double* part, int n_frames, int n_blocks, int width, double* out, int out_width, hipStream_t stream) {
+  if (n_blocks <= kReduceGroups)
+    hipLaunchKernelGGL(reduce_partials_few_kernel, dim3(n_frames), dim3(out_width <= 64 ? 64 : 256), 0, stream, part, n_blocks, width, out,
+                       out_width);
+  else
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(n_frames, (out_width + kReduceCols - 1) / kReduceCols), dim3(kReduceCols * kReduceGroups),
+                       0, stream, part, n_blocks, width, out, out_width);
 }
 
 template <typename T>
@@ -354,11 +392,8 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
       if (int rc = observables_launch(oset, obs, c, q, nf, obs_out + (size_t)f0 * obs.width, stream)) return rc;
     }
     MYTHOS_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(64), 0, stream, sys->d_epart, blocks, (int)T_COUNT,
-                       e_terms + (size_t)f0 * T_COUNT, (int)T_COUNT);
-    if (mode >= 2)
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(nf), dim3(256), 0, stream, sys->d_pgpart, blocks,
-                         oxp_used<MODEL>(), dU_dparams + (size_t)f0 * n_out, n_out);
+    reduce_partials_launch(sys->d_epart, nf, blocks, (int)T_COUNT, e_terms + (size_t)f0 * T_COUNT, (int)T_COUNT, stream);
+    if (mode >= 2) reduce_partials_launch(sys->d_pgpart, nf, blocks, oxp_used<MODEL>(), dU_dparams + (size_t)f0 * n_out, n_out, stream);
     MYTHOS_HIP_TRY(hipGetLastError());
   }
   return 0;

@@ -192,6 +192,43 @@ def pseq_tensors(energy_fns):
     return None
 
 
+def na1_flat_and_types(energy_fns, weights, geom, kt_default=None):
+    """The three flat vectors (one tensor, oxDNA2 | oxRNA2 | hybrid) and ``is_rna`` of a composed oxNA function, plus
+    the term weights and columns: what the energy path and the simulator both hand to an oxNA system."""
+    from mythos_amd.energy import terms as _terms
+    from mythos_amd.input.topology import NucleotideType
+
+    sets = {which: {"geometry": geom.params[which]} if which in geom.params else {} for which in fp.NA1_SETS}
+    term_w, cols = [0.0] * 8, []
+    w_user = weights if weights is not None else torch.ones(len(energy_fns), dtype=torch.float64)
+    kt = salt = hce = nt_type = None
+    for fn, w in zip(energy_fns, w_user):
+        k = TERM_ORDER.index(fn.term)
+        if k in cols:
+            raise ValueError(f"term '{fn.term}' appears twice in one composed energy function")
+        for which, sec in fn.params.sections().items():
+            sets[which][fn.term] = sec
+        term_w[k] = float(w)
+        cols.append(k)
+        t = np.asarray(_np(fn.params["nt_type"]))
+        if nt_type is not None and not np.array_equal(nt_type, t):
+            raise ValueError("the terms of an oxNA energy function carry different nt_type arrays")
+        nt_type = t
+        if "kt" in fn.params and kt is None:
+            kt = fn.params["kt"]
+        if fn.term == "debye":
+            salt, hce = fn.params["salt_conc"], bool(fn.params["half_charged_ends"])
+    _terms.fill_missing_sections_na1(sets)
+    if kt is None:
+        kt = _terms.default_kt() if kt_default is None else kt_default
+    named = fp.derive_flat_na1(sets["dna"], sets["rna"], sets["drh"], kt=kt, salt_conc=0.5 if salt is None else salt,
+                               half_charged_ends=False if hce is None else hce, term_weights=term_w)
+    flat = fp.pack_flat_na1(named, _lib.param_names())
+    if nt_type.shape != (int(_np(energy_fns[0].seq).shape[0]),):
+        raise ValueError("nt_type must have one entry per nucleotide")
+    return flat, nt_type == int(NucleotideType.RNA), term_w, cols
+
+
 def _apply_pseq(entry, request) -> None:
     tag = None if request is None else (request[3], *(a.tobytes() for a in request[:3]))
     if entry["pseq"] != tag:
@@ -598,42 +635,12 @@ class ComposedEnergyFunction(EnergyFunction):
     def _evaluate_na1(self, body: RigidBody, geom):
         """oxNA (mythos/energy/na1/): every term carries three parameter sets and the types of the nucleotides; the
         kernels take three flat vectors - oxDNA2, oxRNA2, hybrid - and ``is_rna``."""
-        from mythos_amd.energy import terms as _terms
-
         first = self.energy_fns[0]
-        sets = {which: {"geometry": geom.params[which]} if which in geom.params else {} for which in fp.NA1_SETS}
-        term_w, cols = [0.0] * 8, []
-        w_user = self.weights if self.weights is not None else torch.ones(len(self.energy_fns), dtype=torch.float64)
-        kt = salt = hce = nt_type = None
-        for fn, w in zip(self.energy_fns, w_user):
-            k = TERM_ORDER.index(fn.term)
-            if k in cols:
-                raise ValueError(f"term '{fn.term}' appears twice in one composed energy function")
-            for which, sec in fn.params.sections().items():
-                sets[which][fn.term] = sec
-            term_w[k] = float(w)
-            cols.append(k)
-            t = np.asarray(_np(fn.params["nt_type"]))
-            if nt_type is not None and not np.array_equal(nt_type, t):
-                raise ValueError("the terms of an oxNA energy function carry different nt_type arrays")
-            nt_type = t
-            if "kt" in fn.params and kt is None:
-                kt = fn.params["kt"]
-            if fn.term == "debye":
-                salt, hce = fn.params["salt_conc"], bool(fn.params["half_charged_ends"])
-        _terms.fill_missing_sections_na1(sets)
-        named = fp.derive_flat_na1(sets["dna"], sets["rna"], sets["drh"], kt=_terms.default_kt() if kt is None else kt,
-                                   salt_conc=0.5 if salt is None else salt, half_charged_ends=False if hce is None else hce,
-                                   term_weights=term_w)
-        flat = fp.pack_flat_na1(named, _lib.param_names())
+        flat, is_rna, term_w, cols = na1_flat_and_types(self.energy_fns, self.weights, geom)
         center, quat = body.center, body.orientation.vec
-        if nt_type.shape != (int(_np(first.seq).shape[0]),):
-            raise ValueError("nt_type must have one entry per nucleotide")
-        from mythos_amd.input.topology import NucleotideType
-
         entry = _get_system(4, _np(first.seq), _np(first.is_end) if first.is_end is not None else None, _np(first.bonded_neighbors),
                             first.unbonded_neighbors, getattr(first.displacement_fn, "box", None), center.dtype, center.device,
-                            is_rna=nt_type == int(NucleotideType.RNA))
+                            is_rna=is_rna)
         entry["observe"] = None
         total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         return total, terms, cols

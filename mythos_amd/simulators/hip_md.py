@@ -107,13 +107,14 @@ class HipMDSimulator(Simulator):
         geom = next(fn.transform_fn for fn in ef.energy_fns if fn.transform_fn is not None)
         model = geom.model
         _terms.check_term_models(model, ef.energy_fns)
-        sections = {"geometry": geom.params}
+        is_rna = None
+        sections = {"geometry": geom.params} if model != 4 else None
         tw = [0.0] * 8
         w_user = ef.weights if ef.weights is not None else torch.ones(len(ef.energy_fns), dtype=torch.float64)
         kt_e = salt = hce = None
         from mythos_amd.energy.base import TERM_ORDER
 
-        for fn, w in zip(ef.energy_fns, w_user):
+        for fn, w in zip(ef.energy_fns if model != 4 else [], w_user):
             sections[fn.term] = {n: fn.params[n] for n in (*type(fn.params).required_params, *type(fn.params).optional_params)
                                  if n not in ("pseq", "pseq_constraints")}
             tw[TERM_ORDER.index(fn.term)] = float(w)
@@ -121,9 +122,16 @@ class HipMDSimulator(Simulator):
                 kt_e = fn.params["kt"]
             if fn.term == "debye":
                 salt, hce = fn.params["salt_conc"], bool(fn.params["half_charged_ends"])
-        _terms.fill_missing_sections(model, sections)
         sp = self.simulator_params
-        flat = fp.pack_flat(
+        if model == 4:
+            # oxNA: three flat vectors and the nucleotide types; the hybrid system is advanced by the unfused path (the
+            # energy kernel's forces + an integrator kernel per step, see mythos_amd/csrc/langevin.hip unfused_*)
+            from mythos_amd.energy.base import na1_flat_and_types
+
+            flat, is_rna, _, _ = na1_flat_and_types(ef.energy_fns, ef.weights, geom, kt_default=sp.kT)
+        else:
+            _terms.fill_missing_sections(model, sections)
+        flat = flat if model == 4 else fp.pack_flat(
             fp.derive_flat(model, sections, kt=sp.kT if kt_e is None else kt_e, salt_conc=0.5 if salt is None else salt,
                            half_charged_ends=True if hce is None else hce, term_weights=tw),
             _lib.param_names(),
@@ -142,7 +150,9 @@ class HipMDSimulator(Simulator):
             seq_a = np.tile(np.asarray(seq_a), n_rep)
             end_a = None if end_a is None else np.tile(np.asarray(end_a), n_rep)
             bonded_a = np.concatenate([bonded_2 + r * n_one for r in range(n_rep)], axis=0)
-        system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev)
+        if n_rep > 1 and is_rna is not None:
+            is_rna = np.tile(np.asarray(is_rna), n_rep)
+        system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev, is_rna=is_rna)
         system.set_params(flat.detach())
         mass, inertia = _pair(sp.mass)
         gamma_t, gamma_r = _pair(sp.gamma)

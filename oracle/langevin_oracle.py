@@ -101,8 +101,9 @@ def drift(x, q, p, L, h, mass, inertia):
 
 
 class LangevinOracle:
-    def __init__(self, model, P, top_tensors, box, dt, kT, gamma_t, gamma_r, mass=1.0, inertia=(1.0, 1.0, 1.0), seed=0):
+    def __init__(self, model, P, top_tensors, box, dt, kT, gamma_t, gamma_r, mass=1.0, inertia=(1.0, 1.0, 1.0), seed=0, is_rna=None):
         self.model, self.P, self.box = model, P, box
+        self.is_rna = None if is_rna is None else torch.as_tensor(np.asarray(is_rna, dtype=bool))  # oxNA (model 4)
         self.seq, self.is_end, self.bonded, self.unbonded = top_tensors
         self.dt, self.kT, self.mass = dt, kT, mass
         self.inertia = np.asarray(inertia, dtype=np.float64)
@@ -114,9 +115,13 @@ class LangevinOracle:
         self.step_index = 0
 
     def forces(self, x, q):
-        u, gc, gq = orc.energy_and_grads(
-            self.model, self.P, torch.as_tensor(x), torch.as_tensor(q), self.seq, self.is_end, self.bonded, self.unbonded, box=self.box
-        )
+        if self.model == 4:
+            u, gc, gq = orc.energy_and_grads_na1(self.P, torch.as_tensor(x), torch.as_tensor(q), self.seq, self.is_rna, self.is_end,
+                                                 self.bonded, self.unbonded, box=self.box)
+        else:
+            u, gc, gq = orc.energy_and_grads(
+                self.model, self.P, torch.as_tensor(x), torch.as_tensor(q), self.seq, self.is_end, self.bonded, self.unbonded, box=self.box
+            )
         tau = orc.quat_grad_to_body_torque(torch.as_tensor(q), gq)
         return float(u), -gc.numpy(), tau.numpy()
 

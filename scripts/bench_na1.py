@@ -39,3 +39,27 @@ for dtype in (torch.float32, torch.float64):
                 ts.append(time.perf_counter() - t0)
             row.append(round(1e3 * float(np.median(ts)), 3))
         print(f"{str(dtype).split('.')[-1]:8s} model {model} {name:22s} {c.shape[0]} frames x {top.n_nucleotides} nt: {row} ms", flush=True)
+
+# ---- MD of hybrid systems: the unfused path (forces launch + integrator launch per step), 1 500 replicas of the DNA-RNA
+#      golden helix = 24 000 nt in one system, Verlet list rebuilt every 10 steps
+from mythos_amd.energy import na1  # noqa: E402
+from mythos_amd.energy.base import Quaternion, RigidBody, space  # noqa: E402
+from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin  # noqa: E402
+from mythos_amd.simulators.neighbors import VerletNeighborList  # noqa: E402
+
+KT = 296.15 * 0.1 / 300.0
+top, traj, _, _ = H.load_golden_na1("simple-helix-dna-rna")
+disp, shift = space.free()
+ef = na1.create_default_energy_fn(top, disp)
+params = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(KT / 2.5, KT / 7.5), bonded_neighbors=top.bonded_neighbors,
+                               checkpoint_every=0, dt=3e-3, kT=KT)
+init = RigidBody(center=torch.as_tensor(traj.center[0], dtype=torch.float32), orientation=Quaternion(vec=torch.as_tensor(traj.quaternions[0], dtype=torch.float32)))
+for dtype in (torch.float32, torch.float64):
+    sim = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin,
+                         neighbors=VerletNeighborList(3.25, 0.6, 10), save_every=0, dtype=dtype, n_replicas=1500)
+    sim.run({}, init, 100, key=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.run({}, init, 1000, key=2)
+    torch.cuda.synchronize()
+    print(f"MD, unfused, 1500 replicas x 16 nt, {str(dtype).split('.')[-1]}: {1000 / (time.perf_counter() - t0):8.0f} steps/s", flush=True)

@@ -1,6 +1,6 @@
 """oxNA (hybrid DNA / RNA, model 4 of the C ABI) on the GPU against the oracle and the reference's seven na1 goldens
 (mythos/energy/na1/tests/test_integration.py): energies per term, forces, quaternion gradients, dU/dtheta for the three
-parameter vectors; random dimers of all four pair kinds; what the boundary refuses."""
+parameter vectors; random dimers of all four pair kinds; Langevin steps through the unfused path; what the boundary refuses."""
 
 import numpy as np
 import pytest
@@ -140,6 +140,77 @@ def test_random_dimers(bonded):
             assert np.abs(got - want).max() <= tol * (np.abs(want).max() if dtype == torch.float32 else rms), (dtype, np.abs(got - want).max(), rms)
 
 
+@pytest.mark.parametrize("name", ["simple-helix-dna-rna", "simple-coax-dna-dna-rna", "simple-helix-rna-rna"])
+def test_langevin_steps_match_the_oracle(name):
+    """A hybrid system is advanced by the unfused path (the energy kernel's forces + an integrator kernel per step,
+    langevin.hip unfused_*): six fp64 steps against LangevinOracle on the same Philox stream - positions, quaternions,
+    potential and kinetic energies of every step, final momenta; then the same trajectory in two advances."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle.langevin_oracle import LangevinOracle
+
+    top, traj, _, is_rna = H.load_golden_na1(name)
+    kT = 296.15 * 0.1 / 300.0
+    gam_t, gam_r, seed = kT / 2.5, kT / 7.5, 0xBADC0FFEE
+    s = _system(top, is_rna, traj.box_size, torch.float64)
+    integ = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    c = torch.as_tensor(traj.center[2], device=s.device).contiguous()
+    q = torch.as_tensor(traj.quaternions[2], device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    start = [t.clone() for t in (c, q, p, L)]
+    tc, tq, et = integ.run(c, q, p, L, 6, save_every=1)
+    lo = LangevinOracle(4, H.oracle_params_na1(), H.topo_tensors(top), traj.box_size, 0.003, kT, gam_t, gam_r, 1.0, (1.0, 1.2, 0.9),
+                        seed=seed, is_rna=is_rna)
+    for k in range(6):
+        x, qq, pp, LL, u = lo.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-10)
+        assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
+        ke_t, ke_r = lo.kinetic(pp, LL)
+        assert abs(et[k, 8].item() - ke_t) < 1e-9 * ke_t and abs(et[k, 9].item() - ke_r) < 1e-9 * ke_r
+    np.testing.assert_allclose(p.cpu().numpy(), pp, atol=1e-9)
+    np.testing.assert_allclose(L.cpu().numpy(), LL, atol=1e-9)
+    assert integ.step == 6
+    # resident: load; advance(2); advance(4); store == run(6), bit for bit (one force evaluation per step either way)
+    integ2 = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    c2, q2, p2, L2 = [t.clone() for t in start]
+    integ2.load(c2, q2, p2, L2)
+    integ2.advance(2)
+    integ2.advance(4)
+    integ2.store(c2, q2, p2, L2)
+    assert torch.equal(c2, c) and torch.equal(q2, q) and torch.equal(p2, p) and torch.equal(L2, L)
+
+
+def test_simulator_runs_a_hybrid_duplex_with_a_dynamic_list():
+    """HipMDSimulator on the DNA-RNA golden helix, fp32, Verlet list rebuilt every 10 steps: finite, the helix holds, the
+    mean potential energy stays where oxDNA's own run (interaction_type = NA) has it; and the static all-pairs list gives
+    the same trajectory while no pair crosses the list range."""
+    from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList, VerletNeighborList
+
+    top, traj, split, _ = H.load_golden_na1("simple-helix-dna-rna")
+    disp, shift = space.periodic(20.0)
+    ef = na1.create_default_energy_fn(top, disp)
+    sp = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(KT / 2.5, KT / 7.5), bonded_neighbors=top.bonded_neighbors,
+                               checkpoint_every=0, dt=0.003, kT=KT)
+    init = _states(traj, torch.float32)[0]
+    outs = []
+    for nb in (VerletNeighborList(3.25, 0.6, 10), NoNeighborList(unbonded_nbrs=top.unbonded_neighbors)):
+        sim = HipMDSimulator(energy_fn=ef, simulator_params=sp, space=(disp, shift), simulator_init=nvt_langevin, neighbors=nb,
+                             save_every=50, dtype=torch.float32)
+        outs.append(sim.run({}, init, 3000, key=5).observables[0])
+    tr = outs[0]
+    assert tr.center.shape == (60, top.n_nucleotides, 3) and torch.isfinite(tr.center).all()
+    # 16 nucleotides, every pair inside the list range at all times: the two lists hold the same pairs, the sums differ in order only
+    assert (outs[0].center[:5] - outs[1].center[:5]).abs().max().item() < 1e-3
+    states = RigidBody(center=tr.center.double(), orientation=Quaternion(vec=tr.orientation.vec.double()))
+    u = ef.map(states).cpu().numpy() / top.n_nucleotides
+    u_gold = split[:, 1:9].sum(1)
+    assert abs(u[15:].mean() - u_gold.mean()) < 4.0 * u_gold.std() + 0.02, (u[15:].mean(), u_gold.mean(), u_gold.std())
+    hb = ef.compute_terms(states)[:, 4].cpu().numpy() / top.n_nucleotides
+    assert hb[15:].mean() < -0.15  # the hybrid duplex stays hybridised (golden: about -0.3)
+
+
 def test_what_the_boundary_refuses():
     from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
 
@@ -150,8 +221,6 @@ def test_what_the_boundary_refuses():
     with pytest.raises(ValueError, match="expected 783"):  # one vector where three are needed
         s.set_params(_flat()[: len(_lib.param_names())])
     s.set_params(_flat())
-    with pytest.raises(_lib.MythosHipError, match="energy entry points only"):
-        LangevinIntegrator(s, dt=0.003, kT=0.1, gamma_t=1.0, gamma_r=1.0)
     with pytest.raises(ValueError, match="not available for oxNA"):
         s.set_pseq(np.full((top.n_nucleotides, 4), 0.25), np.full(top.n_nucleotides, -1), np.zeros((0, 4)), terms=3)
     other = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
