@@ -17,16 +17,17 @@ bp = int(sys.argv[1]) if len(sys.argv) > 1 else 12000
 n_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
 skin = float(sys.argv[3]) if len(sys.argv) > 3 else 0.6
 every = int(sys.argv[4]) if len(sys.argv) > 4 else 25
+dtype = torch.float64 if (len(sys.argv) > 5 and sys.argv[5] == "f64") else torch.float32
 sim, cfg = defaults.default_configs_for("dna2")
 kT = sim["kT"]
 top, c0, q0 = generators.ideal_duplex(bp, model=2, seed=1234)
 flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=0.5, half_charged_ends=True), _lib.param_names())
-s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=torch.float32)
+s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype)
 s.set_params(flat)
 integ = LangevinIntegrator(s, dt=0.005, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5, seed=1)
 integ.set_neighbor_policy(3.25, skin, every)
-c = torch.as_tensor(c0, dtype=torch.float32, device=s.device).contiguous()
-q = torch.as_tensor(q0, dtype=torch.float32, device=s.device).contiguous()
+c = torch.as_tensor(c0, dtype=dtype, device=s.device).contiguous()
+q = torch.as_tensor(q0, dtype=dtype, device=s.device).contiguous()
 p, L = integ.init_momenta()
 n = top.n_nucleotides
 for blk in range(n_steps // 2000):
