@@ -14,14 +14,14 @@ from mythos_amd import _lib  # noqa: E402
 from mythos_amd.energy import flat_params as fp  # noqa: E402
 from mythos_amd.hip_system import OxdnaSystem  # noqa: E402
 from mythos_amd.input import defaults  # noqa: E402
-from tests import helpers as H  # noqa: E402  (golden loader only)
+from scripts import _golden  # noqa: E402
 
 sim, cfg = defaults.default_configs_for("na1")
 flat4 = fp.pack_flat_na1(fp.derive_flat_na1(cfg["dna"], cfg["rna"], cfg["drh"], kt=sim["kT"], salt_conc=0.5, half_charged_ends=False), _lib.param_names())
 flat2 = fp.pack_flat(fp.derive_flat(2, cfg["dna"], kt=sim["kT"], salt_conc=0.5, half_charged_ends=False), _lib.param_names())
 for dtype in (torch.float32, torch.float64):
     for name, model in (("simple-helix-dna-dna", 2), ("simple-helix-dna-dna", 4), ("simple-helix-rna-rna", 4), ("simple-helix-dna-rna", 4)):
-        top, traj, _, is_rna = H.load_golden_na1(name)
+        top, traj, is_rna = _golden.load("na1", name, new_format=True)
         s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=dtype, is_rna=is_rna if model == 4 else None)
         s.set_params(flat4 if model == 4 else flat2)
         s.set_neighbors(top.unbonded_neighbors)
@@ -48,7 +48,7 @@ from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, 
 from mythos_amd.simulators.neighbors import VerletNeighborList  # noqa: E402
 
 KT = 296.15 * 0.1 / 300.0
-top, traj, _, _ = H.load_golden_na1("simple-helix-dna-rna")
+top, traj, _ = _golden.load("na1", "simple-helix-dna-rna", new_format=True)
 disp, shift = space.free()
 ef = na1.create_default_energy_fn(top, disp)
 params = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(KT / 2.5, KT / 7.5), bonded_neighbors=top.bonded_neighbors,

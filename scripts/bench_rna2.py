@@ -12,14 +12,14 @@ from mythos_amd.energy import dna2, rna2  # noqa: E402
 from mythos_amd.energy.base import Quaternion, RigidBody, space  # noqa: E402
 from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin  # noqa: E402
 from mythos_amd.simulators.neighbors import VerletNeighborList  # noqa: E402
-from tests import helpers as H  # noqa: E402  (golden loader only)
+from scripts import _golden  # noqa: E402
 
 KT = 296.15 * 0.1 / 300.0
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 24000
 disp, shift = space.free()
 for model, mod, name in ((3, rna2, "simple-helix-12bp"), (2, dna2, "simple-helix")):
-    top, traj, _, _ = H.load_golden(model, name)
+    top, traj, _ = _golden.load({2: "dna2", 3: "rna2"}[model], name)
     reps = total // top.n_nucleotides
     ef = mod.create_default_energy_fn(top, disp)
     params = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(KT / 2.5, KT / 7.5),

@@ -11,11 +11,11 @@ from mythos_amd.energy import na1  # noqa: E402
 from mythos_amd.energy.base import Quaternion, RigidBody, space  # noqa: E402
 from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin  # noqa: E402
 from mythos_amd.simulators.neighbors import VerletNeighborList  # noqa: E402
-from tests import helpers as H  # noqa: E402
+from scripts import _golden  # noqa: E402
 
 KT = 296.15 * 0.1 / 300.0
 every = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-top, traj, _, _ = H.load_golden_na1("simple-helix-dna-rna")
+top, traj, _ = _golden.load("na1", "simple-helix-dna-rna", new_format=True)
 disp, shift = space.free()
 ef = na1.create_default_energy_fn(top, disp)
 params = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(KT / 2.5, KT / 7.5), bonded_neighbors=top.bonded_neighbors,

@@ -160,6 +160,12 @@ def test_gradient_with_respect_to_the_distribution(model):
     # no gradient asked for the distribution: the ordinary entry point serves the call, same energies
     u_plain = ef.with_params(pseq=(up0, bp0), pseq_constraints=sc).map(st)
     assert torch.equal(u_plain, u_h.detach())
+    # fp32 frames: the same gradients to fp32 accuracy (the accumulators are fp64 either way)
+    up_s, bp_s = (torch.tensor(a, requires_grad=True) for a in (up0, bp0))
+    u_s = ef.with_params(pseq=(up_s, bp_s), pseq_constraints=sc).map(_states(traj, frames, torch.float32))
+    g_s = torch.autograd.grad((u_s * coef.to(u_s.dtype)).sum(), [up_s, bp_s])
+    for a, b in zip(g_s, g_o[:2]):
+        assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * b.abs().max().item()
 
 
 def test_dynamics_refuse_a_sequence_distribution():
