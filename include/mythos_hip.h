@@ -78,9 +78,8 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
  *             forms - and every nucleotide the sites of its own type.  Such a system needs
  *             mythos_oxdna_set_nucleotide_types, takes 3 x mythos_oxdna_param_count() parameters (the oxDNA2, oxRNA2 and
  *             hybrid vectors one after the other; dU_dparams rows have the same layout).  No structural observables and no
- *             probabilistic sequence for it; the Langevin integrator advances it by an UNFUSED path - the energy kernel's
- *             forces launch and an integrator launch per step, no halt-and-resume (a site that leaves its skin between
- *             two scheduled rebuilds is MYTHOS_ERR_OVERFLOW) - about a third of the fused kernel's rate.
+ *             probabilistic sequence for it.  The Langevin integrator has an oxNA instantiation of its fused step kernel
+ *             (about half the oxDNA2 rate: a parameter set is chosen per row entry).
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
  *   bonded    host int32[n_bonded][2] rows (nn_i, nn_j) as mythos/input/topology.py:166-183

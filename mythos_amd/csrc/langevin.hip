@@ -252,6 +252,74 @@ constexpr int md_blocks_per_cu() {
   return sizeof(R) == 4 ? (SAVE ? MYTHOS_MD_F32S_BLOCKS : MYTHOS_MD_F32_BLOCKS) : (SAVE ? MYTHOS_MD_F64S_BLOCKS : (DENSE ? MYTHOS_MD_F64_BLOCKS : 2));
 }
 
+// What the radial pass reads of the parameters, gathered so that the oxNA instantiation (MODEL 4) can hold one set per
+// kind of pair - DNA-DNA, RNA-RNA, hybrid - and choose per row entry; every other instantiation has ONE set, built from
+// the values it always used (scalar registers; the compiler sees the same operands as before).
+template <typename R>
+struct RadSet {
+  F3P<R> f_bb, f_base, f_bkba, f_babk;
+  R eps_n, tw_n, tw_dh;
+  DebyeP<R> dhp;
+  bool half_ends;
+  R rbb2, hb_lo2, hb_hi2, cr_lo2, cr_hi2, cx_lo2, cx_hi2;
+  unsigned int hb_mask;
+};
+template <typename R, int MODEL, class PT>
+__device__ __forceinline__ RadSet<R> radset_from(const PT& P, const MdCut<R>& cut) {
+  RadSet<R> s;
+  s.f_bb = f3_params<R>(P, NEXC_BACKBONE_RSTAR), s.f_base = f3_params<R>(P, NEXC_BASE_RSTAR);
+  s.f_bkba = f3_params<R>(P, NEXC_BACK_BASE_RSTAR), s.f_babk = f3_params<R>(P, NEXC_BASE_BACK_RSTAR);
+  s.eps_n = P[NEXC_EPS];
+  s.tw_n = P[TW_NEXC], s.tw_dh = (MODEL >= 2) ? P[TW_DH] : R(0);
+  s.half_ends = (MODEL >= 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
+  s.dhp = (MODEL >= 2) ? debye_params<R>(P) : DebyeP<R>{};
+  s.rbb2 = cut.rbb2, s.hb_lo2 = cut.hb_lo2, s.hb_hi2 = cut.hb_hi2, s.cr_lo2 = cut.cr_lo2, s.cr_hi2 = cut.cr_hi2;
+  s.cx_lo2 = cut.cx_lo2, s.cx_hi2 = cut.cx_hi2, s.hb_mask = cut.hb_mask;
+  return s;
+}
+// oxNA: the supports of one parameter vector, derived on the device (scalar arithmetic, once per workgroup) the way
+// make_cut derives them on the host for the single-vector models
+template <typename R, class PT>
+__device__ __forceinline__ MdCut<R> cut_from(const PT& P, R rcom2) {
+  MdCut<R> c;
+  const R rbb = fmax(P[NEXC_BACKBONE_RC], P[DH_RCUT]);
+  c.rbb2 = rbb * rbb, c.rcom2 = rcom2;
+  c.hb_lo2 = P[HYDR_RCLOW] * P[HYDR_RCLOW], c.hb_hi2 = P[HYDR_RCHIGH] * P[HYDR_RCHIGH];
+  c.cr_lo2 = P[CRST_RCLOW] * P[CRST_RCLOW], c.cr_hi2 = P[CRST_RCHIGH] * P[CRST_RCHIGH];
+  c.cx_lo2 = P[CXST_RCLOW] * P[CXST_RCLOW], c.cx_hi2 = P[CXST_RCHIGH] * P[CXST_RCHIGH];
+  c.hb_mask = 0u;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) c.hb_mask |= (P[HYDR_EPS_00 + k] != R(0)) ? (1u << k) : 0u;
+  return c;
+}
+template <typename R>
+__device__ __forceinline__ F3P<R> pick3(const F3P<R>& a, const F3P<R>& b, const F3P<R>& c, int k) {
+  return {k == 0 ? a.rstar : (k == 1 ? b.rstar : c.rstar), k == 0 ? a.sigma : (k == 1 ? b.sigma : c.sigma),
+          k == 0 ? a.b : (k == 1 ? b.b : c.b), k == 0 ? a.rc : (k == 1 ? b.rc : c.rc), a.base};
+}
+#define MD_PICK3(f) (k == 0 ? a.f : (k == 1 ? b.f : c.f))
+template <typename R>
+__device__ __forceinline__ RadSet<R> pick3(const RadSet<R>& a, const RadSet<R>& b, const RadSet<R>& c, int k) {
+  RadSet<R> s;
+  s.f_bb = pick3(a.f_bb, b.f_bb, c.f_bb, k), s.f_base = pick3(a.f_base, b.f_base, c.f_base, k);
+  s.f_bkba = pick3(a.f_bkba, b.f_bkba, c.f_bkba, k), s.f_babk = pick3(a.f_babk, b.f_babk, c.f_babk, k);
+  s.eps_n = MD_PICK3(eps_n), s.tw_n = MD_PICK3(tw_n), s.tw_dh = MD_PICK3(tw_dh);
+  s.dhp = {MD_PICK3(dhp.rcut), MD_PICK3(dhp.rhigh), MD_PICK3(dhp.kappa), MD_PICK3(dhp.prefactor), MD_PICK3(dhp.bsmooth)};
+  s.half_ends = a.half_ends;  // one switch for the whole system (na1/debye.py:25)
+  s.rbb2 = MD_PICK3(rbb2), s.hb_lo2 = MD_PICK3(hb_lo2), s.hb_hi2 = MD_PICK3(hb_hi2), s.cr_lo2 = MD_PICK3(cr_lo2);
+  s.cr_hi2 = MD_PICK3(cr_hi2), s.cx_lo2 = MD_PICK3(cx_lo2), s.cx_hi2 = MD_PICK3(cx_hi2), s.hb_mask = MD_PICK3(hb_mask);
+  return s;
+}
+#undef MD_PICK3
+
+// the parameter set of the row entry being evaluated: the one set of the model, or (oxNA) the set of the pair's kind -
+// 0 DNA-DNA, 1 RNA-RNA, 2 hybrid - from the type bits of the two meta words
+#define MD_RADSET_OF_ENTRY                                                                                         \
+  const int md_kind = (MODEL == 4) ? na1_kind(self.rna, ((int)o0.w >> 3) & 1) : 0;                                 \
+  const RadSet<R> rs_picked = (MODEL == 4) ? pick3(rs0, rs1, rs2, md_kind) : rs0;                                  \
+  const RadSet<R>& rs = (MODEL == 4) ? rs_picked : rs0;
+__device__ __forceinline__ int na1_kind(int self_rna, int other_rna) { return (self_rna && other_rna) ? 1 : ((self_rna || other_rna) ? 2 : 0); }
+
 // ITEMS: result rows per nucleotide for the angular work lists.  16 is enough for any duplex, junction or origami
 // at physical density (a base has 3 - 5 partners inside the range of an angular term); a nucleotide with more makes
 // the launch ABORT: it raises flags[3], the host discards what that launch wrote (its inputs are intact: frames and
@@ -327,6 +395,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
   const int ii = valid ? i : n - 1;  // out-of-range groups shadow the last nucleotide and discard
 
   const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK];
+  // oxNA: the oxRNA2 vector (sites of an RNA nucleotide) and the hybrid one; P itself is the oxDNA2 vector there
+  const ConstParams<R> Prna(Pg + ((MODEL == 4) ? OXP_COUNT : 0)), Pdrh(Pg + ((MODEL == 4) ? 2 * OXP_COUNT : 0));
+  const Na1Params<ConstParams<R>> P4{P, Prna, Pdrh};
 
   // ---- owner state (also parked in LDS for the block-wide angular pass)
   Nuc<R> self;
@@ -342,6 +413,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
     const int m = (int)s0.w;
     self.seq = m & 3;
     self.is_end = (m >> 2) & 1;
+    self.rna = (m >> 3) & 1;
     if (lane == 0) {
       R* sl = self_lds[grp];
       sl[0] = s0.x, sl[1] = s0.y, sl[2] = s0.z, sl[3] = s1.x, sl[4] = s1.y, sl[5] = s1.z;
@@ -360,12 +432,10 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
 
   MD_STAMP(0);
   // ---- phase 1: radial pass over the unbonded slots
-  const F3P<R> f_bb = f3_params<R>(P, NEXC_BACKBONE_RSTAR), f_base = f3_params<R>(P, NEXC_BASE_RSTAR);
-  const F3P<R> f_bkba = f3_params<R>(P, NEXC_BACK_BASE_RSTAR), f_babk = f3_params<R>(P, NEXC_BASE_BACK_RSTAR);
-  const R eps_n = P[NEXC_EPS];
-  const R tw_n = P[TW_NEXC], tw_dh = (MODEL >= 2) ? P[TW_DH] : R(0);
-  const bool half_ends = (MODEL >= 2) && (P[DH_HALF_CHARGED_ENDS] != R(0));
-  const DebyeP<R> dhp = (MODEL >= 2) ? debye_params<R>(P) : DebyeP<R>{};
+  const RadSet<R> rs0 = (MODEL == 4) ? radset_from<R, 2>(P, cut_from<R>(P, cut.rcom2)) : radset_from<R, MODEL>(P, cut);
+  // (oxNA: the oxRNA2 and the hybrid vector follow the oxDNA2 one; the other models never read rs1 / rs2)
+  const RadSet<R> rs1 = (MODEL == 4) ? radset_from<R, 2>(ConstParams<R>(Pg + OXP_COUNT), cut_from<R>(ConstParams<R>(Pg + OXP_COUNT), cut.rcom2)) : rs0;
+  const RadSet<R> rs2 = (MODEL == 4) ? radset_from<R, 2>(ConstParams<R>(Pg + 2 * OXP_COUNT), cut_from<R>(ConstParams<R>(Pg + 2 * OXP_COUNT), cut.rcom2)) : rs0;
   int n_items[2] = {0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
@@ -406,6 +476,11 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
       bool flag[2] = {false, false};
       if (entry >= 0) {
         const bool role_p = (entry & ROW_ROLE_Q) == 0;
+        MD_RADSET_OF_ENTRY
+        const bool o_rna = (MODEL == 4) && ((((int)o0.w) >> 3) & 1);
+        const R gba_s = (MODEL == 4 && self.rna) ? Prna[GEO_BASE] : g_ba, gba_o = o_rna ? Prna[GEO_BASE] : g_ba;
+        const R gst_s = (MODEL == 4 && self.rna) ? Prna[GEO_STACK] : g_st, gst_o = o_rna ? Prna[GEO_STACK] : g_st;
+        (void)gst_s, (void)gst_o;
         const V3<R> dco = min_image(centre_diff<R>(o0, ol, self.c, self_lo), box);
         const V3<R> offb_o = xyz<R>(o3);
         const bool close = dot(dco, dco) < cut.rcom2;
@@ -413,19 +488,19 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         {
           const V3<R> d = dco + offb_o - offb_s;
           const R r2 = dot(d, d);
-          if (r2 < cut.rbb2) {
+          if (r2 < rs.rbb2) {
             const R r = m_sqrt(r2);
-            const FD<R> v = f3_eval(r, eps_n, f_bb);
-            R dVdr = tw_n * v.d;
+            const FD<R> v = f3_eval(r, rs.eps_n, rs.f_bb);
+            R dVdr = rs.tw_n * v.d;
             R en = v.f;
             if constexpr (MODEL >= 2) {
-              const FD<R> dh = debye_eval(r, dhp);
+              const FD<R> dh = debye_eval(r, rs.dhp);
               R mult = R(1);
-              if (half_ends) {
+              if (rs.half_ends) {
                 const int mo = (int)o0.w;
                 mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
               }
-              dVdr += tw_dh * mult * dh.d;
+              dVdr += rs.tw_dh * mult * dh.d;
               if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
             }
             if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
@@ -440,33 +515,43 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
           // role so both parameter blocks stay scalar operands
           {
             V3<R> dA = dco - offb_s;
-            axpy(dA, g_ba, a1o);
+            axpy(dA, gba_o, a1o);
             V3<R> dB = dco + offb_o;
-            axpy(dB, -g_ba, self.a1);
+            axpy(dB, -gba_s, self.a1);
             const R ra2 = dot(dA, dA), rb2 = dot(dB, dB);
             R c1, c2;
-            en += f3_coef(eps_n, tw_n, f_bkba, role_p ? ra2 : rb2, c1);
-            en += f3_coef(eps_n, tw_n, f_babk, role_p ? rb2 : ra2, c2);
+            en += f3_coef(rs.eps_n, rs.tw_n, rs.f_bkba, role_p ? ra2 : rb2, c1);
+            en += f3_coef(rs.eps_n, rs.tw_n, rs.f_babk, role_p ? rb2 : ra2, c2);
             axpy(gbk, role_p ? c1 : c2, dA);
             axpy(gba, role_p ? c2 : c1, dB);
           }
           const V3<R> da = a1o - self.a1;
           {
             V3<R> d = dco;
-            axpy(d, g_ba, da);
+            if constexpr (MODEL == 4) {  // each nucleotide's base site at the offset of its own type
+              axpy(d, gba_o, a1o);
+              axpy(d, -gba_s, self.a1);
+            } else {
+              axpy(d, g_ba, da);
+            }
             const R r2 = dot(d, d);
-            en += f3_radial(eps_n, tw_n, f_base, d, r2, gba);
-            flag[0] = cut.cr_lo2 < r2 && r2 < cut.cr_hi2;
-            if (!flag[0] && cut.hb_lo2 < r2 && r2 < cut.hb_hi2) {  // H-bond only for pairs with a non-zero weight
+            en += f3_radial(rs.eps_n, rs.tw_n, rs.f_base, d, r2, gba);
+            flag[0] = rs.cr_lo2 < r2 && r2 < rs.cr_hi2;
+            if (!flag[0] && rs.hb_lo2 < r2 && r2 < rs.hb_hi2) {  // H-bond only for pairs with a non-zero weight
               const int so = (int)o0.w & 3;
-              flag[0] = (cut.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
+              flag[0] = (rs.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
             }
           }
           {
             V3<R> d = dco;
-            axpy(d, g_st, da);
+            if constexpr (MODEL == 4) {
+              axpy(d, gst_o, a1o);
+              axpy(d, -gst_s, self.a1);
+            } else {
+              axpy(d, g_st, da);
+            }
             const R r2 = dot(d, d);
-            flag[1] = cut.cx_lo2 < r2 && r2 < cut.cx_hi2;
+            flag[1] = rs.cx_lo2 < r2 && r2 < rs.cx_hi2;
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
         }
@@ -513,21 +598,22 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         if constexpr (kHiLo<R>) nl = in.pl[jn];
       }
       if (entry >= 0) {
+        MD_RADSET_OF_ENTRY
         const V3<R> dco = min_image(centre_diff<R>(o0, ol, self.c, self_lo), box);
         const V3<R> d = dco + xyz<R>(o3) - offb_s;
         const R r2 = dot(d, d);
-        if (r2 < cut.rbb2) {
+        if (r2 < rs.rbb2) {
           const R r = m_sqrt(r2);
-          const FD<R> v = f3_eval(r, eps_n, f_bb);
-          R dVdr = tw_n * v.d;
+          const FD<R> v = f3_eval(r, rs.eps_n, rs.f_bb);
+          R dVdr = rs.tw_n * v.d;
           if constexpr (MODEL >= 2) {
-            const FD<R> dh = debye_eval(r, dhp);
+            const FD<R> dh = debye_eval(r, rs.dhp);
             R mult = R(1);
-            if (half_ends) {
+            if (rs.half_ends) {
               const int mo = (int)o0.w;
               mult = (self.is_end ? R(0.5) : R(1)) * (((mo >> 2) & 1) ? R(0.5) : R(1));
             }
-            dVdr += tw_dh * mult * dh.d;
+            dVdr += rs.tw_dh * mult * dh.d;
             if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * v.f;
@@ -651,6 +737,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         const int mm = (int)ms[9];
         me.seq = mm & 3;
         me.is_end = (mm >> 2) & 1;
+        me.rna = (mm >> 3) & 1;
         const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
         V4 ol{};
         if constexpr (kHiLo<R>) ol = in.pl[j];
@@ -661,16 +748,21 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         const int mo = (int)o0.w;
         o.seq = mo & 3;
         o.is_end = (mo >> 2) & 1;
+        o.rna = (mo >> 3) & 1;
         const V3<R> dco = min_image(centre_diff<R>(o0, ol, me.c, V3<R>{ms[10], ms[11], ms[12]}), box);
+        // (oxNA: the pair templates pick vector, form and sites by the kind of the pair from the three vectors)
+        const auto& PP = [&]() -> const auto& {
+          if constexpr (MODEL == 4) return P4; else return P;
+        }();
         if (wave == 0) {
-          bonded_pair<R, MODEL, true, NoPG>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          bonded_pair<R, MODEL, true, NoPG>(PP, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else if (wave != 3) {
 #ifdef MYTHOS_MD_EXP_HALF_ITEMS  // (dev experiment, WRONG physics: the step's cost if ONE wavefront's sweep covered the base-pair list)
           if (wave == 1)
 #endif
-          unbonded_angular<R, MODEL, true, NoPG, 3>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          unbonded_angular<R, MODEL, true, NoPG, 3>(PP, me, o, dco, role_p, R(0.5), ee, g, pg);
         } else {
-          unbonded_angular<R, MODEL, true, NoPG, 4>(P, me, o, dco, role_p, R(0.5), ee, g, pg);
+          unbonded_angular<R, MODEL, true, NoPG, 4>(PP, me, o, dco, role_p, R(0.5), ee, g, pg);
         }
       }
       out_r[0] = g.dc.x, out_r[1] = g.dc.y, out_r[2] = g.dc.z;
@@ -734,10 +826,18 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
     const R* rl = rad_lds[grp];
     const V3<R> rbk{rl[0], rl[1], rl[2]}, rba{rl[3], rl[4], rl[5]};
     sg.dc = sg.dc - (rbk + rba);
+    if constexpr (MODEL == 4) {  // the sites of this nucleotide's own type
+      const bool r = self.rna != 0;
+      axpy(sg.g1, -(r ? Prna[GEO_BACK_A1] : P[GEO_BACK_A1]), rbk);
+      axpy(sg.g1, -(r ? Prna[GEO_BASE] : P[GEO_BASE]), rba);
+      axpy(sg.g2, r ? R(0) : -P[GEO_BACK_A2], rbk);
+      axpy(sg.g3, r ? -Prna[GEO_BACK_A2] : R(0), rbk);
+    } else {
     axpy(sg.g1, -P[GEO_BACK_A1], rbk);
     axpy(sg.g1, -P[GEO_BASE], rba);
     if constexpr (MODEL == 2) axpy(sg.g2, -P[GEO_BACK_A2], rbk);
     if constexpr (MODEL == 3) axpy(sg.g3, -P[GEO_BACK_A2], rbk);  // oxRNA2: the backbone site's second axis is a3
+    }
   }
   if constexpr (SAVE) {
     group_reduce<G, R, true>(e, sg);
@@ -779,8 +879,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
       sg.g2 = V3<R>{fr[6], fr[7], fr[8]};
       sg.g3 = V3<R>{fr[9], fr[10], fr[11]};
     }
-    const R g_k1 = P[GEO_BACK_A1];
-    const R g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
+    const bool int_rna = (MODEL == 4) && ((((int)self_lds[il][9]) >> 3) & 1);  // oxNA: this nucleotide's own geometry
+    const R g_k1 = int_rna ? Prna[GEO_BACK_A1] : P[GEO_BACK_A1];
+    const R g_k2 = (MODEL >= 2) ? (int_rna ? Prna[GEO_BACK_A2] : P[GEO_BACK_A2]) : R(0);
     const V3<R> F = -sg.dc;
     const V3<R> tl = axes_grad_to_torque(self, sg);
     const R tb[3] = {dot(self.a1, tl), dot(self.a2, tl), dot(self.a3, tl)};
@@ -814,7 +915,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
     R dxa[3] = {R(0), R(0), R(0)};                                      // this step's displacement
     R* const xd = kHiLo<R> ? dxa : x;
     V3<R> n1 = self.a1, n2 = self.a2, n3 = self.a3;
-    V3<R> nbk = (MODEL == 3) ? n3 : n2;  // second axis of the backbone site (a2; a3 in oxRNA2)
+    V3<R> nbk = (MODEL == 3 || int_rna) ? n3 : n2;  // second axis of the backbone site (a2; a3 in oxRNA2)
     if (do_step && !(ablate & 4)) {
       p[0] += K.half_dt * F.x;
       p[1] += K.half_dt * F.y;
@@ -849,7 +950,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
       qs[3] *= inv;
       if (!(x[0] == x[0]) || !(qs[0] == qs[0])) atomicOr(flags, 2);
       quat_axes(qs[0], qs[1], qs[2], qs[3], n1, n2, n3);
-      nbk = (MODEL == 3) ? n3 : n2;
+      nbk = (MODEL == 3 || int_rna) ? n3 : n2;
       if (K.skin_half_sq > R(0)) {
         // the list is valid while neither the centre nor the backbone and base sites (the segments are selected
         // by site distances, and a rotation moves the sites) have travelled more than skin / 2 since the build
@@ -857,7 +958,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         const R bx = dx + (g_k1 * n1.x + g_k2 * nbk.x - f0.x), by = dy + (g_k1 * n1.y + g_k2 * nbk.y - f0.y),
                 bz = dz + (g_k1 * n1.z + g_k2 * nbk.z - f0.z);
         // base site c + g_base a1 (the stacking site lies between it and the centre)
-        const R gb = P[GEO_BASE];
+        const R gb = int_rna ? Prna[GEO_BASE] : P[GEO_BASE];
         const R sx = dx + gb * (n1.x - a0.x), sy = dy + gb * (n1.y - a0.y), sz = dz + gb * (n1.z - a0.z);
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq || bx * bx + by * by + bz * bz > K.skin_half_sq ||
             sx * sx + sy * sy + sz * sz > K.skin_half_sq)
@@ -913,8 +1014,10 @@ __global__ __launch_bounds__(256) void reduce_trace_kernel(const double* __restr
 }
 
 // ------------------------------------------------------------------ packed (N,3)/(N,4) <-> frame
+// BX: the axis of the second backbone coefficient (2: a2, 3: a3), or 0 = by the nucleotide's type (oxNA: g_* for DNA on
+// a1 / a2, r_* for RNA on a1 / a3)
 template <typename R, int BX>
-__global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c, const R* __restrict__ q,
+__global__ void pack_state_kernel(int n, R g_k1, R g_k2, R r_k1, R r_k2, const R* __restrict__ c, const R* __restrict__ q,
                                   const R* __restrict__ p, const R* __restrict__ l, const int* __restrict__ meta,
                                   const Frame<R> f, const R* __restrict__ keep_hi, const R* __restrict__ keep_lo) {
   using V4 = typename Vec4T<R>::type;
@@ -940,8 +1043,10 @@ __global__ void pack_state_kernel(int n, R g_k1, R g_k2, const R* __restrict__ c
   f.p0[i] = V4{c[3 * i], c[3 * i + 1], c[3 * i + 2], R(meta[i])};
   f.p1[i] = V4{a1.x, a1.y, a1.z, R(0)};
   f.p2[i] = V4{a3.x, a3.y, a3.z, R(0)};
-  const V3<R> ab = BX == 3 ? a3 : a2;  // second axis of the backbone site
-  f.p3[i] = V4{g_k1 * a1.x + g_k2 * ab.x, g_k1 * a1.y + g_k2 * ab.y, g_k1 * a1.z + g_k2 * ab.z, R(0)};
+  const bool rna = BX == 0 && ((meta[i] >> 3) & 1);
+  const V3<R> ab = (BX == 3 || rna) ? a3 : a2;  // second axis of the backbone site
+  const R k1 = rna ? r_k1 : g_k1, k2 = rna ? r_k2 : g_k2;
+  f.p3[i] = V4{k1 * a1.x + k2 * ab.x, k1 * a1.y + k2 * ab.y, k1 * a1.z + k2 * ab.z, R(0)};
   f.q[i] = V4{q0, q1, q2, q3};
   f.mom[i] = V4{p[3 * i], p[3 * i + 1], p[3 * i + 2], R(0)};
   f.ang[i] = V4{l[3 * i], l[3 * i + 1], l[3 * i + 2], R(0)};
@@ -1079,8 +1184,9 @@ static LangevinConst<R> make_const(const mythos_sim* s) {
 template <typename R>
 static MdCut<R> make_cut(const mythos_system* sys) {
   const OxParams<double>& P = sys->pd;
-  double rbb = P[NEXC_BACKBONE_RC];
-  if (sys->model >= 2) rbb = std::max(rbb, (double)P[DH_RCUT]);
+  // (oxNA: rbb2 and rcom2 - the coarse tests - cover all three vectors; the kernel derives the supports of each vector itself)
+  double rbb = oxdna_param_max(sys, NEXC_BACKBONE_RC);
+  if (sys->model >= 2) rbb = std::max(rbb, oxdna_param_max(sys, DH_RCUT));
   const double rcom = oxdna_close_range(sys);
   MdCut<R> c;
   c.rbb2 = R(rbb * rbb);
@@ -1125,7 +1231,10 @@ static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* 
   const R g_k1 = P[GEO_BACK_A1], g_k2 = (MODEL >= 2) ? P[GEO_BACK_A2] : R(0);
   sim->cur = 0;
   const Frame<R> f0 = frame_of<R>(sim, 0);
-  hipLaunchKernelGGL((pack_state_kernel<R, back_axis<MODEL>()>), dim3(tb), dim3(256), 0, st, n, g_k1, g_k2, center, quat, p_lin, p_ang,
+  // (oxNA: the RNA nucleotides take the oxRNA2 vector's backbone site)
+  const double* Prna = oxdna_param_set(sys, sys->param_sets() == 1 ? 0 : 1);
+  hipLaunchKernelGGL((pack_state_kernel<R, (MODEL == 4 ? 0 : back_axis<MODEL>())>), dim3(tb), dim3(256), 0, st, n, g_k1, g_k2,
+                     R(Prna[GEO_BACK_A1]), R(Prna[GEO_BACK_A2]), center, quat, p_lin, p_ang,
                      sys->d_meta, f0, sim->keep_valid ? (const R*)sim->keep_hi : nullptr,
                      (const R*)sim->keep_lo);
   MYTHOS_HIP_TRY(hipGetLastError());
@@ -1703,36 +1812,48 @@ int md_ready(mythos_sim_t* s, const char* who) {
   return MYTHOS_OK;
 }
 
+// oxNA systems step through the fused kernel's MODEL 4 instantiation; MYTHOS_NA1_UNFUSED=1 selects the two-launch path
+// (the energy kernel's forces + unfused_integrate_kernel) instead - a second implementation the tests hold the first to
+static bool na1_unfused(const mythos_system* sys) {
+  if (sys->model != 4) return false;
+  const char* v = getenv("MYTHOS_NA1_UNFUSED");
+  return v != nullptr && v[0] == '1';
+}
+
 int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
   mythos_system* sys = s->sys;
-  if (sys->model == 4)  // oxNA: the unfused path
+  if (na1_unfused(sys))
     return sys->dtype == MYTHOS_F32 ? unfused_load<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
                                     : unfused_load<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (sys->dtype == MYTHOS_F32)
     return sys->model == 1   ? load_typed<float, 1>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
            : sys->model == 2 ? load_typed<float, 2>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
-                             : load_typed<float, 3>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
+           : sys->model == 3 ? load_typed<float, 3>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
+                             : load_typed<float, 4>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
   return sys->model == 1   ? load_typed<double, 1>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
          : sys->model == 2 ? load_typed<double, 2>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
-                           : load_typed<double, 3>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
+         : sys->model == 3 ? load_typed<double, 3>(s, (double*)c, (double*)q, (double*)p, (double*)l, st)
+                           : load_typed<double, 4>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
 }
 
 int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
   mythos_system* sys = s->sys;
-  if (sys->model == 4)
+  if (na1_unfused(sys))
     return sys->dtype == MYTHOS_F32 ? unfused_advance<float>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
                                     : unfused_advance<double>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
   if (sys->dtype == MYTHOS_F32)
     return sys->model == 1   ? advance_typed<float, 1>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
            : sys->model == 2 ? advance_typed<float, 2>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
-                             : advance_typed<float, 3>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st);
+           : sys->model == 3 ? advance_typed<float, 3>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
+                             : advance_typed<float, 4>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st);
   return sys->model == 1   ? advance_typed<double, 1>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
          : sys->model == 2 ? advance_typed<double, 2>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
-                           : advance_typed<double, 3>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
+         : sys->model == 3 ? advance_typed<double, 3>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st)
+                           : advance_typed<double, 4>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
 }
 
 int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
-  if (s->sys->model == 4)
+  if (na1_unfused(s->sys))
     return s->sys->dtype == MYTHOS_F32 ? unfused_store<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
                                        : unfused_store<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (s->sys->dtype == MYTHOS_F32) return store_typed<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);

@@ -143,15 +143,31 @@ inline int* row_close_of(const mythos_system* sys) { return sys->d_row_len + (si
 // volume between base / backbone sites, H-bond, cross- and coaxial stacking) can act.  Rows keep the
 // neighbours inside this range (+ skin) in a leading "close" segment so the MD kernel's radial pass
 // runs its heavy and its Debye-only code on homogeneous wavefronts.
+// One flat vector of the system: the only one, or (oxNA) vector k of oxDNA2, oxRNA2, hybrid.
+inline const double* oxdna_param_set(const mythos_system* sys, int k) {
+  return sys->param_sets() == 1 ? sys->pd.v : sys->pd_sets.data() + (size_t)k * OXP_COUNT;
+}
+// max over the system's vectors of one entry, or of a function of a vector
+inline double oxdna_param_max(const mythos_system* sys, int idx) {
+  double m = oxdna_param_set(sys, 0)[idx];
+  for (int k = 1; k < sys->param_sets(); ++k) m = std::max(m, oxdna_param_set(sys, k)[idx]);
+  return m;
+}
+
 inline double oxdna_close_range(const mythos_system* sys) {
-  const OxParams<double>& P = sys->pd;
-  const double off_back =
-      std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model >= 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0));
-  const double off_base = std::fabs(P[GEO_BASE]), off_stack = std::fabs(P[GEO_STACK]);
-  double rcom = std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]) + off_back + off_base;
-  rcom = std::max(rcom, P[NEXC_BASE_RC] + 2 * off_base);
-  rcom = std::max(rcom, std::max((double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH]) + 2 * off_base);
-  rcom = std::max(rcom, P[CXST_RCHIGH] + 2 * off_stack);
+  // (oxNA: ranges from whichever vector is largest, site offsets from whichever geometry reaches farthest)
+  double off_back = 0.0, off_base = 0.0, off_stack = 0.0;
+  for (int k = 0; k < std::min(sys->param_sets(), 2); ++k) {  // the hybrid vector carries no geometry of its own
+    const double* P = oxdna_param_set(sys, k);
+    off_back = std::max(off_back, std::sqrt(P[GEO_BACK_A1] * P[GEO_BACK_A1] + (sys->model >= 2 ? P[GEO_BACK_A2] * P[GEO_BACK_A2] : 0.0)));
+    off_base = std::max(off_base, std::fabs(P[GEO_BASE]));
+    off_stack = std::max(off_stack, std::fabs(P[GEO_STACK]));
+  }
+  auto mx = [&](int idx) { return oxdna_param_max(sys, idx); };
+  double rcom = std::max(mx(NEXC_BACK_BASE_RC), mx(NEXC_BASE_BACK_RC)) + off_back + off_base;
+  rcom = std::max(rcom, mx(NEXC_BASE_RC) + 2 * off_base);
+  rcom = std::max(rcom, std::max(mx(HYDR_RCHIGH), mx(CRST_RCHIGH)) + 2 * off_base);
+  rcom = std::max(rcom, mx(CXST_RCHIGH) + 2 * off_stack);
   return rcom * (1.0 + 1e-6);
 }
 

@@ -343,26 +343,30 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   R* ref_a1 = write_refs ? (R*)sys->d_ref_a1 : nullptr;
   const int n = sys->n;
   // classification radius of the leading "close" segment (everything is close until parameters exist)
-  // (oxNA systems are evaluated by the energy kernel only, which does not use the segment)
-  const double rcl = (sys->params_set && sys->model != 4) ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
+  const double rcl = sys->params_set ? std::min(rl, oxdna_close_range(sys) + skin) : rl;
   int* d_close = row_close_of(sys);
   // range of the backbone-backbone terms (excluded volume, and Debye-Hueckel in oxDNA2) for the far segment
   double rbb = rl;
   if (off && sys->params_set) {
-    rbb = sys->pd[NEXC_BACKBONE_RC];
-    if (sys->model >= 2) rbb = std::max(rbb, (double)sys->pd[DH_RCUT]);
+    rbb = oxdna_param_max(sys, NEXC_BACKBONE_RC);
+    if (sys->model >= 2) rbb = std::max(rbb, oxdna_param_max(sys, DH_RCUT));
     rbb = std::min(rl, rbb + skin);
   }
   if (!sys->params_set || !a1) off = nullptr;
   SiteCrit<R> sc{off, a1, R(rbb * rbb), R(0), R(0), R(0), R(0), R(0)};
   if (off) {
-    const OxParams<double>& P = sys->pd;
+    // oxNA: the largest range over the three vectors; the base / stack sites of the two geometries sit at the mean
+    // offset along a1, and the ranges grow by the distance either real site can be from there
+    auto mx = [&](int idx) { return oxdna_param_max(sys, idx); };
+    const double* Pd = oxdna_param_set(sys, 0);
+    const double* Pr = oxdna_param_set(sys, sys->param_sets() == 1 ? 0 : 1);
+    const double slack_ba = std::fabs(Pd[GEO_BASE] - Pr[GEO_BASE]), slack_st = std::fabs(Pd[GEO_STACK] - Pr[GEO_STACK]);
     auto sq = [&](double r) { return R((r + skin) * (r + skin)); };
-    sc.rbase2 = sq(std::max({(double)P[HYDR_RCHIGH], (double)P[CRST_RCHIGH], (double)P[NEXC_BASE_RC]}));
-    sc.rstack2 = sq(P[CXST_RCHIGH]);
-    sc.rkb2 = sq(std::max((double)P[NEXC_BACK_BASE_RC], (double)P[NEXC_BASE_BACK_RC]));
-    sc.g_ba = R(P[GEO_BASE]);
-    sc.g_st = R(P[GEO_STACK]);
+    sc.rbase2 = sq(std::max({mx(HYDR_RCHIGH), mx(CRST_RCHIGH), mx(NEXC_BASE_RC)}) + slack_ba);
+    sc.rstack2 = sq(mx(CXST_RCHIGH) + slack_st);
+    sc.rkb2 = sq(std::max(mx(NEXC_BACK_BASE_RC), mx(NEXC_BASE_BACK_RC)) + 0.5 * slack_ba);
+    sc.g_ba = R(0.5 * (Pd[GEO_BASE] + Pr[GEO_BASE]));
+    sc.g_st = R(0.5 * (Pd[GEO_STACK] + Pr[GEO_STACK]));
   }
   CellGrid<R> g;
   bool ok = true;

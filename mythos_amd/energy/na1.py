@@ -6,8 +6,8 @@ pairs, mythos/input/na1/default_energy.toml) - evaluates each set's term on all 
 pair (e.g. na1/hydrogen_bonding.py:314-362).  Here the configurations have the same names and the same dependent
 sub-configurations (``dna_config``, ``rna_config``, ``drh_config``); the selection happens per pair inside the HIP
 energy kernel's oxNA instantiation (model 4 of the C ABI), which takes the three flat vectors and ``is_rna``.
-Energies, forces and dU/dtheta come from that kernel; dynamics (HipMDSimulator / mythos_langevin_*) run through an unfused
-path - its forces launch plus an integrator launch per step - because the fused MD step kernel has no hybrid instantiation.
+Energies, forces and dU/dtheta come from that kernel; dynamics (HipMDSimulator / mythos_langevin_*) from the oxNA
+instantiation of the fused MD step kernel.
 """
 
 from __future__ import annotations

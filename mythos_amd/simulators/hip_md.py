@@ -124,8 +124,7 @@ class HipMDSimulator(Simulator):
                 salt, hce = fn.params["salt_conc"], bool(fn.params["half_charged_ends"])
         sp = self.simulator_params
         if model == 4:
-            # oxNA: three flat vectors and the nucleotide types; the hybrid system is advanced by the unfused path (the
-            # energy kernel's forces + an integrator kernel per step, see mythos_amd/csrc/langevin.hip unfused_*)
+            # oxNA: three flat vectors and the nucleotide types (the step kernel's MODEL 4 instantiation)
             from mythos_amd.energy.base import na1_flat_and_types
 
             flat, is_rna, _, _ = na1_flat_and_types(ef.energy_fns, ef.weights, geom, kt_default=sp.kT)

@@ -40,8 +40,8 @@ for dtype in (torch.float32, torch.float64):
             row.append(round(1e3 * float(np.median(ts)), 3))
         print(f"{str(dtype).split('.')[-1]:8s} model {model} {name:22s} {c.shape[0]} frames x {top.n_nucleotides} nt: {row} ms", flush=True)
 
-# ---- MD of hybrid systems: the unfused path (forces launch + integrator launch per step), 1 500 replicas of the DNA-RNA
-#      golden helix = 24 000 nt in one system, Verlet list rebuilt every 10 steps
+# ---- MD of hybrid systems: the fused step kernel's oxNA instantiation (MYTHOS_NA1_UNFUSED=1: the two-launch path), 1 500
+#      replicas of the DNA-RNA golden helix = 24 000 nt in one system, Verlet list rebuilt every 10 steps
 from mythos_amd.energy import na1  # noqa: E402
 from mythos_amd.energy.base import Quaternion, RigidBody, space  # noqa: E402
 from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin  # noqa: E402
@@ -62,4 +62,4 @@ for dtype in (torch.float32, torch.float64):
     t0 = time.perf_counter()
     sim.run({}, init, 1000, key=2)
     torch.cuda.synchronize()
-    print(f"MD, unfused, 1500 replicas x 16 nt, {str(dtype).split('.')[-1]}: {1000 / (time.perf_counter() - t0):8.0f} steps/s", flush=True)
+    print(f"MD, 1500 replicas x 16 nt, {str(dtype).split('.')[-1]}: {1000 / (time.perf_counter() - t0):8.0f} steps/s", flush=True)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""dev: the unfused oxNA MD loop alone (for rocprofv3 --kernel-trace --stats): 1 500 replicas of the DNA-RNA golden helix."""
+"""dev: the oxNA MD loop alone (for rocprofv3 --kernel-trace --stats; MYTHOS_NA1_UNFUSED=1 for the two-launch path): 1 500
+replicas of the DNA-RNA golden helix."""
 import sys
 import time
 from pathlib import Path

@@ -140,14 +140,18 @@ def test_random_dimers(bonded):
             assert np.abs(got - want).max() <= tol * (np.abs(want).max() if dtype == torch.float32 else rms), (dtype, np.abs(got - want).max(), rms)
 
 
+@pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("name", ["simple-helix-dna-rna", "simple-coax-dna-dna-rna", "simple-helix-rna-rna"])
-def test_langevin_steps_match_the_oracle(name):
-    """A hybrid system is advanced by the unfused path (the energy kernel's forces + an integrator kernel per step,
-    langevin.hip unfused_*): six fp64 steps against LangevinOracle on the same Philox stream - positions, quaternions,
-    potential and kinetic energies of every step, final momenta; then the same trajectory in two advances."""
+def test_langevin_steps_match_the_oracle(name, unfused, monkeypatch):
+    """The fused step kernel's oxNA instantiation (per row entry: the parameter set of the pair's kind; sites by the type of
+    each nucleotide), and the two-launch path behind MYTHOS_NA1_UNFUSED=1 (the energy kernel's forces + an integrator
+    kernel): six fp64 steps against LangevinOracle on the same Philox stream - positions, quaternions, potential and kinetic
+    energies of every step, final momenta; then the same trajectory in two advances."""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle
 
+    if unfused:
+        monkeypatch.setenv("MYTHOS_NA1_UNFUSED", "1")
     top, traj, _, is_rna = H.load_golden_na1(name)
     kT = 296.15 * 0.1 / 300.0
     gam_t, gam_r, seed = kT / 2.5, kT / 7.5, 0xBADC0FFEE
