@@ -1,6 +1,6 @@
 """oxNA (hybrid DNA / RNA, model 4 of the C ABI) on the GPU against the oracle and the reference's seven na1 goldens
 (mythos/energy/na1/tests/test_integration.py): energies per term, forces, quaternion gradients, dU/dtheta for the three
-parameter vectors; random dimers of all four pair kinds; Langevin steps through the unfused path; what the boundary refuses."""
+parameter vectors; random dimers of all four pair kinds; Langevin steps through the fused kernel's oxNA instantiation and through the two-launch path; what the boundary refuses."""
 
 import numpy as np
 import pytest
@@ -186,7 +186,7 @@ def test_langevin_steps_match_the_oracle(name, unfused, monkeypatch):
 
 
 def test_simulator_runs_a_hybrid_duplex_with_a_dynamic_list():
-    """HipMDSimulator on the DNA-RNA golden helix, fp32, Verlet list rebuilt every 10 steps: finite, the helix holds, the
+    """HipMDSimulator (the fused step kernel) on the DNA-RNA golden helix, fp32, Verlet list rebuilt every 10 steps: finite, the helix holds, the
     mean potential energy stays where oxDNA's own run (interaction_type = NA) has it; and the static all-pairs list gives
     the same trajectory while no pair crosses the list range."""
     from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
