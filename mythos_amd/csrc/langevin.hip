@@ -1466,11 +1466,11 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
 }
 
 // ------------------------------------------------------------------------------------------------
-// oxNA (model 4): the UNFUSED path.  The fused step kernel has no hybrid instantiation (its hand-written radial pass and
-// per-role work lists would need the three-way dispatch of oxdna_pair.h); a hybrid system is advanced by two launches
-// per step instead - the energy kernel's forces instantiation (dU/dcentre, dU/dquaternion of the packed state), then
-// this integrator kernel, one thread per nucleotide: the same B A O A | B map, Philox stream and free-rotor drift as
-// md_step_kernel's integrator (shared device functions), so a trajectory is held to the same oracle.
+// oxNA (model 4): the UNFUSED path, behind MYTHOS_NA1_UNFUSED=1 - a second implementation of a hybrid system's dynamics
+// that the tests hold md_step_kernel<R, 4, ...> to (it came first and stayed as the cross-check).  Two launches per step:
+// the energy kernel's forces instantiation (dU/dcentre, dU/dquaternion of the packed state), then this integrator
+// kernel, one thread per nucleotide: the same B A O A | B map, Philox stream and free-rotor drift as md_step_kernel's
+// integrator (shared device functions), so a trajectory is held to the same oracle.
 // The list: static rows (mythos_oxdna_set_neighbors), or the integrator's policy - rows of range r_cut + skin rebuilt
 // every rebuild_every steps from the centres; the host looks at the skin flag at every rebuild (it synchronises there
 // anyway) and a violation is an error (no halt-and-resume on this path): shorten the interval or widen the skin.
