@@ -143,6 +143,46 @@ def test_12kbp_fp32_step_matches_energy_kernel_forces():
     assert np.abs(qd.cpu().double().numpy() - q).max() <= 1e-3 * np.abs(q - qn).max() + 3e-7
 
 
+def test_12kbp_fp64_step_matches_energy_kernel_forces():
+    """The same step in fp64: 750 workgroups, more than two per CU, so this is the stepping instantiation with the
+    three-per-CU register bound (168 VGPRs + scratch) and the pooled result rows - the one `config.f64` of the bench
+    measures.  Held to 1e-9 of the forces of the fp64 energy kernel (itself held to the oracle at 1 kbp)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle.langevin_oracle import drift
+
+    top, c0, q0 = generators.ideal_duplex(12000, model=2, seed=1234)
+    rng = np.random.default_rng(12)
+    c0 = c0 + 0.015 * rng.standard_normal(c0.shape)
+    q0 = q0 + 0.0075 * rng.standard_normal(q0.shape)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    s = _system(2, top, torch.float64)
+
+    def forces(x, q):
+        cd, qd = _dev(x, torch.float64, s), _dev(q, torch.float64, s)
+        s.build_neighbors(cd, R_CUT, 0.0)
+        _, gc, gq, _ = s.energy(cd, qd, grads=True)
+        return -gc.cpu().numpy().reshape(-1, 3), _body_torque(q, gq.cpu().numpy().reshape(-1, 4))
+
+    dt, inertia = 0.005, np.array([1.0, 1.1, 0.9])
+    F0, t0 = forces(c0, q0)
+    p, L = 0.5 * dt * F0, 0.5 * dt * t0
+    x, q, L = drift(c0, q0, p, L, 0.5 * dt, 1.0, inertia)
+    x, q, L = drift(x, q, p, L, 0.5 * dt, 1.0, inertia)
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    F1, t1 = forces(x, q)
+    p_ref, L_ref = p + 0.5 * dt * F1, L + 0.5 * dt * t1
+    integ = LangevinIntegrator(s, dt=dt, kT=KT, gamma_t=0.0, gamma_r=0.0, mass=1.0, inertia=tuple(inertia), seed=1)
+    integ.set_neighbor_policy(R_CUT, 0.6, 25)
+    c, qd = _dev(c0, torch.float64, s), _dev(q0, torch.float64, s)
+    pz, Lz = torch.zeros_like(c), torch.zeros_like(c)
+    integ.run(c, qd, pz, Lz, 1)
+    assert integ.last_recoveries() == 0  # the pool of 320 rows holds a thermal duplex: no abort, this IS the small instantiation
+    for got, ref in ((pz, p_ref), (Lz, L_ref)):
+        np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(c.cpu().numpy(), x, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(qd.cpu().numpy(), q, rtol=0, atol=1e-11)
+
+
 def _nicked_duplex(model):
     """16 bp duplex whose second strand is two 8-mers: the two bases either side of the nick stack coaxially.  (The
     reference's dna1/simple-coax trajectory has a non-zero coaxial term only in its initial configuration, which is
