@@ -10,7 +10,6 @@ dU/dtheta of the frames (``mythos_oxdna_energy_obs``), so a DiffTRe iteration re
 from __future__ import annotations
 
 import ctypes as C
-import weakref
 
 import numpy as np
 import torch

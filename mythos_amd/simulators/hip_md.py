@@ -25,7 +25,7 @@ from mythos_amd.energy import terms as _terms
 from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
 from mythos_amd.simulators.base import Simulator, SimulatorOutput
 from mythos_amd.simulators.io import SimulatorTrajectory
-from mythos_amd.simulators.neighbors import NoNeighborList, VerletNeighborList
+from mythos_amd.simulators.neighbors import NoNeighborList, VerletNeighborList  # noqa: F401  (NoNeighborList: re-exported, the docstring's example)
 
 
 @dc.dataclass

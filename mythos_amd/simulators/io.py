@@ -3,7 +3,6 @@
 from __future__ import annotations
 
 import dataclasses as dc
-from pathlib import Path
 from typing import Any, Callable
 
 import numpy as np
