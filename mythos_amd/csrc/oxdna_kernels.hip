@@ -61,8 +61,12 @@ constexpr int energy_blocks_per_cu() {
   if (MODEL == 4 && MODE >= 2) return 2;
   // fp64: the energy-only mode runs faster at three workgroups per CU with 100 B of scratch than at two without
   // (0.58 -> 0.49 ms on the DiffTRe shape); the gradient modes spill too much for that (0.72 -> 1.43 ms)
+  // and do not want ONE either (no spills, but one wavefront per SIMD: 0.72 -> 1.16 ms forces, 1.18 -> 1.44 ms dU/dtheta)
   // fp32 forces mode: 128 registers without scratch, so four fit (at three the allocator takes 138 and the call is 18 % slower)
-  return sizeof(R) == 4 ? (MODE <= 1 ? 4 : EN_LB) : (MODE == 0 ? 3 : 2);
+#ifndef MYTHOS_EN_F64_GRAD_BLOCKS  // (dev A/B)
+#define MYTHOS_EN_F64_GRAD_BLOCKS 2
+#endif
+  return sizeof(R) == 4 ? (MODE <= 1 ? 4 : EN_LB) : (MODE == 0 ? 3 : MYTHOS_EN_F64_GRAD_BLOCKS);
 }
 
 // SEG: rows longer than the LDS lists are walked in segments (gather_row)
