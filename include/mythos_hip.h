@@ -77,8 +77,8 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
  *             functional forms of its kind - DNA-DNA: oxDNA2, RNA-RNA: oxRNA2, DNA-RNA: the hybrid numbers in the oxDNA1
  *             forms - and every nucleotide the sites of its own type.  Such a system needs
  *             mythos_oxdna_set_nucleotide_types, takes 3 x mythos_oxdna_param_count() parameters (the oxDNA2, oxRNA2 and
- *             hybrid vectors one after the other; dU_dparams rows have the same layout).  No structural observables and no
- *             probabilistic sequence for it.  The Langevin integrator has an oxNA instantiation of its fused step kernel
+ *             hybrid vectors one after the other; dU_dparams rows have the same layout).  No structural observables for it;
+ *             a probabilistic sequence for hydrogen bonding only (mythos_oxdna_set_pseq terms = 2), no dU/d(distribution).  The Langevin integrator has an oxNA instantiation of its fused step kernel
  *             (about half the oxDNA2 rate: a parameter set is chosen per row entry).
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL

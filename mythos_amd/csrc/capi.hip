@@ -203,8 +203,9 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
     set_error("mythos_oxdna_set_pseq: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (s->model == 4 && terms != 0) {
-    set_error("mythos_oxdna_set_pseq: probabilistic sequences are not available for oxNA systems (model 4)");
+  if (s->model == 4 && (terms & 1) != 0) {
+    set_error("mythos_oxdna_set_pseq: an oxNA system (model 4) takes a probabilistic sequence for hydrogen bonding only "
+              "(terms = 2), as the reference's na1 terms do");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   MYTHOS_HIP_TRY(hipSetDevice(s->device));

@@ -89,11 +89,13 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
-  // (oxNA, MODEL 4: three vectors one after the other - oxDNA2, oxRNA2, hybrid; no probabilistic sequence)
+  // (oxNA, MODEL 4: three vectors one after the other - oxDNA2, oxRNA2, hybrid; a probabilistic sequence reaches the
+  //  weight look-ups through each of them - the reference threads it through its na1 hydrogen-bonding term,
+  //  na1/hydrogen_bonding.py:243-304)
   const auto P = [&] {
     if constexpr (MODEL == 4) {
-      using CP = ConstParams<R, false>;
-      return Na1Params<CP>{CP(Pg), CP(Pg + OXP_COUNT), CP(Pg + 2 * OXP_COUNT)};
+      using CP = ConstParams<R, true>;
+      return Na1Params<CP>{CP(Pg, pseq), CP(Pg + OXP_COUNT, pseq), CP(Pg + 2 * OXP_COUNT, pseq)};
     } else {
 #ifdef MYTHOS_EN_NO_PSEQ  // (dev A/B)
       return ConstParams<R, false>(Pg);

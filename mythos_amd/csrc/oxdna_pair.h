@@ -272,7 +272,7 @@ __device__ __forceinline__ R f3_site_pair_geo(const PT& P, int ie, const F3P<R>&
 template <class PT>
 struct Na1Params {
   static constexpr bool indexed = false;
-  static constexpr bool has_pseq = false;
+  static constexpr bool has_pseq = PT::has_pseq;
   static constexpr bool has_pseq_grad = false;
   PT dna, rna, drh;
 };

@@ -641,6 +641,7 @@ class ComposedEnergyFunction(EnergyFunction):
         entry = _get_system(4, _np(first.seq), _np(first.is_end) if first.is_end is not None else None, _np(first.bonded_neighbors),
                             first.unbonded_neighbors, getattr(first.displacement_fn, "box", None), center.dtype, center.device,
                             is_rna=is_rna)
+        _apply_pseq(entry, pseq_request(self.energy_fns))  # hydrogen bonding only (na1/hydrogen_bonding.py:127-128)
         entry["observe"] = None
         total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         return total, terms, cols

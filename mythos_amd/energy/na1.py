@@ -5,7 +5,8 @@ prefixed names - ``dna_*`` (oxDNA2 numbers), ``rna_*`` (oxRNA2), and for the unb
 pairs, mythos/input/na1/default_energy.toml) - evaluates each set's term on all pairs and selects by the types of the
 pair (e.g. na1/hydrogen_bonding.py:314-362).  Here the configurations have the same names and the same dependent
 sub-configurations (``dna_config``, ``rna_config``, ``drh_config``); the selection happens per pair inside the HIP
-energy kernel's oxNA instantiation (model 4 of the C ABI), which takes the three flat vectors and ``is_rna``.
+energy kernel's oxNA instantiation (model 4 of the C ABI), which takes the three flat vectors and ``is_rna``
+(and, for hydrogen bonding, the probabilistic sequence the reference's configuration carries).
 Energies, forces and dU/dtheta come from that kernel; dynamics (HipMDSimulator / mythos_langevin_*) from the oxNA
 instantiation of the fused MD step kernel.
 """
@@ -27,10 +28,10 @@ from mythos_amd.energy.base import (
 from mythos_amd.energy.configuration import BaseConfiguration
 from mythos_amd.input import defaults
 
-_SKIP = ("pseq", "pseq_constraints")  # probabilistic sequences are not available for oxNA systems
+_SKIP = ("pseq", "pseq_constraints")  # never prefixed: the hydrogen-bonding configuration carries ONE distribution for its three sets
 
 
-def _na1_configuration(name: str, doc: str, bases: dict, shared: tuple = ()) -> type:
+def _na1_configuration(name: str, doc: str, bases: dict, shared: tuple = (), pseq: bool = False) -> type:
     """A configuration whose required parameters are ``nt_type``, the shared ones, and the required parameters of each
     base configuration under its prefix; ``init_params`` builds the initialised base configurations."""
     req = ["nt_type", *shared]
@@ -39,11 +40,16 @@ def _na1_configuration(name: str, doc: str, bases: dict, shared: tuple = ()) -> 
         req += [f"{which}_{n}" for n in cls.required_params if n not in shared]
         opt += [f"{which}_{n}" for n in cls.optional_params if n not in _SKIP]
 
+    if pseq:  # one sequence distribution for all three sets (na1/hydrogen_bonding.py:127-128, 243-304)
+        opt += list(_SKIP)
+
     def derive(self) -> dict:
         out = {}
         for which, cls in bases.items():
             vals = {n: (self[n] if n in shared else self[f"{which}_{n}"]) for n in cls.required_params}
             vals.update({n: self[f"{which}_{n}"] for n in cls.optional_params if n not in _SKIP and self[f"{which}_{n}"] is not None})
+            if pseq and self["pseq"] is not None:
+                vals.update(pseq=self["pseq"], pseq_constraints=self["pseq_constraints"])
             out[f"{which}_config"] = cls(**vals).init_params()
         return out
 
@@ -75,7 +81,8 @@ UnbondedExcludedVolumeConfiguration = _na1_configuration(
     "UnbondedExcludedVolumeConfiguration", "na1/unbonded_excluded_volume.py:17-137.",
     {w: T.UnbondedExcludedVolumeConfiguration for w in ("dna", "rna", "drh")})
 HydrogenBondingConfiguration = _na1_configuration(
-    "HydrogenBondingConfiguration", "na1/hydrogen_bonding.py:19-311.", {w: T.HydrogenBondingConfiguration for w in ("dna", "rna", "drh")})
+    "HydrogenBondingConfiguration", "na1/hydrogen_bonding.py:19-311 (the one na1 term that carries ``pseq`` / ``pseq_constraints``).",
+    {w: T.HydrogenBondingConfiguration for w in ("dna", "rna", "drh")}, pseq=True)
 CrossStackingConfiguration = _na1_configuration(
     "CrossStackingConfiguration", "na1/cross_stacking.py:19-259: oxDNA form for DNA-DNA and hybrid pairs, oxRNA2 form for RNA-RNA.",
     {"dna": T.CrossStackingConfiguration, "rna": T.CrossStackingConfigurationRna2, "drh": T.CrossStackingConfiguration})

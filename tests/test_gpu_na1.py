@@ -225,7 +225,7 @@ def test_what_the_boundary_refuses():
     with pytest.raises(ValueError, match="expected 783"):  # one vector where three are needed
         s.set_params(_flat()[: len(_lib.param_names())])
     s.set_params(_flat())
-    with pytest.raises(ValueError, match="not available for oxNA"):
+    with pytest.raises(ValueError, match="hydrogen bonding only"):  # stacking weights of an oxNA system take no distribution
         s.set_pseq(np.full((top.n_nucleotides, 4), 0.25), np.full(top.n_nucleotides, -1), np.zeros((0, 4)), terms=3)
     other = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
     with pytest.raises(ValueError, match="only an oxNA system"):
@@ -314,3 +314,40 @@ def test_default_function_total_and_autograd():
     for k, g, w in zip(opt, got, want):
         assert abs(float(g) - float(w)) <= 1e-7 * max(1.0, abs(float(w))), (k, float(g), float(w))
         assert abs(float(w)) > 1e-6, k
+
+
+def test_probabilistic_sequence_through_the_hydrogen_bonding_term():
+    """The reference's na1 HydrogenBondingConfiguration carries ``pseq`` / ``pseq_constraints`` and hands them to its
+    three sub-configurations (na1/hydrogen_bonding.py:127-128, 243-304): a one-hot distribution reproduces the discrete
+    energies of the hybrid golden, a soft one equals the oracle's expectation - with the hybrid weight table for the
+    DNA-RNA pairs."""
+    from mythos_amd.input import sequence_constraints as scm
+
+    top, traj, _, is_rna = H.load_golden_na1("simple-helix-dna-rna")
+    disp, _ = space.periodic(20.0)
+    ef = na1.create_default_energy_fn(top, disp)
+    frames = [0, 25, 50, 75]
+    states = _states(traj)
+    sub = RigidBody(center=states.center[frames], orientation=Quaternion(vec=states.orientation.vec[frames]))
+    e_d = ef.compute_terms(sub).cpu().numpy()
+    sc = scm.from_bps(top.n_nucleotides, np.array([[1, 14], [3, 12]]))
+    e_hot = ef.with_params(pseq=scm.dseq_to_pseq(top.seq, sc), pseq_constraints=sc).compute_terms(sub).cpu().numpy()
+    np.testing.assert_allclose(e_hot, e_d, rtol=0, atol=1e-12)
+    rng = np.random.default_rng(3)
+
+    def dist(rows):
+        a = rng.random((rows, 4)) + 0.05
+        return a / a.sum(1, keepdims=True)
+
+    up, bp = dist(sc.n_unpaired), dist(sc.n_bp)
+    e_soft = ef.with_params(pseq=(up, bp), pseq_constraints=sc).compute_terms(sub).cpu().numpy()
+    sim, cfg = defaults.default_configs_for("na1")
+    for which in cfg:
+        cfg[which]["hydrogen_bonding"].update(pseq=(up, bp), pseq_constraints=sc)
+    P = orc.init_all_na1(cfg["dna"], cfg["rna"], cfg["drh"], kt=sim["kT"], salt_conc=0.5, half_charged_ends=False)
+    seq, is_end, b, u = H.topo_tensors(top)
+    want = np.array([orc.energy_terms_na1(P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, torch.as_tensor(is_rna),
+                                          is_end, b, u, box=traj.box_size).numpy() for f in frames])
+    np.testing.assert_allclose(e_soft, want, rtol=1e-10, atol=1e-10)
+    assert np.abs(e_soft[:, 4] - e_d[:, 4]).max() > 1e-2   # the distribution matters ...
+    np.testing.assert_allclose(np.delete(e_soft, 4, axis=1), np.delete(e_d, 4, axis=1), rtol=0, atol=1e-12)  # ... to hydrogen bonding only
