@@ -2,7 +2,8 @@
 // energies and forces, runs a few Langevin steps with list rebuilds, prints the numbers.  Built twice by
 // oracle/Makefile: plain, and with -fsanitize=address,undefined (the test compares the two outputs and requires a
 // clean sanitizer log).  File layout: int32 {model, n, n_bonded, n_params, has_box, n_steps}, then seq int32[n],
-// is_end int32[n], bonded int32[n_bonded][2], box double[3], flat double[n_params], center double[n][3], quat double[n][4].
+// is_end int32[n], bonded int32[n_bonded][2], box double[3], flat double[n_params], center double[n][3], quat double[n][4],
+// and for model 4 (oxNA; n_params = three vectors) is_rna int32[n].
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@ extern "C" {
 void* mythos_cpu_create(int model, int n, const int32_t* seq, const uint8_t* is_end, int n_bonded, const int32_t* bonded,
                         const double* box, const double* flat, int n_params);
 void mythos_cpu_destroy(void* h);
+void mythos_cpu_set_types(void* h, const uint8_t* is_rna);
 int mythos_cpu_build_pairs(void* h, const double* center, double r_list);
 int mythos_cpu_energy(void* h, const double* center, const double* quat, double* e_terms, double* dU_dcenter,
                       double* dU_dquat, double* torque_body);
@@ -43,10 +45,15 @@ int main(int argc, char** argv) {
   const auto flat = rd<double>(f, np);
   auto c = rd<double>(f, 3 * (size_t)n);
   auto q = rd<double>(f, 4 * (size_t)n);
+  const auto rna32 = model == 4 ? rd<int32_t>(f, n) : std::vector<int32_t>();
   fclose(f);
   std::vector<uint8_t> is_end(end32.begin(), end32.end());
   void* h = mythos_cpu_create(model, n, seq.data(), is_end.data(), nb, bonded.data(), has_box ? box.data() : nullptr, flat.data(), np);
   if (!h) return 3;
+  if (model == 4) {
+    std::vector<uint8_t> is_rna(rna32.begin(), rna32.end());
+    mythos_cpu_set_types(h, is_rna.data());
+  }
   mythos_cpu_build_pairs(h, c.data(), 3.25);
   double e[8];
   std::vector<double> dc(3 * (size_t)n), dq(4 * (size_t)n), tb(3 * (size_t)n);

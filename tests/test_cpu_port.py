@@ -209,9 +209,17 @@ def test_sanitizers_are_clean_and_agree_with_the_plain_build(tmp_path):
     plain, san = cpu_port.BUILD / "md_cpu_selftest", cpu_port.BUILD / "md_cpu_selftest_san"
     if not san.exists():
         subprocess.run(["make", "-C", str(cpu_port.BUILD.parent)], check=True, capture_output=True)
-    for model, box in ((2, None), (1, np.array([40.0, 40.0, 60.0]))):
-        top, c0, q0 = generators.ideal_duplex(80, model=model, seed=9)
-        flat = _flat(model, model == 2)
+    for model, box in ((2, None), (1, np.array([40.0, 40.0, 60.0])), (3, np.array([20.0, 20.0, 20.0])), (4, np.array([20.0, 20.0, 20.0]))):
+        is_rna = None
+        if model == 3:    # oxRNA2: the reference's RNA helix (an ideal B-duplex is outside the FENE well of the RNA geometry)
+            top, traj, _, _ = H.load_golden(3, "simple-helix-12bp")
+            c0, q0, flat = traj.center[0], traj.quaternions[0], _flat(3, False)
+        elif model == 4:  # oxNA: the DNA-RNA hybrid helix, three vectors and the nucleotide types
+            top, traj, _, is_rna = H.load_golden_na1("simple-helix-dna-rna")
+            c0, q0, flat = traj.center[0], traj.quaternions[0], _flat_na1()
+        else:
+            top, c0, q0 = generators.ideal_duplex(80, model=model, seed=9)
+            flat = _flat(model, model == 2)
         path = tmp_path / f"sys{model}.bin"
         with open(path, "wb") as f:
             np.array([model, top.n_nucleotides, len(top.bonded_neighbors), len(flat), 0 if box is None else 1, 20], np.int32).tofile(f)
@@ -222,6 +230,8 @@ def test_sanitizers_are_clean_and_agree_with_the_plain_build(tmp_path):
             flat.astype(np.float64).tofile(f)
             c0.astype(np.float64).tofile(f)
             q0.astype(np.float64).tofile(f)
+            if is_rna is not None:
+                np.asarray(is_rna, np.int32).tofile(f)
         env = {"OMP_NUM_THREADS": "4", "ASAN_OPTIONS": "detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1"}
         a = subprocess.run([str(plain), str(path)], capture_output=True, text=True, env=env, timeout=120)
         b = subprocess.run([str(san), str(path)], capture_output=True, text=True, env=env, timeout=300)
