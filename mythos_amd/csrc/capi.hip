@@ -318,6 +318,11 @@ int mythos_oxdna_energy_dpseq(mythos_system_t* s, const void* center, const void
     set_error("mythos_oxdna_energy_dpseq: invalid argument (dU_dparams and both distribution-gradient buffers are required)");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
+  if (s->model == 4) {
+    set_error("mythos_oxdna_energy_dpseq: not available for oxNA systems (model 4); their energies and dU/dparams honour the "
+              "distribution, the gradient with respect to it is not accumulated");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
   if (!s->params_set || !s->nbrs_set || s->pseq_terms == 0) {
     set_error("mythos_oxdna_energy_dpseq: parameters, neighbours and a probabilistic sequence (mythos_oxdna_set_pseq) must be set first");
     return MYTHOS_ERR_NOT_READY;

@@ -227,6 +227,13 @@ def test_what_the_boundary_refuses():
     s.set_params(_flat())
     with pytest.raises(ValueError, match="hydrogen bonding only"):  # stacking weights of an oxNA system take no distribution
         s.set_pseq(np.full((top.n_nucleotides, 4), 0.25), np.full(top.n_nucleotides, -1), np.zeros((0, 4)), terms=3)
+    s.set_neighbors(top.unbonded_neighbors)
+    s.set_pseq(np.full((top.n_nucleotides, 4), 0.25), np.full(top.n_nucleotides, -1), np.zeros((0, 4)), terms=2)
+    c1 = torch.as_tensor(traj.center[:1], device=s.device)
+    q1 = torch.as_tensor(traj.quaternions[:1], device=s.device)
+    with pytest.raises(ValueError, match="not available for oxNA"):  # dU/d(distribution): oxDNA / oxRNA2 systems only
+        s.energy(c1, q1, param_grads=True, pseq_grads=True)
+    s.set_pseq()
     other = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
     with pytest.raises(ValueError, match="only an oxNA system"):
         t = np.ascontiguousarray(is_rna, dtype=np.uint8)
