@@ -8,11 +8,15 @@ Langevin) per GPU, one independent replica per GPU (BASELINE.json metric / confi
     python bench.py --gpus N ...      (no launcher: starts the N ranks itself as child processes)
 
 A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin.hip).
-The timed region is one ``mythos_langevin_advance`` call of K steps with the state resident in HBM
-(loaded into the integrator before the clock starts), bracketed by barrier + synchronize; value =
-N_gpus * K / max-over-ranks time.  Nothing else is inside it: the per-dispatch HIP events behind
-``roofline.kernel_ms`` are taken in a second, untimed pass of the same length.  For N > 1 the
-replicas' observables (energy trace) are all-gathered over RCCL inside the timed region.
+The timed region is one ``mythos_langevin_advance`` call of exactly K steps with the state resident in HBM
+(loaded into the integrator before the clock starts), bracketed by barrier + synchronize, MAX over ranks.
+It is measured ``--repeats`` times back to back (default 5; the trajectory continues from sample to sample);
+value = N_gpus * K / the MEDIAN sample, all samples are in ``config.samples_ms`` and the number of scheduled
+list rebuilds that fell inside each in ``config.scheduled_rebuilds_per_sample``.  Nothing else is inside a
+sample: the per-dispatch HIP events behind ``roofline.kernel_ms`` are taken in a second, untimed pass.  For
+N > 1 the replicas' observables (energy trace) are all-gathered over RCCL inside the timed region (one
+collective).  The headline precision is fp32 (north_star: fp32 forces at 1e-3); the same measurement in the
+reference's fp64 is ``config.f64``, ``f64_steps_per_s`` and the tail of ``config.timed_region``.
 
 Rank 0 prints ONE JSON line with the fields of the driver contract plus
   roofline      HBM roofline of the step kernel: algorithmic bytes per launch (2 x 14 state
@@ -67,6 +71,9 @@ def parse_args():
                     help="oxdna2-12kbp is the headline (BASELINE.json metric); martini-bilayer is BASELINE configs[2] "
                          "(20 480-bead DMPC bilayer, LJ + bonds + angles, Langevin) and prints its own line")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the measurement at the other precision (config.f64 / config.f32)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the timed region (exactly --steps steps) is run this many times back to back, each bracketed by barrier + "
+                         "synchronize; value = steps / the MEDIAN sample, every sample is in config.samples_ms")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
                          "between ranks); the printed line is then marked as a rehearsal, not a measurement")
@@ -182,8 +189,7 @@ def cpu_baseline(top, c0, q0, sim, n_steps: int, pairs: np.ndarray, budget_s: fl
         "unit": "steps/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"{n_steps} Langevin steps of the same {top.n_nucleotides}-nt system, torch-fp64 oracle over the "
-        f"same Verlet pair list ({len(pairs)} pairs), {dt:.1f} s",
+        "sample": f"{n_steps} steps, same {top.n_nucleotides}-nt system, torch-fp64 oracle, {len(pairs)} listed pairs, {dt:.1f} s",
     }
 
 
@@ -215,9 +221,9 @@ def cpu_baseline_openmp(top, c0, q0, sim, flat, n_steps: int = 1000, repeats: in
         done += n_steps
     assert np.isfinite(x).all()
     return {"value": float(np.median(rates)), "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"C++/OpenMP port of the same kernels (oracle/cpu_port), fp64, median of {repeats} x {n_steps} Langevin steps after "
-                      f"{warmup} warm-up steps of the same {top.n_nucleotides}-nt system, Verlet list r_cut {R_CUT} + skin 0.6 rebuilt "
-                      f"every 25 steps; all {repeats} rates: " + ", ".join(f"{r:.1f}" for r in rates)}
+            "sample": f"C++/OpenMP port (oracle/cpu_port) fp64, median of {repeats} x {n_steps} steps after {warmup}, same "
+                      f"{top.n_nucleotides}-nt system",
+            "rates": [float(r) for r in rates], "neighbor_list": {"r_cut": R_CUT, "skin": 0.6, "rebuild_every": 25}}
 
 
 def martini_main(args):
@@ -318,29 +324,37 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     integ.advance(args.warmup)
     torch.cuda.synchronize(dev)
 
-    # ---- timed region: exactly args.steps steps
+    # ---- timed region: exactly args.steps steps, measured args.repeats times back to back (the trajectory simply
+    #      continues); every sample has its own barrier + synchronize on both sides and its own MAX over ranks
     world = 1 if dist is None else dist.get_world_size()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    _, _, et = integ.advance(args.steps, save_every=args.save_every)
-    if dist is not None:
-        # per-replica observables (energy trace, or one row of zeros without --save-every), replica id =
-        # rank: one all-gather over RCCL / xGMI - the only collective, the MD data path has none
-        obs = et if et is not None else torch.zeros((1, 10), dtype=torch.float64, device=dev)
-        obs = obs.reshape(1, -1)
-        gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs)
-        assert gathered.shape[0] == world
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    recoveries = integ.last_recoveries()
+    zeros_obs = torch.zeros((1, 10), dtype=torch.float64, device=dev)
+    samples, rebuilds, recoveries = [], [], 0
+    for _ in range(max(1, args.repeats)):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _, _, et = integ.advance(args.steps, save_every=args.save_every)
+        if dist is not None:
+            # per-replica observables (energy trace, or one row of zeros without --save-every), replica id = rank: ONE
+            # all-gather over RCCL / xGMI - the only collective, the MD data path has none - and no host read-back
+            obs = (et if et is not None else zeros_obs).reshape(1, -1)
+            gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs, n_total=world)
+            assert gathered.shape[0] == world
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        samples.append(elapsed)
+        rebuilds.append(integ.last_rebuilds())
+        recoveries += integ.last_recoveries()
+    order = sorted(range(len(samples)), key=lambda k: samples[k])
+    mid = order[len(order) // 2]  # the median sample (the upper one of an even count): value, ms_per_step and its rebuild count
+    elapsed = samples[mid]
 
     # ---- instrumented pass (untimed): duration of the step kernel from HIP events attached to sampled dispatches on
     #      the launch stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
@@ -358,7 +372,19 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
     return {"elapsed": elapsed, "steps_per_s": world * args.steps / elapsed, "kernel_ms": kms,
             "loop_ms_per_launch": timing["loop_ms_per_launch"], "alg": alg, "achieved": achieved,
-            "mean_row": nbar, "max_row": mx, "recoveries": recoveries}
+            "mean_row": nbar, "max_row": mx, "recoveries": recoveries, "samples_ms": [1e3 * t for t in samples],
+            "rebuilds": rebuilds, "rebuilds_in_median": rebuilds[mid]}
+
+
+def _timed_region(args, m, m2) -> str:
+    """What the timed region held, in under 120 characters: steps, launches, list rebuilds inside the median sample,
+    and the rate at the other precision."""
+    txt = (f"{args.steps} steps = {args.steps + 1} launches + {m['rebuilds_in_median']} list rebuilds + 1 sync; "
+           f"median of {len(m['samples_ms'])}")
+    if m2 is not None:
+        other = "f64" if args.dtype == "f32" else "f32"
+        txt += f"; {other} {m2['steps_per_s'] / 1e3:.1f}k steps/s"
+    return txt
 
 
 def main():
@@ -413,16 +439,21 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            # (strings of the record are kept under 120 characters: the driver's parsed copy truncates there)
             "config": {
-                "workload": f"oxDNA2 {args.bp} bp ideal B-duplex ({n} nt), Debye-Hueckel salt 0.5, half-charged ends, "
-                f"Langevin dt {sim['dt']}, kT {kT:.6f}, free space, 1 replica per GPU",
+                "workload": f"oxDNA2 {args.bp} bp duplex ({n} nt), Debye-Hueckel salt 0.5, Langevin dt {sim['dt']}, free space, 1 replica/GPU",
+                "kT": kT,
+                "half_charged_ends": True,
                 "replicas": world,
                 **({"rehearsal": "all ranks on cuda:0 over gloo - not a measurement"} if args.rehearse_on_one_gpu else {}),
                 "neighbor_list": {"r_cut": R_CUT, "skin": args.skin, "rebuild_every": args.rebuild_every, "mean_row": m["mean_row"],
                                   "max_row": m["max_row"], "out_of_turn_rebuilds": m["recoveries"]},
                 "ns_per_day": m["steps_per_s"] / world * sim["dt"] * OXDNA_TIME_UNIT_PS * 86400.0 * 1e-3,
-                "timed_region": f"one mythos_langevin_advance of {args.steps} steps on the resident state = {args.steps + 1} "
-                "step-kernel launches (the last closes the final half kick) + scheduled list rebuilds + one stream synchronisation",
+                "timed_region": _timed_region(args, m, m2),
+                "repeats": len(m["samples_ms"]),
+                "samples_ms": m["samples_ms"],
+                "scheduled_rebuilds_per_sample": m["rebuilds"],
+                "precision": f"headline {args.dtype} (north_star: fp32 at 1e-3); the reference's fp64 is config.{other} and f64_steps_per_s",
             },
             "roofline": {
                 "bound": "hbm",
@@ -431,6 +462,7 @@ def main():
                 "unit": "GB/s",
                 "frac": m["achieved"] / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args, n),
+                "traffic_source": "profiles/traffic.json: PMC passes of this command (rocprofv3), not measured inside this run",
                 "kernel": "md_step_kernel",
                 "kernel_ms": m["kernel_ms"],
                 "loop_ms_per_launch": m["loop_ms_per_launch"],
@@ -438,7 +470,9 @@ def main():
             },
         }
         if m2 is not None:
+            out[f"{other}_steps_per_s"] = m2["steps_per_s"]  # top level too: nested objects do not survive every parser
             out["config"][other] = {"steps_per_s": m2["steps_per_s"], "ms_per_step": 1e3 * m2["elapsed"] / args.steps,
+                                    "samples_ms": m2["samples_ms"], "scheduled_rebuilds_per_sample": m2["rebuilds"],
                                     "kernel_ms": m2["kernel_ms"], "loop_ms_per_launch": m2["loop_ms_per_launch"],
                                     "achieved_GBs": m2["achieved"], "frac": m2["achieved"] / HBM_PEAK_GBS,
                                     "algorithmic_bytes_per_launch": m2["alg"]}

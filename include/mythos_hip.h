@@ -106,8 +106,9 @@ int mythos_oxdna_set_nucleotide_types(mythos_system_t* sys, const uint8_t* is_rn
  *   unit       host int32[n]       2 * base_pair + position_in_pair for constrained base pairs, -1 for unpaired
  *   bp_probs   host double[n_bp][4] probability of the types AT, TA, GC, CG (mythos/utils/constants.py:13) per base pair
  *   terms      bit 0: stacking, bit 1: hydrogen bonding use the expectation; 0 switches back to the discrete sequence
- * The Langevin integrator refuses a system with a probabilistic sequence (MYTHOS_ERR_NOT_READY): dynamics need a
- * sequence, reweighting a distribution over them. */
+ * The Langevin integrator steps such a system too (since round 3): the stepping kernel has instantiations whose two
+ * weight look-ups are the expectations (md_step_kernel<..., PSEQ>), as the reference's configurations carry pseq into
+ * any energy function, the one a simulator steps with included (dna1/stacking.py:284-285, hydrogen_bonding.py:330-331). */
 int mythos_oxdna_set_pseq(mythos_system_t* sys, const double* marginals, const int32_t* unit, int n_bp,
                           const double* bp_probs, int terms);
 
@@ -229,6 +230,14 @@ int mythos_langevin_store(mythos_sim_t* sim, void* center, void* quat, void* p_l
 int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
 int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
 
+/* Integrator options.  MYTHOS_LANGEVIN_UNFUSED (oxNA systems only, value 0 / 1): step through the two-launch path -
+ * the energy kernel's forces launch + a one-thread-per-nucleotide integrator - instead of the fused step kernel.  A
+ * second implementation of the same map (same Philox stream), kept as the cross-check of the fused oxNA instantiation;
+ * it has no halt-and-resume (a skin violation is an error).  Takes effect at the next mythos_langevin_load / _run and
+ * holds while that state is resident. */
+enum mythos_langevin_option { MYTHOS_LANGEVIN_UNFUSED = 0 };
+int mythos_langevin_set_option(mythos_sim_t* sim, int option, int64_t value);
+
 /* timing hook for bench.py, HIP events on the launch stream of the last run / advance (all zero unless
  * mythos_langevin_set_timing asked for samples: an untimed run records no events at all):
  *   kernel_ms            mean duration of the step kernel over up to 16 launches spread evenly over the
@@ -248,6 +257,9 @@ int mythos_langevin_last_kernel_ms(const mythos_sim_t* sim, double* kernel_ms, d
  * list signals `did_buffer_overflow` and leaves the reallocation to the caller (jax_md partition, used at
  * mythos/simulators/jax_md/utils.py:70-126).  More than 64 in one run fails with MYTHOS_ERR_OVERFLOW. */
 int mythos_langevin_last_recoveries(const mythos_sim_t* sim, int* recoveries);
+/* scheduled list rebuilds (every rebuild_every steps) that fell inside the last run / advance; the build that creates a
+ * list and the out-of-turn ones above are not counted.  bench.py reports it next to the timed region. */
+int mythos_langevin_last_rebuilds(const mythos_sim_t* sim, int* scheduled);
 
 /* ---- oxDNA text trajectories (host only) -----------------------------------------------------
  * Replaces the Python parse of mythos/input/trajectory.py:192-320 (frames of `t = / b = / E =` header lines and
@@ -262,6 +274,22 @@ int mythos_oxdna_read_trajectory(const char* path, int n, int max_frames, double
  * same double (what the reference's str(float) prints); append != 0 adds to an existing file. */
 int mythos_oxdna_write_trajectory(const char* path, int n, int n_frames, const double* times, const double* box,
                                   const double* energies, const double* frames, int append);
+
+/* ---- test and diagnostic switches ---------------------------------------------------------------
+ * No counterpart in the reference.  The GPU tests use them to reach code paths that physical inputs reach only by
+ * chance (a cell bucket that overflows, a row walk in several segments, a list rebuild that overflows in front of the
+ * first launch of a segment).  Process-wide, read when a list is built / a call starts (never per launch); a value of 0
+ * restores the default.  Nothing in the library reads the environment. */
+enum mythos_debug_key {
+  MYTHOS_DEBUG_CELL_BUCKET_CAP = 0, /* places per cell bucket, fixed (no growth): exercises the spill list */
+  MYTHOS_DEBUG_ENERGY_LIST_CAP = 1, /* entries per segment of the energy kernel's row walk (8 ... 192) */
+  MYTHOS_DEBUG_MD_SEGMENT = 2,      /* step launches queued between two looks at the halt word (default 8192) */
+  MYTHOS_DEBUG_MD_OVERFLOW_AT = 3,  /* k + 1: the scheduled list rebuild in front of step launch k reports a row
+                                       overflow although its rows fit (one shot: cleared when it fires) */
+  MYTHOS_DEBUG_KEYS = 4
+};
+int mythos_debug_set(int key, int64_t value);
+int64_t mythos_debug_get(int key);
 
 /* ---- MARTINI 2/3 ------------------------------------------------------------------------------
  * Replaces mythos/energy/martini/m2/{lj,bond,angle}.py and m3/angle.py.

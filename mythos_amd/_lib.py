@@ -46,6 +46,8 @@ def load() -> C.CDLL:
         "mythos_version": (C.c_char_p, []),
         "mythos_last_error": (C.c_char_p, []),
         "mythos_device_count": (C.c_int, []),
+        "mythos_debug_set": (C.c_int, [C.c_int, C.c_int64]),
+        "mythos_debug_get": (C.c_int64, [C.c_int]),
         "mythos_oxdna_param_count": (C.c_int, []),
         "mythos_oxdna_param_name": (C.c_char_p, [C.c_int]),
         "mythos_oxdna_create": (V, [C.c_int, C.c_int, c_int_p, c_uint8_p, C.c_int, c_int_p, c_double_p, C.c_int, C.c_int]),
@@ -74,9 +76,11 @@ def load() -> C.CDLL:
         "mythos_langevin_get_step": (C.c_int64, [V]),
         "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
         "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "mythos_langevin_set_option": (C.c_int, [V, C.c_int, C.c_int64]),
         "mythos_langevin_set_timing": (C.c_int, [V, C.c_int]),
         "mythos_martini_langevin_set_timing": (C.c_int, [V, C.c_int]),
         "mythos_langevin_last_recoveries": (C.c_int, [V, C.POINTER(C.c_int)]),
+        "mythos_langevin_last_rebuilds": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_oxdna_read_trajectory": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.POINTER(C.c_int)]),
         "mythos_oxdna_write_trajectory": (C.c_int, [C.c_char_p, C.c_int, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p, C.c_int]),
         "mythos_martini_create": (
@@ -108,6 +112,8 @@ DECLARED_SYMBOLS = (
     "mythos_version",
     "mythos_last_error",
     "mythos_device_count",
+    "mythos_debug_set",
+    "mythos_debug_get",
     "mythos_oxdna_param_count",
     "mythos_oxdna_param_name",
     "mythos_oxdna_create",
@@ -137,6 +143,8 @@ DECLARED_SYMBOLS = (
     "mythos_langevin_set_step",
     "mythos_langevin_last_kernel_ms",
     "mythos_langevin_last_recoveries",
+    "mythos_langevin_last_rebuilds",
+    "mythos_langevin_set_option",
     "mythos_langevin_set_timing",
     "mythos_martini_langevin_set_timing",
     "mythos_oxdna_read_trajectory",
@@ -170,6 +178,19 @@ def check(rc: int, what: str = "") -> None:
     if rc == -6:
         raise FloatingPointError(msg)
     raise MythosHipError(msg)
+
+
+# keys of mythos_debug_set (include/mythos_hip.h: enum mythos_debug_key) - test and diagnostic switches
+DEBUG_KEYS = {"cell_bucket_cap": 0, "energy_list_cap": 1, "md_segment": 2, "md_overflow_at": 3}
+
+
+def debug_set(key: str, value: int) -> None:
+    """Process-wide test / diagnostic switch of the library; 0 restores the default."""
+    check(load().mythos_debug_set(DEBUG_KEYS[key], int(value)), f"debug_set({key})")
+
+
+def debug_get(key: str) -> int:
+    return int(load().mythos_debug_get(DEBUG_KEYS[key]))
 
 
 def param_names() -> list[str]:

@@ -1,4 +1,5 @@
 // C-ABI entry points of libmythos_hip.so (declared in include/mythos_hip.h).
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -14,6 +15,13 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int hip_fail(hipError_t e, const char* what) {
   g_last_error = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
   return MYTHOS_ERR_HIP;
+}
+
+static std::atomic<long long> g_debug[MYTHOS_DEBUG_KEYS];
+
+long long debug_value(int key) { return (key >= 0 && key < MYTHOS_DEBUG_KEYS) ? g_debug[key].load(std::memory_order_relaxed) : 0; }
+void debug_clear(int key) {
+  if (key >= 0 && key < MYTHOS_DEBUG_KEYS) g_debug[key].store(0, std::memory_order_relaxed);
 }
 
 static const char* const kParamNames[] = {
@@ -37,6 +45,17 @@ int mythos_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+
+int mythos_debug_set(int key, int64_t value) {
+  if (key < 0 || key >= MYTHOS_DEBUG_KEYS || value < 0) {
+    set_error("mythos_debug_set: unknown key or negative value");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  g_debug[key].store((long long)value, std::memory_order_relaxed);
+  return MYTHOS_OK;
+}
+
+int64_t mythos_debug_get(int key) { return (int64_t)debug_value(key); }
 
 int mythos_oxdna_param_count(void) { return (int)OXP_COUNT; }
 
@@ -177,6 +196,7 @@ int mythos_oxdna_set_params(mythos_system_t* s, const double* flat, int n_params
   MYTHOS_HIP_TRY(hipMemcpy(s->d_pd, s->pd_sets.data(), total * sizeof(double), hipMemcpyHostToDevice));
   s->params_set = true;
   ++s->list_epoch;  // cut-offs may have moved: integrators rebuild their list
+  ++s->param_epoch; // ... and re-derive the site offsets their resident frames carry
   return MYTHOS_OK;
 }
 
@@ -194,6 +214,8 @@ int mythos_oxdna_set_nucleotide_types(mythos_system_t* s, const uint8_t* is_rna)
   MYTHOS_HIP_TRY(hipDeviceSynchronize());
   MYTHOS_HIP_TRY(hipMemcpy(s->d_meta, s->h_meta.data(), s->n * sizeof(int), hipMemcpyHostToDevice));
   s->types_set = true;
+  ++s->list_epoch;
+  ++s->param_epoch;
   return MYTHOS_OK;
 }
 
@@ -223,10 +245,46 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
     }
   }
   for (size_t k = 0; k < 4 * (size_t)n; ++k)
-    if (!std::isfinite(marginals[k])) {
-      set_error("mythos_oxdna_set_pseq: non-finite probability");
+    if (!std::isfinite(marginals[k]) || marginals[k] < 0.0) {
+      set_error("mythos_oxdna_set_pseq: non-finite or negative probability");
       return MYTHOS_ERR_NUMERIC;
     }
+  for (size_t k = 0; k < 4 * (size_t)n_bp; ++k)
+    if (!std::isfinite(bp_probs[k]) || bp_probs[k] < 0.0) {
+      set_error("mythos_oxdna_set_pseq: non-finite or negative base-pair type probability");
+      return MYTHOS_ERR_NUMERIC;
+    }
+  {
+    // every constrained base pair has exactly one member 0 and one member 1 (the kernels split a pair's contribution
+    // half and half between its two visits), and a member's marginal is what its pair's type distribution implies:
+    // types AT, TA, GC, CG give member 0 the bases A, T, G, C and member 1 the bases T, A, C, G (A, C, G, T = 0 .. 3)
+    std::vector<int> owner(2 * (size_t)n_bp, -1);
+    for (int i = 0; i < n; ++i) {
+      const int u = unit[i];
+      if (u < 0) continue;
+      if (owner[u] >= 0) {
+        set_error("mythos_oxdna_set_pseq: nucleotides " + std::to_string(owner[u]) + " and " + std::to_string(i) +
+                  " claim the same place of base pair " + std::to_string(u >> 1));
+        return MYTHOS_ERR_INVALID_ARGUMENT;
+      }
+      owner[u] = i;
+    }
+    static const int kBase[2][4] = {{0, 3, 2, 1}, {3, 0, 1, 2}};
+    for (int u = 0; u < 2 * n_bp; ++u) {
+      if (owner[u] < 0) {
+        set_error("mythos_oxdna_set_pseq: base pair " + std::to_string(u >> 1) + " has no member " + std::to_string(u & 1));
+        return MYTHOS_ERR_INVALID_ARGUMENT;
+      }
+      double implied[4] = {0, 0, 0, 0};
+      for (int t = 0; t < 4; ++t) implied[kBase[u & 1][t]] += bp_probs[4 * (size_t)(u >> 1) + t];
+      for (int b = 0; b < 4; ++b)
+        if (std::fabs(implied[b] - marginals[4 * (size_t)owner[u] + b]) > 1e-6) {
+          set_error("mythos_oxdna_set_pseq: the marginal of nucleotide " + std::to_string(owner[u]) +
+                    " is not the one its base pair's type probabilities imply");
+          return MYTHOS_ERR_INVALID_ARGUMENT;
+        }
+    }
+  }
   const size_t word = s->dtype == MYTHOS_F32 ? sizeof(float) : sizeof(double);
   const int nb = std::max(n_bp, 1);
   if (!s->d_ps_marg) MYTHOS_HIP_TRY(hipMalloc(&s->d_ps_marg, 4 * (size_t)n * word));
@@ -318,12 +376,7 @@ int mythos_oxdna_energy_dpseq(mythos_system_t* s, const void* center, const void
     set_error("mythos_oxdna_energy_dpseq: invalid argument (dU_dparams and both distribution-gradient buffers are required)");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (s->model == 4) {
-    set_error("mythos_oxdna_energy_dpseq: not available for oxNA systems (model 4); their energies and dU/dparams honour the "
-              "distribution, the gradient with respect to it is not accumulated");
-    return MYTHOS_ERR_INVALID_ARGUMENT;
-  }
-  if (!s->params_set || !s->nbrs_set || s->pseq_terms == 0) {
+  if (!s->params_set || !s->nbrs_set || s->pseq_terms == 0 || (s->model == 4 && !s->types_set)) {
     set_error("mythos_oxdna_energy_dpseq: parameters, neighbours and a probabilistic sequence (mythos_oxdna_set_pseq) must be set first");
     return MYTHOS_ERR_NOT_READY;
   }

@@ -206,14 +206,12 @@ static __global__ __launch_bounds__(256) void cell_sort_bins_kernel(int H, const
   }
 }
 
-// MYTHOS_CELL_BUCKET_CAP=<places>: fixes the bucket capacity (no growth), e.g. to a handful of places to exercise
-// the spill path in tests.  0 / unset: managed by the callers.
+// mythos_debug_set(MYTHOS_DEBUG_CELL_BUCKET_CAP, places): fixes the bucket capacity (no growth), e.g. to a handful of
+// places to exercise the spill path in tests.  0: managed by the callers.
+long long debug_value(int key);
 static inline int cell_cap_override() {
-  static const int v = [] {
-    const char* e = getenv("MYTHOS_CELL_BUCKET_CAP");
-    return e ? atoi(e) : 0;
-  }();
-  return v > 0 ? v : 0;
+  const long long v = debug_value(0 /* MYTHOS_DEBUG_CELL_BUCKET_CAP */);
+  return v > 0 ? (int)v : 0;
 }
 
 static inline int next_pow2(int v) {

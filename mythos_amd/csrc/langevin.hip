@@ -29,6 +29,15 @@
 
 #include <hip/hip_ext.h>
 
+// The fp32 stepping kernels evaluate the piecewise modulation functions (f1, f2, f4, f5) in their branch-free forms
+// and read the sequence weights with one indexed load (oxdna_math.h: MYTHOS_LEAN_MATH).  Measured on MI355X (round 3,
+// A/B of one build against the other on one box): 12 kbp 61.4 k -> 63.9 k steps/s, 100 kbp 10.7 k -> 11.3 k, 256
+// replicas of 64 nt 62.7 k -> 65.4 k; the base-pair item of the angular pass 949 VALU + 434 SALU -> 744 + 151.  fp64
+// keeps the branchy forms: with the branch-free ones the three-per-CU instantiation spilled more (29.4 k -> 25.7 k).
+#ifndef MYTHOS_LEAN_MATH
+#define MYTHOS_LEAN_MATH 1
+#endif
+
 #include "chunk_order.h"
 #include "oxdna_gather.h"
 #include "philox.h"
@@ -183,23 +192,40 @@ __device__ __forceinline__ V3<R> xyz(const typename Vec4T<R>::type& v) {
   return V3<R>{v.x, v.y, v.z};
 }
 
+#ifdef MYTHOS_MD_EXP_RADIAL_STUB  // (dev experiment, WRONG physics: the radial functions at the price of two multiplications -
+// the step's cost if tabulating f3 / Debye-Hueckel made them free; bounds what such tables can save)
+#define MD_RAD_F3(r, eps, fp) FD<R>{(r) * R(1e-4), (r) * R(-1e-4)}
+#define MD_RAD_DH(r, dhp) FD<R>{(r) * R(1e-5), (r) * R(-1e-5)}
+#define MD_RAD_SQRT(r2) (r2)
+#define MD_RAD_OVER(a, r) ((a))
+#else
+#define MD_RAD_F3(r, eps, fp) f3_eval(r, eps, fp)
+#define MD_RAD_DH(r, dhp) debye_eval(r, dhp)
+#define MD_RAD_SQRT(r2) m_sqrt(r2)
+#define MD_RAD_OVER(a, r) ((a) / (r))
+#endif
+
 // radial f3 from r^2: returns the energy and, in coef, tw * V'(r) / r (0 outside the support)
 template <typename R>
 __device__ __forceinline__ R f3_coef(R eps, R tw, const F3P<R>& fp, R r2, R& coef) {
   coef = R(0);
+#ifndef MYTHOS_MD_EXP_RADIAL_STUB
   if (r2 >= fp.rc * fp.rc) return R(0);
-  const R r = m_sqrt(r2);
-  const FD<R> v = f3_eval(r, eps, fp);
-  coef = tw * v.d / r;
+#endif
+  const R r = MD_RAD_SQRT(r2);
+  const FD<R> v = MD_RAD_F3(r, eps, fp);
+  coef = MD_RAD_OVER(tw * v.d, r);
   return v.f;
 }
 
 template <typename R>
 __device__ __forceinline__ R f3_radial(R eps, R tw, const F3P<R>& fp, V3<R> d, R r2, V3<R>& g) {
+#ifndef MYTHOS_MD_EXP_RADIAL_STUB
   if (r2 >= fp.rc * fp.rc) return R(0);
-  const R r = m_sqrt(r2);
-  const FD<R> v = f3_eval(r, eps, fp);
-  axpy(g, tw * v.d / r, d);
+#endif
+  const R r = MD_RAD_SQRT(r2);
+  const FD<R> v = MD_RAD_F3(r, eps, fp);
+  axpy(g, MD_RAD_OVER(tw * v.d, r), d);
   return v.f;
 }
 
@@ -325,7 +351,11 @@ __device__ __forceinline__ int na1_kind(int self_rna, int other_rna) { return (s
 // the launch ABORT: it raises flags[3], the host discards what that launch wrote (its inputs are intact: frames and
 // momenta ping-pong) and runs the step again with the ITEMS = 32 instantiation, which stays in use for the rest of
 // the run.  More than 32 is reported as an error (sterically that takes overlapping bases).
-template <typename R, int MODEL, bool SAVE, int ITEMS, bool DENSE = false>
+// PSEQ: the system carries a probabilistic sequence (mythos_oxdna_set_pseq): the two sequence-weight look-ups of the
+// angular pass are expectations (ConstParams<R, true>, as in the energy kernel) and the radial pass flags every pair
+// inside the hydrogen-bonding range, whatever the discrete sequence says.  Its own instantiations (with the wide work
+// lists only): the plain ones keep their registers and instruction counts.
+template <typename R, int MODEL, bool SAVE, int ITEMS, bool DENSE = false, bool PSEQ = false>
 __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>())) void md_step_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, const LangevinConst<R> K, const MdCut<R> cut, int n, const Frame<R> in,
     const Frame<R> out,
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
     const typename Vec4T<R>::type* __restrict__ ref_off, const typename Vec4T<R>::type* __restrict__ ref_a1,
     int* __restrict__ flags,
     R* __restrict__ traj_c, R* __restrict__ traj_q, double* __restrict__ e_part, const int* __restrict__ chunk_order,
-    const int* __restrict__ list_overflow, int k_index, int ablate_arg) {
+    const int* __restrict__ list_overflow, int k_index, int ablate_arg, const PseqView<R> pseq) {
   using V4 = typename Vec4T<R>::type;
   const int ablate = MD_ABLATE(ablate_arg);
   constexpr int G = kMdG, PPB = kMdPPB;
@@ -362,7 +392,11 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
   auto pool_row = [&](int row) -> R* { return res_flat + row * RW; };
   auto fixed_row = [&](int pp, int slot) -> R* { return res_flat + pp * kFixedStride + slot * RW; };
   __shared__ double e_lds[SAVE ? PPB : 1][kTraceWidth];
-  const ConstParams<R> P(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
+  using CP = ConstParams<R, PSEQ>;
+  const auto make_cp = [&](const R* g) {
+    if constexpr (PSEQ) return CP(g, pseq); else return CP(g);
+  };
+  const CP P = make_cp(Pg);  // scalar loads at the point of use; an LDS copy was measured 2.4x slower
   const int grp = threadIdx.x / G;
   const int lane = threadIdx.x % G;
   // XCD-aware order: the hardware deals consecutive workgroups round-robin to the 8 XCDs, so workgroup b
@@ -396,8 +430,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
 
   const R g_ba = P[GEO_BASE], g_st = P[GEO_STACK];
   // oxNA: the oxRNA2 vector (sites of an RNA nucleotide) and the hybrid one; P itself is the oxDNA2 vector there
-  const ConstParams<R> Prna(Pg + ((MODEL == 4) ? OXP_COUNT : 0)), Pdrh(Pg + ((MODEL == 4) ? 2 * OXP_COUNT : 0));
-  const Na1Params<ConstParams<R>> P4{P, Prna, Pdrh};
+  const CP Prna = make_cp(Pg + ((MODEL == 4) ? OXP_COUNT : 0)), Pdrh = make_cp(Pg + ((MODEL == 4) ? 2 * OXP_COUNT : 0));
+  const Na1Params<CP> P4{P, Prna, Pdrh};
 
   // ---- owner state (also parked in LDS for the block-wide angular pass)
   Nuc<R> self;
@@ -434,8 +468,8 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
   // ---- phase 1: radial pass over the unbonded slots
   const RadSet<R> rs0 = (MODEL == 4) ? radset_from<R, 2>(P, cut_from<R>(P, cut.rcom2)) : radset_from<R, MODEL>(P, cut);
   // (oxNA: the oxRNA2 and the hybrid vector follow the oxDNA2 one; the other models never read rs1 / rs2)
-  const RadSet<R> rs1 = (MODEL == 4) ? radset_from<R, 2>(ConstParams<R>(Pg + OXP_COUNT), cut_from<R>(ConstParams<R>(Pg + OXP_COUNT), cut.rcom2)) : rs0;
-  const RadSet<R> rs2 = (MODEL == 4) ? radset_from<R, 2>(ConstParams<R>(Pg + 2 * OXP_COUNT), cut_from<R>(ConstParams<R>(Pg + 2 * OXP_COUNT), cut.rcom2)) : rs0;
+  const RadSet<R> rs1 = (MODEL == 4) ? radset_from<R, 2>(Prna, cut_from<R>(Prna, cut.rcom2)) : rs0;
+  const RadSet<R> rs2 = (MODEL == 4) ? radset_from<R, 2>(Pdrh, cut_from<R>(Pdrh, cut.rcom2)) : rs0;
   int n_items[2] = {0, 0};
   const int lane64 = threadIdx.x & 63;
   const int gshift = lane64 & ~(G - 1);
@@ -444,20 +478,26 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
   // L2 / Infinity-Cache round trips overlap the arithmetic instead of serialising with it.
   // (rolled: keeping the body once in the instruction stream matters more than unrolling - the whole
   // kernel has to stay inside the instruction cache that two CUs share)
+  // (the prefetches are unconditional: an entry past the end of the segment is read from a clamped slot and replaced by
+  // -1, a missing neighbour's state is read from nucleotide 0 and never used - a load behind a lane-dependent branch
+  // made the compiler wait for ALL outstanding loads at the join, the one just issued included)
+  const int last_slot = row_stride - 1;
+  auto row_at = [&](int s, int end) -> int {
+    const int v = row[min(s, last_slot)];
+    return s < end ? v : -1;
+  };
   {
     int e_cur = -1, e_nxt = -1;
     V4 n0{}, n3{}, n1{}, nl{};
     {
       const int s = ROW_BONDED_SLOTS + lane;
-      e_cur = (s < close_end) ? row[s] : -1;
-      e_nxt = (s + G < close_end) ? row[s + G] : -1;
-      if (e_cur >= 0) {
-        const int j = e_cur & ROW_INDEX_MASK;
-        n0 = in.p0[j];
-        n3 = in.p3[j];
-        n1 = in.p1[j];
-        if constexpr (kHiLo<R>) nl = in.pl[j];
-      }
+      e_cur = row_at(s, close_end);
+      e_nxt = row_at(s + G, close_end);
+      const int j = max(e_cur, 0) & ROW_INDEX_MASK;
+      n0 = in.p0[j];
+      n3 = in.p3[j];
+      n1 = in.p1[j];
+      if constexpr (kHiLo<R>) nl = in.pl[j];
     }
 #pragma unroll 1
     for (int s0 = ROW_BONDED_SLOTS; s0 < close_end; s0 += G) {
@@ -465,9 +505,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
       const int entry = e_cur;
       const V4 o0 = n0, o3 = n3, o1 = n1, ol = nl;
       e_cur = e_nxt;
-      e_nxt = (s + 2 * G < close_end) ? row[s + 2 * G] : -1;
-      if (e_cur >= 0) {  // the close segment reads a1 as well: nearly all of its entries need it
-        const int jn = e_cur & ROW_INDEX_MASK;
+      e_nxt = row_at(s + 2 * G, close_end);
+      {  // the close segment reads a1 as well: nearly all of its entries need it
+        const int jn = max(e_cur, 0) & ROW_INDEX_MASK;
         n0 = in.p0[jn];
         n3 = in.p3[jn];
         n1 = in.p1[jn];
@@ -489,12 +529,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
           const V3<R> d = dco + offb_o - offb_s;
           const R r2 = dot(d, d);
           if (r2 < rs.rbb2) {
-            const R r = m_sqrt(r2);
-            const FD<R> v = f3_eval(r, rs.eps_n, rs.f_bb);
+            const R r = MD_RAD_SQRT(r2);
+            const FD<R> v = MD_RAD_F3(r, rs.eps_n, rs.f_bb);
             R dVdr = rs.tw_n * v.d;
             R en = v.f;
             if constexpr (MODEL >= 2) {
-              const FD<R> dh = debye_eval(r, rs.dhp);
+              const FD<R> dh = MD_RAD_DH(r, rs.dhp);
               R mult = R(1);
               if (rs.half_ends) {
                 const int mo = (int)o0.w;
@@ -504,7 +544,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
               if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
             }
             if constexpr (SAVE) e[T_NEXC] += R(0.5) * en;
-            axpy(gbk, dVdr / r, d);
+            axpy(gbk, MD_RAD_OVER(dVdr, r), d);
           }
         }
         if (close) {
@@ -539,7 +579,10 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
             flag[0] = rs.cr_lo2 < r2 && r2 < rs.cr_hi2;
             if (!flag[0] && rs.hb_lo2 < r2 && r2 < rs.hb_hi2) {  // H-bond only for pairs with a non-zero weight
               const int so = (int)o0.w & 3;
-              flag[0] = (rs.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
+              if (PSEQ && (pseq.terms & 2) != 0)
+                flag[0] = rs.hb_mask != 0u;  // the weight is an expectation over both bases: any non-zero table entry may count
+              else
+                flag[0] = (rs.hb_mask >> (role_p ? (self.seq * 4 + so) : (so * 4 + self.seq))) & 1u;
             }
           }
           {
@@ -575,14 +618,12 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
     V4 n0{}, n3{}, nl{};
     {
       const int s = close_end + lane;
-      e_cur = (s < len) ? row[s] : -1;
-      e_nxt = (s + G < len) ? row[s + G] : -1;
-      if (e_cur >= 0) {
-        const int j = e_cur & ROW_INDEX_MASK;
-        n0 = in.p0[j];
-        n3 = in.p3[j];
-        if constexpr (kHiLo<R>) nl = in.pl[j];
-      }
+      e_cur = row_at(s, len);
+      e_nxt = row_at(s + G, len);
+      const int j = max(e_cur, 0) & ROW_INDEX_MASK;
+      n0 = in.p0[j];
+      n3 = in.p3[j];
+      if constexpr (kHiLo<R>) nl = in.pl[j];
     }
 #pragma unroll 1
     for (int s0 = close_end; s0 < len; s0 += G) {
@@ -590,9 +631,9 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
       const int entry = e_cur;
       const V4 o0 = n0, o3 = n3, ol = nl;
       e_cur = e_nxt;
-      e_nxt = (s + 2 * G < len) ? row[s + 2 * G] : -1;
-      if (e_cur >= 0) {
-        const int jn = e_cur & ROW_INDEX_MASK;
+      e_nxt = row_at(s + 2 * G, len);
+      {
+        const int jn = max(e_cur, 0) & ROW_INDEX_MASK;
         n0 = in.p0[jn];
         n3 = in.p3[jn];
         if constexpr (kHiLo<R>) nl = in.pl[jn];
@@ -603,11 +644,11 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         const V3<R> d = dco + xyz<R>(o3) - offb_s;
         const R r2 = dot(d, d);
         if (r2 < rs.rbb2) {
-          const R r = m_sqrt(r2);
-          const FD<R> v = f3_eval(r, rs.eps_n, rs.f_bb);
+          const R r = MD_RAD_SQRT(r2);
+          const FD<R> v = MD_RAD_F3(r, rs.eps_n, rs.f_bb);
           R dVdr = rs.tw_n * v.d;
           if constexpr (MODEL >= 2) {
-            const FD<R> dh = debye_eval(r, rs.dhp);
+            const FD<R> dh = MD_RAD_DH(r, rs.dhp);
             R mult = R(1);
             if (rs.half_ends) {
               const int mo = (int)o0.w;
@@ -617,7 +658,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
             if constexpr (SAVE) e[T_DH] += R(0.5) * mult * dh.f;
           }
           if constexpr (SAVE) e[T_NEXC] += R(0.5) * v.f;
-          axpy(gbk, dVdr / r, d);
+          axpy(gbk, MD_RAD_OVER(dVdr, r), d);
         }
       }
     }
@@ -738,6 +779,7 @@ __global__ __launch_bounds__(kMdBlock, (md_blocks_per_cu<R, SAVE, ITEMS, DENSE>(
         me.seq = mm & 3;
         me.is_end = (mm >> 2) & 1;
         me.rna = (mm >> 3) & 1;
+        me.idx = ip, o.idx = j;  // (read only by the expectation of a probabilistic sequence)
         const V4 o0 = in.p0[j], o1 = in.p1[j], o2 = in.p2[j];
         V4 ol{};
         if constexpr (kHiLo<R>) ol = in.pl[j];
@@ -1072,6 +1114,25 @@ __global__ void unpack_state_kernel(int n, const Frame<R> f, R* __restrict__ c, 
   l[3 * i] = w.x, l[3 * i + 1] = w.y, l[3 * i + 2] = w.z;
 }
 
+// Parameters (site geometry) or nucleotide types were replaced while a state is resident: the words of the frame that
+// were derived from them - the meta word and the backbone offset - are derived again from the quaternion.
+template <typename R, int BX>
+__global__ void rederive_frame_kernel(int n, R g_k1, R g_k2, R r_k1, R r_k2, const int* __restrict__ meta, const Frame<R> f) {
+  using V4 = typename Vec4T<R>::type;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const V4 q = f.q[i];
+  V3<R> a1, a2, a3;
+  quat_axes(q.x, q.y, q.z, q.w, a1, a2, a3);
+  V4 c = f.p0[i];
+  c.w = R(meta[i]);
+  f.p0[i] = c;
+  const bool rna = BX == 0 && ((meta[i] >> 3) & 1);
+  const V3<R> ab = (BX == 3 || rna) ? a3 : a2;
+  const R k1 = rna ? r_k1 : g_k1, k2 = rna ? r_k2 : g_k2;
+  f.p3[i] = V4{k1 * a1.x + k2 * ab.x, k1 * a1.y + k2 * ab.y, k1 * a1.z + k2 * ab.z, R(0)};
+}
+
 // Maxwell-Boltzmann momenta; the centre-of-mass momentum is removed (jax_md initialize_momenta
 // with center_velocity=True).  Single block: n is at most a few 10^4 and this runs once.
 template <typename R>
@@ -1125,6 +1186,9 @@ struct mythos_sim {
   bool keep_valid = false;
   static constexpr int kCtlWords = 4;  // [0] error bits (2 NaN), [1] halt, [2] progress, [3] aborted launch + 1
   bool items_big = false;              // the ITEMS = 32 instantiation is in use (a launch of this load found 16 too few)
+  bool want_unfused = false;           // mythos_langevin_set_option(MYTHOS_LANGEVIN_UNFUSED): takes effect at the next load
+  bool unfused = false;                // the resident state lives in the unfused path's buffers (decided by load)
+  int param_epoch = 0;                 // sys->param_epoch the packed site offsets of the resident frames were derived from
   int* d_flags = nullptr;
   // control words as the device published them at the end of a segment: [0..3] d_flags, [4..6] the list builder's
   // overflow words.  Pinned host memory the publishing kernel writes directly: one stream synchronisation per
@@ -1132,6 +1196,7 @@ struct mythos_sim {
   int* h_ctl = nullptr;
   int* d_ctl = nullptr;          // device address of h_ctl
   int last_recoveries = 0;       // halts of the last run that were rebuilt and resumed
+  int last_rebuilds = 0;         // scheduled list rebuilds inside the last advance (the first build of a list not counted)
   bool list_fitted = false;      // a synchronising, growing build has sized rows and buckets for this integrator
   int* d_chunk_order = nullptr;  // [blocks] spatial order of the 32-nucleotide chunks (null: index order)
   unsigned long long* d_chunk_keys = nullptr;
@@ -1242,6 +1307,7 @@ static int load_typed(mythos_sim* sim, const R* center, const R* quat, const R* 
   sim->list_valid = false;
   sim->since_build = 0;
   sim->items_big = false;
+  sim->param_epoch = sys->param_epoch;
   return update_chunk_order<R>(sim, f0.p0, (n + kMdPPB - 1) / kMdPPB, st);
 }
 
@@ -1276,6 +1342,15 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
   const MdCut<R> cut = make_cut<R>(sys);
   const Frame<R> fr[2] = {frame_of<R>(sim, 0), frame_of<R>(sim, 1)};
   int cur = sim->cur;
+  if (sim->param_epoch != sys->param_epoch) {  // mythos_oxdna_set_params / set_nucleotide_types since the load
+    const OxParams<R>& Ph = params_of<R>(sys);
+    const double* Prna = oxdna_param_set(sys, sys->param_sets() == 1 ? 0 : 1);
+    hipLaunchKernelGGL((rederive_frame_kernel<R, (MODEL == 4 ? 0 : back_axis<MODEL>())>), dim3((n + 255) / 256), dim3(256), 0, st, n,
+                       Ph[GEO_BACK_A1], (MODEL >= 2) ? Ph[GEO_BACK_A2] : R(0), R(Prna[GEO_BACK_A1]), R(Prna[GEO_BACK_A2]),
+                       (const int*)sys->d_meta, fr[cur]);
+    MYTHOS_HIP_TRY(hipGetLastError());
+    sim->param_epoch = sys->param_epoch;
+  }
 #ifdef MYTHOS_MD_DIAG
   const char* abl = getenv("MYTHOS_MD_ABLATE");  // profiling aid: bit 0/1/2 skip radial / angular / integrate
   const int ablate = abl ? atoi(abl) : 0;
@@ -1284,6 +1359,13 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
 #endif
   const bool dynamic_list = sim->rebuild_every > 0;
   const bool timing = sim->timing_samples > 0;
+  // a probabilistic sequence (mythos_oxdna_set_pseq): the PSEQ instantiations, which exist with the wide work lists only
+  PseqView<R> pseq;
+  const bool use_pseq = sys->pseq_terms != 0;
+  if (use_pseq) {
+    pseq.marg = (const R*)sys->d_ps_marg, pseq.unit = sys->d_ps_unit, pseq.bp = (const R*)sys->d_ps_bp, pseq.terms = sys->pseq_terms;
+    sim->items_big = true;
+  }
   auto rebuild = [&](int buf) -> int {
     if ((++sim->builds & 63) == 0)
       if (int rc = update_chunk_order<R>(sim, fr[buf].p0, blocks, st)) return rc;
@@ -1307,7 +1389,7 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
     sim->list_valid = true;
   }
   if (timing) MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
-  int launches = 0, samples = 0, recoveries = 0;
+  int launches = 0, samples = 0, recoveries = 0, scheduled_rebuilds = 0;
   const int max_samples = std::min(sim->timing_samples, (int)mythos_sim::kMaxSamples);  // 0: no dispatch is bracketed
   const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
   int* halt_words = dynamic_list ? sys->d_overflow : nullptr;
@@ -1316,11 +1398,17 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
   // (they return at once); the host then rebuilds at the last valid state - growing what overflowed - and resumes
   // there.  A run never integrates on a stale or truncated list, and neither condition is an error any more; what
   // it costs is the empty launches behind the halt (at most a segment) and a synchronisation.
-  constexpr int kSegment = 8192, kMaxRecoveries = 64;
+  constexpr int kMaxRecoveries = 64;
+  const long long dbg_seg = debug_value(MYTHOS_DEBUG_MD_SEGMENT);
+  const int kSegment = dbg_seg > 0 ? (int)std::min<long long>(dbg_seg, 1 << 20) : 8192;
   int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
   int err_bits = 0, ovw[kOverflowWords] = {0, 0, 0};
   while (k <= n_steps) {
     const int seg_end = std::min(n_steps, k + seg_len - 1);
+    // The device's progress word (flags[2], cleared by publish_ctl_kernel after every segment) says nothing when the
+    // FIRST launch of a segment halts before writing it (a scheduled rebuild in front of it overflowed): the launches
+    // of the earlier segments count all the same.
+    const int seg_start = k;
     for (; k <= seg_end; ++k) {
       const bool last = (k == n_steps);
       const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
@@ -1328,6 +1416,11 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       if (dynamic_list && !last && k - built_at >= sim->rebuild_every) {
         if (int rc = rebuild(cur)) return rc;
         built_at = k;
+        ++scheduled_rebuilds;
+        if (debug_value(MYTHOS_DEBUG_MD_OVERFLOW_AT) == k + 1) {  // test hook: this build claims a row did not fit
+          debug_clear(MYTHOS_DEBUG_MD_OVERFLOW_AT);
+          MYTHOS_HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)sys->d_overflow, sys->row_stride + 1, 1, st));
+        }
       }
       const R kick_close = (k == 0) ? R(0) : R(0.5);
       const int do_step = last ? 0 : 1;
@@ -1337,16 +1430,32 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       const V4* ref_off = (const V4*)sys->d_ref_off;
       const V4* ref_a1 = (const V4*)sys->d_ref_a1;
       const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
+      auto launch_pseq = [&](auto save_tag, hipEvent_t ea, hipEvent_t eb) {  // (the wide work lists only, see md_step_kernel)
+        constexpr bool SV = decltype(save_tag)::value;
+        hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, SV, md_items_big<R, SV>(), false, true>), dim3(grid), dim3(kMdBlock), 0, st, ea, eb, 0,
+                              Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], sys->d_rows, sys->d_row_len, row_close_of(sys),
+                              sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k), ref,
+                              ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate, pseq);
+      };
       auto launch = [&](auto save_tag, auto items_tag, hipEvent_t ea, hipEvent_t eb) {
         constexpr bool SV = decltype(save_tag)::value;
         constexpr int IT = decltype(items_tag)::value;
         // with events: the pair receives the begin / end time stamps of THIS dispatch (the same stamps a profiler's
         // kernel trace reports), not the time between two markers in the queue
         auto go = [&](auto dense_tag) {
+#ifdef MYTHOS_MD_PLAIN_LAUNCH  // (dev A/B: the host cost of the two launch calls)
+          if (!ea && !eb) {
+            hipLaunchKernelGGL((md_step_kernel<R, MODEL, SV, IT, decltype(dense_tag)::value>), dim3(grid), dim3(kMdBlock), 0, st,
+                               Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], sys->d_rows, sys->d_row_len, row_close_of(sys),
+                               sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k), ref,
+                               ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate, PseqView<R>{});
+            return;
+          }
+#endif
           hipExtLaunchKernelGGL((md_step_kernel<R, MODEL, SV, IT, decltype(dense_tag)::value>), dim3(grid), dim3(kMdBlock), 0, st, ea, eb, 0,
                                 Pdev, box, K, cut, n, fr[cur], fr[cur ^ 1], sys->d_rows, sys->d_row_len, row_close_of(sys),
                                 sys->row_stride, sys->extra_bonds ? 1 : 0, kick_close, do_step, sim->seed, (uint64_t)(sim->step + k), ref,
-                                ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate);
+                                ref_off, ref_a1, sim->d_flags, tc, tq, sim->d_epart, sim->d_chunk_order, halt_words, k, ablate, PseqView<R>{});
         };
         if constexpr (sizeof(R) == 8 && !SV && IT == kMdItems) {
           if (grid > 2 * sim_cus) go(std::true_type{}); else go(std::false_type{});
@@ -1361,7 +1470,12 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
       using BigN = std::integral_constant<int, md_items_big<R, false>()>;
       hipEvent_t ea = nullptr, eb = nullptr;
       if (sampled) ea = sim->sa[samples], eb = sim->sb[samples], ++samples;
-      if (save) {
+      if (use_pseq) {
+        if (save) launch_pseq(T{}, ea, eb); else launch_pseq(F{}, ea, eb);
+        if (save)
+          hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
+                             e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
+      } else if (save) {
         if (sim->items_big) launch(T{}, BigS{}, ea, eb); else launch(T{}, Small{}, ea, eb);
         hipLaunchKernelGGL(reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
                            e_trace ? e_trace + (size_t)sidx * kTraceWidth : nullptr);
@@ -1395,20 +1509,21 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
     } else if (!dynamic_list) {
       break;  // (a static list cannot halt; defensive)
     }
+    // kernels 0 .. ran-1 count; the state they left is in the frame kernel `ran` reads (an aborted launch and
+    // everything behind it do not count: their inputs are untouched)
+    const int progressed = std::max(ctl[2], seg_start);
+    const int ran = aborted != 0 ? std::min(progressed, aborted - 1) : progressed;
     if (++recoveries > kMaxRecoveries) {
-      sim->cur ^= (ctl[2] & 1);  // positions after the last step that counted, momenta short of its closing half kick
-      sim->step += ctl[2];
+      sim->cur ^= (ran & 1);  // positions after the last step that counted, momenta short of its closing half kick
+      sim->step += ran;
       set_error("mythos_langevin_run: the neighbour list had to be rebuilt out of turn more than " + std::to_string(kMaxRecoveries) +
                 " times in one run: the skin (" + std::to_string(sim->skin) + ") is too small for a rebuild every " +
                 std::to_string(sim->rebuild_every) + " steps");
       return MYTHOS_ERR_OVERFLOW;
     }
-    // kernels 0 .. ran-1 count; the state they left is in the frame kernel `ran` reads (an aborted launch and
-    // everything behind it do not count: their inputs are untouched)
-    const int ran = aborted != 0 ? std::min(ctl[2], aborted - 1) : ctl[2];
     cur = sim->cur ^ (ran & 1);
     k = ran;
-    seg_len = std::max(256, seg_len / 4);
+    seg_len = std::max(std::min(256, kSegment), seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, 3 * sizeof(int), st));
     if (dynamic_list) {
       if (int rc = rows_build_until_fit(sys, fr[cur].p0, true, sim->r_cut, sim->skin, fr[cur].p3, fr[cur].p1, true, true, st))
@@ -1418,6 +1533,7 @@ static int advance_typed(mythos_sim* sim, int n_steps, int save_every, R* traj_c
     ovw[0] = ovw[1] = 0;
   }
   sim->last_recoveries = recoveries;
+  sim->last_rebuilds = scheduled_rebuilds;
   sim->cur = cur;
   sim->since_build = n_steps - built_at;
   if (timing) {
@@ -1787,15 +1903,12 @@ int mythos_langevin_init_momenta(mythos_sim_t* s, void* p_lin, void* p_ang, myth
 
 namespace {
 
-// what every entry that launches step kernels checks first
-int md_ready(mythos_sim_t* s, const char* who) {
+// what a state needs before it can be packed into frames: the site geometry (parameters) and, for oxNA, the types that
+// choose between the two geometries
+int md_ready_state(mythos_sim_t* s, const char* who) {
   mythos_system* sys = s->sys;
-  if (!sys->params_set || (!sys->nbrs_set && s->rebuild_every <= 0)) {
-    set_error(std::string(who) + ": parameters and neighbours (or a neighbour policy) must be set first");
-    return MYTHOS_ERR_NOT_READY;
-  }
-  if (sys->pseq_terms != 0) {
-    set_error(std::string(who) + ": the system carries a probabilistic sequence (mythos_oxdna_set_pseq); dynamics need a discrete one");
+  if (!sys->params_set) {
+    set_error(std::string(who) + ": parameters must be set first");
     return MYTHOS_ERR_NOT_READY;
   }
   if (sys->model == 4 && !sys->types_set) {
@@ -1803,6 +1916,17 @@ int md_ready(mythos_sim_t* s, const char* who) {
     return MYTHOS_ERR_NOT_READY;
   }
   MYTHOS_HIP_TRY(hipSetDevice(sys->device));
+  return MYTHOS_OK;
+}
+
+// what every entry that launches step kernels checks first
+int md_ready(mythos_sim_t* s, const char* who) {
+  mythos_system* sys = s->sys;
+  if (int rc = md_ready_state(s, who)) return rc;
+  if (!sys->nbrs_set && s->rebuild_every <= 0) {
+    set_error(std::string(who) + ": parameters and neighbours (or a neighbour policy) must be set first");
+    return MYTHOS_ERR_NOT_READY;
+  }
   if (s->rebuild_every > 0 && sys->row_stride == 0)
     if (int rc = rows_reserve(sys, 64)) return rc;
   if (s->list_epoch != sys->list_epoch) {  // parameters or rows were replaced behind the integrator's back
@@ -1812,17 +1936,14 @@ int md_ready(mythos_sim_t* s, const char* who) {
   return MYTHOS_OK;
 }
 
-// oxNA systems step through the fused kernel's MODEL 4 instantiation; MYTHOS_NA1_UNFUSED=1 selects the two-launch path
-// (the energy kernel's forces + unfused_integrate_kernel) instead - a second implementation the tests hold the first to
-static bool na1_unfused(const mythos_system* sys) {
-  if (sys->model != 4) return false;
-  const char* v = getenv("MYTHOS_NA1_UNFUSED");
-  return v != nullptr && v[0] == '1';
-}
+// oxNA systems step through the fused kernel's MODEL 4 instantiation; mythos_langevin_set_option(MYTHOS_LANGEVIN_UNFUSED)
+// selects the two-launch path (the energy kernel's forces + unfused_integrate_kernel) instead - a second implementation
+// the tests hold the first to.  The choice is made when a state is loaded and holds while that state is resident.
 
 int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
   mythos_system* sys = s->sys;
-  if (na1_unfused(sys))
+  s->unfused = s->want_unfused && sys->model == 4;
+  if (s->unfused)
     return sys->dtype == MYTHOS_F32 ? unfused_load<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
                                     : unfused_load<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (sys->dtype == MYTHOS_F32)
@@ -1838,7 +1959,7 @@ int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st)
 
 int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
   mythos_system* sys = s->sys;
-  if (na1_unfused(sys))
+  if (s->unfused)
     return sys->dtype == MYTHOS_F32 ? unfused_advance<float>(s, n_steps, save_every, (float*)tc, (float*)tq, e_trace, st)
                                     : unfused_advance<double>(s, n_steps, save_every, (double*)tc, (double*)tq, e_trace, st);
   if (sys->dtype == MYTHOS_F32)
@@ -1853,7 +1974,7 @@ int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq,
 }
 
 int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
-  if (na1_unfused(s->sys))
+  if (s->unfused)
     return s->sys->dtype == MYTHOS_F32 ? unfused_store<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st)
                                        : unfused_store<double>(s, (double*)c, (double*)q, (double*)p, (double*)l, st);
   if (s->sys->dtype == MYTHOS_F32) return store_typed<float>(s, (float*)c, (float*)q, (float*)p, (float*)l, st);
@@ -1884,11 +2005,7 @@ int mythos_langevin_load(mythos_sim_t* s, const void* center, const void* quat, 
     set_error("mythos_langevin_load: invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
-  if (!s->sys->params_set) {
-    set_error("mythos_langevin_load: parameters must be set first");
-    return MYTHOS_ERR_NOT_READY;
-  }
-  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  if (int rc = md_ready_state(s, "mythos_langevin_load")) return rc;
   return md_load(s, (void*)center, (void*)quat, (void*)p_lin, (void*)p_ang, (hipStream_t)stream);
 }
 
@@ -1950,6 +2067,28 @@ int mythos_langevin_last_recoveries(const mythos_sim_t* s, int* recoveries) {
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   *recoveries = s->last_recoveries;
+  return MYTHOS_OK;
+}
+
+int mythos_langevin_last_rebuilds(const mythos_sim_t* s, int* scheduled) {
+  if (!s || !scheduled) {
+    set_error("mythos_langevin_last_rebuilds: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  *scheduled = s->last_rebuilds;
+  return MYTHOS_OK;
+}
+
+int mythos_langevin_set_option(mythos_sim_t* s, int option, int64_t value) {
+  if (!s || option != MYTHOS_LANGEVIN_UNFUSED || (value != 0 && value != 1)) {
+    set_error("mythos_langevin_set_option: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (value == 1 && s->sys->model != 4) {
+    set_error("mythos_langevin_set_option: the unfused path exists for oxNA systems (model 4) only");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->want_unfused = value == 1;
   return MYTHOS_OK;
 }
 

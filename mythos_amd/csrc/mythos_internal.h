@@ -15,6 +15,9 @@ namespace mythos {
 
 void set_error(const std::string& msg);
 int hip_fail(hipError_t e, const char* what);
+// test / diagnostic switches (mythos_debug_set): process-wide, 0 = default
+long long debug_value(int key);
+void debug_clear(int key);
 
 #define MYTHOS_HIP_TRY(expr)                                   \
   do {                                                         \
@@ -63,6 +66,7 @@ struct mythos_system {
   size_t rows_cap = 0;  // allocated ints in d_rows
   bool nbrs_set = false;
   int list_epoch = 0;  // bumped when parameters or rows are replaced through the ABI (integrators re-validate their list)
+  int param_epoch = 0; // bumped when parameters or nucleotide types are replaced (integrators re-derive the site offsets they carry)
   // host copy of the bonded partners, [n][2]
   std::vector<int> h_partners;
   bool extra_bonds = false;  // some nucleotide uses slot 2 or 3 (circular strands)

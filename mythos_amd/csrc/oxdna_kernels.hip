@@ -94,8 +94,12 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   //  na1/hydrogen_bonding.py:243-304)
   const auto P = [&] {
     if constexpr (MODEL == 4) {
-      using CP = ConstParams<R, true>;
-      return Na1Params<CP>{CP(Pg, pseq), CP(Pg + OXP_COUNT, pseq), CP(Pg + 2 * OXP_COUNT, pseq)};
+      // (MODE 3: dU/d(distribution) through the hydrogen-bonding weight of whichever vector a pair takes,
+      //  na1/hydrogen_bonding.py:127-128, 243-304: all three views add into the same two buffers of this frame)
+      using CP = ConstParams<R, true, MODE == 3>;
+      PseqView<R> ps = pseq;
+      if constexpr (MODE == 3) ps.gmarg += (size_t)blockIdx.y * n * 4, ps.gbp += (size_t)blockIdx.y * ps.bp_rows * 4;
+      return Na1Params<CP>{CP(Pg, ps), CP(Pg + OXP_COUNT, ps), CP(Pg + 2 * OXP_COUNT, ps)};
     } else {
 #ifdef MYTHOS_EN_NO_PSEQ  // (dev A/B)
       return ConstParams<R, false>(Pg);
@@ -349,9 +353,8 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   }
   // LDS lists of the row walk: a row is walked in segments of list_cap entries (gather_row)
   int list_cap = std::min(sys->row_stride, kEnergyListCap);
-  if (const char* ov = getenv("MYTHOS_ENERGY_LIST_CAP")) {  // test hook: short segments on small systems
-    const int v = atoi(ov);
-    if (v >= 8 && v <= kEnergyListCap) list_cap = std::min(list_cap, v);
+  if (const long long v = debug_value(MYTHOS_DEBUG_ENERGY_LIST_CAP)) {  // test hook: short segments on small systems
+    if (v >= 8 && v <= kEnergyListCap) list_cap = std::min(list_cap, (int)v);
   }
   ObsView obs;  // width 0: no epilogue
   if (oset && obs_out) {
@@ -389,9 +392,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
     using F = std::false_type;
     if (mode == 0) { if (fuse) by_seg(std::integral_constant<int, 0>{}, T{}); else by_seg(std::integral_constant<int, 0>{}, F{}); }
     else if (mode == 1) by_seg(std::integral_constant<int, 1>{}, F{});
-    else if (mode == 3) {
-      if constexpr (MODEL != 4) by_seg(std::integral_constant<int, 3>{}, F{});  // (oxNA systems take no sequence distribution)
-    }
+    else if (mode == 3) by_seg(std::integral_constant<int, 3>{}, F{});
     else { if (fuse) by_seg(std::integral_constant<int, 2>{}, T{}); else by_seg(std::integral_constant<int, 2>{}, F{}); }
     if (obs.width > 0 && !fuse) {
       MYTHOS_HIP_TRY(hipGetLastError());

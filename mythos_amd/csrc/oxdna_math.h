@@ -136,6 +136,17 @@ struct FD {  // value and derivative with respect to the argument
 
 constexpr double kPi = 3.14159265358979323846;
 
+// MYTHOS_LEAN_MATH (set by langevin.hip for the stepping kernels: 1 = the fp32 instantiations, 2 = both precisions):
+// branch-free forms of the piecewise modulation functions - all pieces computed, then selected - instead of divergent
+// three-way branches (every piece is executed anyway as soon as the lanes of a wavefront disagree, plus the exec-mask
+// traffic around it).  Equal to the branchy forms except AT the breakpoints, where the reference's strict inequalities
+// give 0 (a removable discontinuity) and these forms give the continuous value.
+#ifndef MYTHOS_LEAN_MATH
+#define MYTHOS_LEAN_MATH 0
+#endif
+template <typename R>
+constexpr bool kLeanMath = (MYTHOS_LEAN_MATH == 2) || ((MYTHOS_LEAN_MATH == 1) && sizeof(R) == 4);
+
 // No-op / real sinks for parameter partials.  A sink receives (index, dV/dparam).
 struct NoPG {
   static constexpr bool on = false;
@@ -159,6 +170,17 @@ __device__ __forceinline__ FD<R> acos_clamped(R c) {
 template <typename R, class PT>
 __device__ __forceinline__ FD<R> f1_eval(R r, const PT& P, int b) {
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3];
+  if constexpr (kLeanMath<R>) {  // all three pieces, then selects (see f4_eval_lean; equal to the branchy form off the breakpoints)
+    const R a = P[b + 4];
+    const R e = m_exp(-a * (r - P[b + 5]));
+    const bool lo = r < rlow;
+    const R t = (lo ? rclow : rchigh) - r, bq = lo ? P[b + 7] : P[b + 8];
+    const bool core = rlow < r && r < rhigh, tail = (rclow < r && lo) || (rhigh < r && r < rchigh);
+    FD<R> o;
+    o.f = core ? (R(1) - e) * (R(1) - e) - P[b + 9] : (tail ? bq * t * t : R(0));
+    o.d = core ? R(2) * a * e * (R(1) - e) : (tail ? R(-2) * bq * t : R(0));
+    return o;
+  }
   FD<R> o{R(0), R(0)};
   if (rlow < r && r < rhigh) {
     const R a = P[b + 4];
@@ -202,6 +224,16 @@ __device__ __forceinline__ void f1_pgrad(R r, const PT& P, int b, R scale, PG& p
 template <typename R, class PT>
 __device__ __forceinline__ FD<R> f2_eval(R r, const PT& P, int b) {
   const R rlow = P[b + 0], rhigh = P[b + 1], rclow = P[b + 2], rchigh = P[b + 3], k = P[b + 4];
+  if constexpr (kLeanMath<R>) {
+    const R x = r - P[b + 5];
+    const bool lo = r < rlow;
+    const R t = (lo ? rclow : rchigh) - r, kb = k * (lo ? P[b + 7] : P[b + 8]);
+    const bool core = rlow < r && r < rhigh, tail = (rclow < r && lo) || (rhigh < r && r < rchigh);
+    FD<R> o;
+    o.f = core ? k * (R(0.5) * x * x - P[b + 9]) : (tail ? kb * t * t : R(0));
+    o.d = core ? k * x : (tail ? R(-2) * kb * t : R(0));
+    return o;
+  }
   FD<R> o{R(0), R(0)};
   if (rlow < r && r < rhigh) {
     const R x = r - P[b + 5];
@@ -313,8 +345,26 @@ __device__ __forceinline__ F4P<R> f4_params_sel(const PT& P, bool first, int ba,
   return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
           first ? P[ba + 3] : P[bb + 3], first ? P[ba + 4] : P[bb + 4], first ? ba : bb};
 }
+// Branch-free form for the fp32 stepping kernels (MYTHOS_LEAN_MATH, set by langevin.hip): f4 is symmetric about t0, so
+// one |x| serves both tails; the three pieces are computed and selected (15 VALU, no exec-mask traffic) instead of the
+// three-way divergent branch.  The only difference from the branchy form: at the exact breakpoints |x| == ts, where the
+// reference's strict inequalities give 0 (a removable discontinuity), this form gives the continuous value.
+template <typename R>
+__device__ __forceinline__ FD<R> f4_eval_lean(R th, const F4P<R>& p) {
+  const R x = th - p.t0;
+  const R ax = x < R(0) ? -x : x;
+  const R t = p.tc - ax;
+  const R bt = p.b * t;
+  const bool core = ax < p.ts, tail = ax < p.tc;
+  const R dtail = x < R(0) ? R(2) * bt : R(-2) * bt;
+  FD<R> o;
+  o.f = core ? R(1) - p.a * ax * ax : (tail ? bt * t : R(0));
+  o.d = core ? R(-2) * p.a * x : (tail ? dtail : R(0));
+  return o;
+}
 template <typename R>
 __device__ __forceinline__ FD<R> f4_eval(R th, const F4P<R>& p) {
+  if constexpr (kLeanMath<R>) return f4_eval_lean(th, p);
   FD<R> o{R(0), R(0)};
   if (p.t0 - p.ts < th && th < p.t0 + p.ts) {
     const R x = th - p.t0;
@@ -373,6 +423,15 @@ __device__ __forceinline__ F5P<R> f5_params_sel(const PT& P, bool first, int ba,
 }
 template <typename R>
 __device__ __forceinline__ FD<R> f5_eval(R x, const F5P<R>& p) {
+  if constexpr (kLeanMath<R>) {  // (as f4_eval_lean; differs from the branchy form only at x == 0 and x == xs exactly)
+    const R t = p.xc - x;
+    const R bt = p.b * t;
+    const bool one = x > R(0), core = x > p.xs, tail = x > p.xc;
+    FD<R> o;
+    o.f = one ? R(1) : (core ? R(1) - p.a * x * x : (tail ? bt * t : R(0)));
+    o.d = one ? R(0) : (core ? R(-2) * p.a * x : (tail ? R(-2) * bt : R(0)));
+    return o;
+  }
   FD<R> o{R(0), R(0)};
   if (x > R(0)) {
     o.f = R(1);

@@ -57,7 +57,9 @@ __device__ __forceinline__ void quat_axes(R q0, R q1, R q2, R q3, V3<R>& a1, V3<
 // whole block into scratch memory)
 template <typename R = void, class PT>
 __device__ __forceinline__ auto weight_lookup(const PT& P, int base, int k) {
-  if constexpr (PT::indexed) {
+  if constexpr (PT::indexed || (MYTHOS_LEAN_MATH != 0)) {
+    // (fp32 stepping kernels, MYTHOS_LEAN_MATH: ONE vector load at a lane-varying address; the select chain below is
+    // what the compiler makes of it anyway - fifteen compares and selects that compute the offset of that same load)
     return P[base + k];
   } else {
     auto w = P[base];

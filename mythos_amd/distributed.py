@@ -36,28 +36,39 @@ def shard_replicas(n_replicas: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_replicas, world))
 
 
-def all_gather_observables(local: torch.Tensor, group=None) -> torch.Tensor:
-    """(R_local, ...) per rank -> (R_total, ...) ordered by replica id (ranks may own different
-    counts: rows are padded to the maximum and trimmed after the gather)."""
+def all_gather_observables(local: torch.Tensor, group=None, n_total: int | None = None) -> torch.Tensor:
+    """(R_local, ...) per rank -> (R_total, ...) ordered by replica id (replica r lives on rank r mod world).
+
+    ``n_total`` given (the caller knows how many replicas the job has - always true for ``shard_replicas``): every rank's
+    count follows from it, so the gather is ONE collective (``all_gather_into_tensor`` of rows padded to ceil(n_total /
+    world)) and nothing crosses to the host.  Without it the counts are gathered first (a second collective and a host
+    read-back), which is fine off the timed path."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts)
-    pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    total = sum(counts)
+    if n_total is not None:
+        counts = [len(range(r, n_total, world)) for r in range(world)]
+        if local.shape[0] != counts[dist.get_rank(group)]:
+            raise ValueError(f"rank {dist.get_rank(group)} holds {local.shape[0]} rows, {counts[dist.get_rank(group)]} expected of {n_total}")
+    else:
+        n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        gathered = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(gathered, n_local, group=group)
+        counts = [int(c.item()) for c in gathered]
+    mx, total = max(counts), sum(counts)
+    if local.shape[0] == mx:
+        pad = local.contiguous()
+    else:
+        pad = torch.zeros((mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    buf = torch.empty((world * mx, *local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    buf = buf.reshape(world, mx, *local.shape[1:])
+    if total == world * mx:  # equal shares: replica k * world + r is row k of rank r - a transpose, no index lists
+        return buf.transpose(0, 1).reshape(total, *local.shape[1:])
     out = torch.empty((total, *local.shape[1:]), dtype=local.dtype, device=local.device)
     for r in range(world):  # replica id = rank + k * world
-        ids = torch.arange(r, total, world, device=local.device)[: counts[r]]
-        out[ids] = bufs[r][: counts[r]]
-    del rank
+        out[r:total:world] = buf[r, : counts[r]]
     return out
 
 

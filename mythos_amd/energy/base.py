@@ -643,7 +643,11 @@ class ComposedEnergyFunction(EnergyFunction):
                             is_rna=is_rna)
         _apply_pseq(entry, pseq_request(self.energy_fns))  # hydrogen bonding only (na1/hydrogen_bonding.py:127-128)
         entry["observe"] = None
-        total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
+        pseq_leaves = pseq_tensors(self.energy_fns)  # d<U>/d(distribution) wanted: mythos_oxdna_energy_dpseq
+        if pseq_leaves is not None:
+            total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w, *pseq_leaves)
+        else:
+            total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)
         return total, terms, cols
 
     def compute_terms(self, body: RigidBody) -> torch.Tensor:

@@ -115,9 +115,11 @@ class OxdnaSystem:
         bp = np.ascontiguousarray(bp_probs, dtype=np.float64).reshape(-1, 4)
         if marg.shape != (self.n, 4) or unit.shape != (self.n,):
             raise ValueError(f"marginals must be ({self.n}, 4) and unit ({self.n},)")
-        n_bp = int(unit.max() // 2 + 1) if (unit >= 0).any() else 0
+        # every row of bp_probs is a constrained base pair (the library checks that unit names each of them exactly
+        # twice, once per member); a system without base pairs passes one row of zeros, as the reference does
+        n_bp = int(bp.shape[0]) if (unit >= 0).any() else 0
         self._pseq_n_bp = n_bp
-        if bp.shape[0] < n_bp:
+        if (unit >= 0).any() and int(unit.max()) >= 2 * n_bp:
             raise ValueError("bp_probs has fewer rows than the base pairs named in unit")
         _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, marg.ctypes.data_as(_lib.c_double_p), unit.ctypes.data_as(_lib.c_int_p),
                                                    n_bp, bp.ctypes.data_as(_lib.c_double_p), int(terms)), "set_pseq")
@@ -216,6 +218,14 @@ class OxdnaSystem:
         return e, gc, gq, gp
 
 
+def _touched(*tensors) -> None:
+    """The library has just written into these caller tensors through raw pointers: bump torch's version counters, so that
+    anything keyed on them (the fused-observable rows of mythos_amd/observables/base.py) sees the change."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 class LangevinIntegrator:
     """BAOAB rigid-body Langevin dynamics bound to an :class:`OxdnaSystem`."""
 
@@ -248,6 +258,11 @@ class LangevinIntegrator:
             "set_neighbor_policy",
         )
 
+    def set_unfused(self, on: bool = True) -> None:
+        """oxNA systems: step through the two-launch path (forces launch + integrator launch) from the next load / run
+        on - the second implementation the fused oxNA step kernel is checked against (mythos_langevin_set_option)."""
+        _lib.check(self._lib.mythos_langevin_set_option(self._h, 0, 1 if on else 0), "set_option(unfused)")
+
     def init_momenta(self):
         s = self.system
         p = torch.empty((s.n, 3), dtype=s.dtype, device=s.device)
@@ -272,6 +287,7 @@ class LangevinIntegrator:
             ),
             "langevin_run",
         )
+        _touched(center, quat, p_lin, p_ang)
         return tc, tq, et
 
     # ---- resident form: the state stays in the integrator's layout on the device between calls ----------
@@ -303,6 +319,7 @@ class LangevinIntegrator:
     def store(self, center, quat, p_lin, p_ang) -> None:
         """Copy the resident state out (mythos_langevin_store, asynchronous on the current stream)."""
         _lib.check(self._lib.mythos_langevin_store(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device)), "langevin_store")
+        _touched(center, quat, p_lin, p_ang)
 
     @property
     def step(self) -> int:
@@ -320,6 +337,12 @@ class LangevinIntegrator:
         """Out-of-turn list rebuilds of the last run (a site left its skin early, or rows / buckets had to grow)."""
         r = C.c_int(0)
         _lib.check(self._lib.mythos_langevin_last_recoveries(self._h, C.byref(r)), "last_recoveries")
+        return int(r.value)
+
+    def last_rebuilds(self) -> int:
+        """Scheduled list rebuilds inside the last run / advance."""
+        r = C.c_int(0)
+        _lib.check(self._lib.mythos_langevin_last_rebuilds(self._h, C.byref(r)), "last_rebuilds")
         return int(r.value)
 
     def last_kernel_ms(self) -> dict:

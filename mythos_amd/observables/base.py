@@ -95,20 +95,39 @@ def _frames(trajectory):
     return c, q.to(c.dtype)
 
 
-# rows computed in the epilogue of an energy launch, keyed by the frames they belong to:
-# (center ptr, version, quat ptr, version, shape, set signature) -> (S, width) tensor.  A handful of entries; an entry
-# is only trusted while the tensors it was computed from are unmodified (torch's version counters).
-_FUSED: dict = {}
+# Rows computed in the epilogue of an energy launch, remembered together with the frames they belong to.  An entry
+# HOLDS its two tensors: while it lives their memory cannot go back to the allocator and be handed to another trajectory
+# of the same shape, so "same address, same shape, same version counters" does identify the frames (an entry keyed on
+# data_ptr alone would serve the rows of a freed trajectory to the next one allocated in its place).  The library
+# writes into caller tensors through raw pointers in two places only - LangevinIntegrator.run / store - and those bump
+# the version counters (hip_system._touched).  At most four entries, i.e. at most four trajectories kept alive here;
+# clear_fused() drops them.
+_FUSED: list = []
+_FUSED_MAX = 4
 
 
-def _traj_key(c: torch.Tensor, q: torch.Tensor):
-    return (c.data_ptr(), c._version, q.data_ptr(), q._version, tuple(c.shape), c.dtype)
+def _same_frames(entry, c: torch.Tensor, q: torch.Tensor) -> bool:
+    ec, eq, cv, qv = entry[0], entry[1], entry[2], entry[3]
+    return (ec.data_ptr() == c.data_ptr() and eq.data_ptr() == q.data_ptr() and tuple(ec.shape) == tuple(c.shape)
+            and ec.dtype == c.dtype and ec._version == cv == c._version and eq._version == qv == q._version)
 
 
 def remember_fused(c, q, signature, rows) -> None:
-    if len(_FUSED) >= 8:
-        _FUSED.pop(next(iter(_FUSED)))
-    _FUSED[(*_traj_key(c, q), signature)] = rows
+    _FUSED[:] = [e for e in _FUSED if not (_same_frames(e, c, q) and e[4] == signature)]
+    while len(_FUSED) >= _FUSED_MAX:
+        _FUSED.pop(0)
+    _FUSED.append((c, q, c._version, q._version, signature, rows))
+
+
+def lookup_fused(c, q, signature):
+    for e in reversed(_FUSED):
+        if e[4] == signature and _same_frames(e, c, q):
+            return e[5]
+    return None
+
+
+def clear_fused() -> None:
+    _FUSED.clear()
 
 
 class HipObservable:
@@ -137,7 +156,7 @@ class HipObservable:
         """(S, width) rows of this observable's set for the frames: from the energy launch that already produced
         them, or from a stand-alone launch."""
         c, q = _frames(trajectory)
-        hit = _FUSED.get((*_traj_key(c, q), self.signature()))
+        hit = lookup_fused(c, q, self.signature())
         if hit is not None:
             return hit
         cache = self.__dict__.setdefault("_sets", {})

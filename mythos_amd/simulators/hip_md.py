@@ -101,9 +101,10 @@ class HipMDSimulator(Simulator):
         first = ef.energy_fns[0]
         from mythos_amd.energy.base import pseq_request
 
-        if pseq_request(ef.energy_fns) is not None:
-            raise ValueError("HipMDSimulator: the energy function carries a probabilistic sequence (pseq); dynamics need a "
-                             "discrete sequence - reweight the stored frames with the pseq energy function instead")
+        # a probabilistic sequence rides along into the dynamics, as it does in the reference - there the stacking /
+        # hydrogen-bonding configurations carry pseq into whatever energy function a simulator steps with
+        # (dna1/stacking.py:284-285, hydrogen_bonding.py:330-331)
+        pseq = pseq_request(ef.energy_fns)
         geom = next(fn.transform_fn for fn in ef.energy_fns if fn.transform_fn is not None)
         model = geom.model
         _terms.check_term_models(model, ef.energy_fns)
@@ -153,6 +154,13 @@ class HipMDSimulator(Simulator):
             is_rna = np.tile(np.asarray(is_rna), n_rep)
         system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev, is_rna=is_rna)
         system.set_params(flat.detach())
+        if pseq is not None:
+            marg, unit, bp, terms = pseq
+            if n_rep > 1:  # every replica its own copy of the base pairs
+                n_bp = int(bp.shape[0]) if (unit >= 0).any() else 0
+                unit = np.concatenate([np.where(unit >= 0, unit + 2 * n_bp * r, -1) for r in range(n_rep)])
+                marg, bp = np.tile(marg, (n_rep, 1)), (np.tile(bp, (n_rep, 1)) if n_bp > 0 else bp)
+            system.set_pseq(marg, unit, bp, terms)
         mass, inertia = _pair(sp.mass)
         gamma_t, gamma_r = _pair(sp.gamma)
         integ = LangevinIntegrator(system, dt=sp.dt, kT=sp.kT, gamma_t=float(gamma_t), gamma_r=float(gamma_r),

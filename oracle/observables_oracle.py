@@ -3,8 +3,11 @@
 The checker of mythos_amd/observables (whose product path is the HIP code in mythos_amd/csrc/observables.h): the same
 quantities written with torch ops on whatever device the trajectory lives on, following the reference function by
 function - mythos/observables/base.py:24-66 (local helical axis, quartets), propeller.py:19-71, pitch.py:33-102,
-rise.py:21-80, persistence_length.py:21-185.  Pinned by closed-form geometries (tests/test_observables_cpu.py): the
-reference ships no golden values for its observables.  Only tests/ may import this module.
+rise.py:21-80, persistence_length.py:21-185.  Pinned (tests/test_observables_cpu.py) by the known answers the
+reference's own tests hold - observables/tests/test_rise.py:14-83 (14.753608, 11.065206), test_propeller.py:39-80 (120) -
+and by closed-form geometries; test_lp.py:50-59 reads data/test-data/simple-helix-60bp/output.dat, which this snapshot of
+the reference does not contain, so the persistence-length fit is pinned by a discrete worm-like chain only.
+Only tests/ may import this module.
 """
 
 from __future__ import annotations
@@ -131,13 +134,18 @@ def vector_autocorrelate(vecs: torch.Tensor) -> torch.Tensor:
 
 
 def persistence_length_fit(correlations: torch.Tensor, l0_av):
-    """Lp and offset of the line log C(d) = offset - d l0 / Lp (persistence_length.py:21-44)."""
-    y = torch.log(correlations)
-    d = torch.arange(correlations.shape[0], dtype=y.dtype, device=y.device)
-    design = torch.stack([torch.ones_like(d), d], dim=1)
-    sol = torch.linalg.lstsq(design, y[:, None]).solution[:, 0]
-    offset, slope = sol[0], sol[1]
-    return -l0_av / slope, offset
+    """Lp and offset of the line log C(d) = offset - d l0 / Lp (persistence_length.py:21-44).
+
+    Written as the textbook closed form of a straight-line fit (slope = cov(d, y) / var(d)) so that it is NOT the product's
+    arithmetic (mythos_amd/observables/persistence_length.py solves the (n, 2) least-squares system with a QR solver):
+    comparing the two is a check, not a self-comparison."""
+    y = torch.log(correlations.detach().double().cpu())
+    d = torch.arange(y.shape[0], dtype=torch.float64)
+    dm, ym = d.mean(), y.mean()
+    slope = ((d - dm) * (y - ym)).sum() / ((d - dm) ** 2).sum()
+    offset = ym - slope * dm
+    l0 = l0_av.detach().double().cpu() if isinstance(l0_av, torch.Tensor) else torch.tensor(float(l0_av), dtype=torch.float64)
+    return -l0 / slope, offset
 
 
 class PersistenceLength:

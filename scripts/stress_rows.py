@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Stress of the device row builder against a k-d tree (scipy): random clouds, free and periodic, fp32 and fp64, with
-the cell buckets at their managed size or squeezed (MYTHOS_CELL_BUCKET_CAP in the environment).  Compares the number
-of listed pairs exactly (every pair is in two rows) and the longest row."""
+the cell buckets at their managed size or squeezed (second argument: places per bucket, through mythos_debug_set).
+Compares the number of listed pairs exactly (every pair is in two rows) and the longest row.
+
+    python scripts/stress_rows.py [seed] [bucket_cap]"""
 import sys
 from pathlib import Path
 
@@ -9,10 +11,13 @@ import numpy as np
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from mythos_amd import _lib  # noqa: E402
 from mythos_amd.hip_system import OxdnaSystem  # noqa: E402
 from mythos_amd.simulators.neighbors import verlet_pairs_numpy  # noqa: E402
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+if len(sys.argv) > 2:
+    _lib.debug_set("cell_bucket_cap", int(sys.argv[2]))
 bad = 0
 for case in range(24):
     n = int(rng.integers(600, 6000))

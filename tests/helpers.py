@@ -235,3 +235,18 @@ def random_dimers(model: int, bonded: bool, keep: int = 512, sample: int = 200_0
         kinds = is_rna[nuc].reshape(-1, 2)
         live["pairs dna-dna / rna-rna / hybrid"] = (int((~kinds).all(1).sum()), int(kinds.all(1).sum()), int((kinds[:, 0] != kinds[:, 1]).sum()))
     return top, np.ascontiguousarray(center), np.ascontiguousarray(q[nuc]), live
+
+
+# ---- the known answers the reference's own observable tests hold (mythos/observables/tests/test_rise.py:14-83,
+#      test_propeller.py:13-80), as inputs our classes take.  The reference's mocks make the base site / base normal of a
+#      nucleotide its CENTRE; here: site offsets 0 (base site = centre) and quaternions whose a3 is the wanted normal.
+#      test_rise_call indexes site 3 of a 3-site frame; JAX clamps out-of-range gathers, so its fourth site IS the third.
+#      (test_lp.py:50-59 needs data/test-data/simple-helix-60bp/output.dat, which this snapshot of the reference does not hold.)
+ZERO_GEOMETRY = {"com_to_hb": 0.0, "com_to_stacking": 0.0, "com_to_backbone_x": 0.0, "com_to_backbone_y": 0.0}
+RISE_SINGLE = {"quartets": [[[0, 1], [1, 2]]], "centers": [[0, 0, 0], [1, 1, 1], [2, 2, 2], [3, 3, 3]], "expected": 14.753608}
+RISE_CALL = {"quartets": [[[0, 1], [1, 2]], [[1, 2], [2, 3]]], "centers": [[0, 0, 0], [1, 1, 1], [2, 2, 2], [2, 2, 2]],
+             "frames": 5, "expected": 11.065206}
+_S = 0.5 ** 0.5
+# a3 = e_x, e_y, e_z, e_x (TEST_NORMALS): z -> x is +90 degrees about y, z -> y is -90 degrees about x
+PROPELLER_CALL = {"pairs": [[0, 1], [0, 2], [0, 3]], "quats": [[_S, 0, _S, 0], [_S, -_S, 0, 0], [1, 0, 0, 0], [_S, 0, _S, 0]],
+                  "frames": 5, "expected": 120.0}

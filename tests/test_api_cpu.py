@@ -101,6 +101,17 @@ assert ids == ([0, 2, 4] if rank == 0 else [1, 3])
 local = torch.tensor([[float(i), 10.0 * i] for i in ids], dtype=torch.float64)
 allv = md.all_gather_observables(local)
 assert allv.shape == (5, 2) and torch.equal(allv[:, 0], torch.arange(5, dtype=torch.float64)), allv
+# the job's replica count known: one collective, no host read-back - ragged (5 over 2 ranks) and equal (4 over 2) shares
+assert torch.equal(md.all_gather_observables(local, n_total=5), allv)
+ids4 = md.shard_replicas(4, rank, world)
+loc4 = torch.tensor([[float(i), 10.0 * i, -float(i)] for i in ids4], dtype=torch.float64)
+all4 = md.all_gather_observables(loc4, n_total=4)
+assert all4.shape == (4, 3) and torch.equal(all4[:, 0], torch.arange(4, dtype=torch.float64)) and torch.equal(all4[:, 2], -all4[:, 0]), all4
+try:
+    md.all_gather_observables(loc4, n_total=7)
+    raise SystemExit("a share that does not match n_total must be refused")
+except ValueError:
+    pass
 g = torch.Generator().manual_seed(7)
 e_new = torch.randn(10, generator=g, dtype=torch.float64) * 3
 e_ref = torch.randn(10, generator=g, dtype=torch.float64) * 3

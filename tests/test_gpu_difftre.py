@@ -157,3 +157,32 @@ def test_rank_sharded_difftre_equals_the_single_process_gradient():
                       "--iterations", "2", "--check", "--rehearse-on-one-gpu"], nproc=2)
     assert len(two) == 2 and two[0]["world"] == 2 and two[0]["replicas_this_rank"] == 32
     assert two[1]["check"]["max_rel_grad_err"] <= 1e-10 and two[0]["check"]["frames"] == 256
+
+
+def test_bench_with_two_ranks_prints_one_line_of_the_contract():
+    """`python bench.py --gpus 2` starts its own two ranks (torch.distributed.run on 127.0.0.1; here both on this GPU over
+    gloo: --rehearse-on-one-gpu).  Exactly ONE JSON line comes out, from rank 0, with n_gpus 2, weak scaling, two replicas,
+    strings short enough for the driver's parsed copy, every timed sample listed and the rebuild count of each."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--bp", "300", "--steps", "20",
+                        "--warmup", "5", "--cpu-steps", "0", "--repeats", "3"], capture_output=True, text=True, env=env, timeout=900,
+                       cwd=root, check=False)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["replicas"] == 2 and d["steps"] == 20 and d["warmup"] == 5
+    assert d["unit"] == "steps/s" and d["higher_is_better"] is True and d["value"] > 0 and d["dtype"] == "f32"
+    assert len(d["config"]["samples_ms"]) == 3 == len(d["config"]["scheduled_rebuilds_per_sample"])
+    assert abs(d["ms_per_step"] - sorted(d["config"]["samples_ms"])[1] / 20) < 1e-9
+    assert d["value"] == pytest.approx(2 * 20 / (sorted(d["config"]["samples_ms"])[1] * 1e-3))
+    assert "rehearsal" in d["config"] and d["f64_steps_per_s"] > 0 and "f64" in d["config"]["timed_region"]
+    for text in (d["config"]["workload"], d["config"]["timed_region"], d["metric"]):
+        assert len(text) <= 120, text

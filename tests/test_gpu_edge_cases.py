@@ -204,38 +204,35 @@ def test_md_partially_filled_workgroup_matches_the_oracle():
 
 
 def test_full_cell_buckets_spill_without_losing_neighbours():
-    """Cell buckets of three places (MYTHOS_CELL_BUCKET_CAP, read when the library first builds a list, hence the child
-    process): nearly every cell overflows into the spill list, and the lists must still be complete - the 1 kbp
-    energies against the k-d tree list of the oracle, and the MARTINI Verlet forces against the all-pairs kernel."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
+    """Cell buckets of three places (mythos_debug_set, read when a list is built): nearly every cell overflows into the
+    spill list, and the lists must still be complete - the 1 kbp energies against the k-d tree list of the oracle, and
+    the MARTINI Verlet forces against the all-pairs kernel."""
+    from mythos_amd import _lib
+    from tests.test_gpu_full_size import test_cfg2_1kbp_energy_and_forces_match_oracle
+    from tests.test_gpu_martini_md import test_step_by_step_parity_with_oracle_fp64, test_verlet_list_forces_equal_all_pairs_energy_kernel
 
-    root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, MYTHOS_CELL_BUCKET_CAP="3")
-    cases = ["tests/test_gpu_full_size.py::test_cfg2_1kbp_energy_and_forces_match_oracle",
-             "tests/test_gpu_martini_md.py::test_verlet_list_forces_equal_all_pairs_energy_kernel",
-             "tests/test_gpu_martini_md.py::test_step_by_step_parity_with_oracle_fp64"]
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *cases],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout
+    _lib.debug_set("cell_bucket_cap", 3)
+    try:
+        test_cfg2_1kbp_energy_and_forces_match_oracle()
+        test_verlet_list_forces_equal_all_pairs_energy_kernel()
+        test_step_by_step_parity_with_oracle_fp64()
+    finally:
+        _lib.debug_set("cell_bucket_cap", 0)
+    assert _lib.debug_get("cell_bucket_cap") == 0
 
 
 def test_row_builder_equals_a_kd_tree_on_random_clouds():
     """scripts/stress_rows.py: 24 random systems (600-6 000 particles, blobs in free space and periodic boxes with
     wrapped and unwrapped coordinates, fp32 and fp64, 8-45 neighbours per particle): the device-built rows hold exactly
     the pairs of scipy's k-d tree and the same longest row - with managed buckets and with buckets of five places."""
-    import os
     import subprocess
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    for seed, extra in ((11, {}), (12, {"MYTHOS_CELL_BUCKET_CAP": "5"})):
-        r = subprocess.run([sys.executable, str(root / "scripts" / "stress_rows.py"), str(seed)], cwd=root,
-                           env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
+    for args in (("11",), ("12", "5")):
+        r = subprocess.run([sys.executable, str(root / "scripts" / "stress_rows.py"), *args], cwd=root,
+                           capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "mismatches: 0" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
 
 

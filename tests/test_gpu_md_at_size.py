@@ -183,6 +183,139 @@ def test_12kbp_fp64_step_matches_energy_kernel_forces():
     np.testing.assert_allclose(qd.cpu().numpy(), q, rtol=0, atol=1e-11)
 
 
+def test_12kbp_two_fp64_steps_and_forces_match_the_oracle_directly():
+    """the 12 kbp checks above go through the HIP energy kernel; this one does not.  Two thermostatted fp64
+    steps of the 24 000-nt duplex against LangevinOracle on the same Philox stream (positions, quaternions, potential
+    energy: 1e-9), and dU/dcentre, dU/dquat of mythos_oxdna_energy against oracle autograd at the same size (fp64 1e-5,
+    fp32 1e-3 of the largest component; per-term energies likewise)."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle import oxdna_oracle as orc
+    from oracle.langevin_oracle import LangevinOracle
+
+    top, c0, q0 = generators.ideal_duplex(12000, model=2, seed=1234)
+    rng = np.random.default_rng(21)
+    c0 = c0 + 0.02 * rng.standard_normal(c0.shape)
+    q0 = q0 + 0.01 * rng.standard_normal(q0.shape)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    # the configuration every precision sees: fp32-representable (a 12 kbp duplex is 4 800 units long, where an fp32
+    # coordinate resolves 5e-4 - rounding the INPUT differently for the two sides would be an error of the test)
+    c0 = c0.astype(np.float32).astype(np.float64)
+    q0 = q0.astype(np.float32).astype(np.float64)
+    pairs = verlet_pairs_numpy(c0, top.bonded_neighbors, R_CUT + 0.6)
+    P = H.oracle_params(2, half_charged_ends=True)
+    tt = _top_tensors(top, pairs)
+    # ---- energies and gradients of the energy kernel, both precisions
+    e_ref = orc.energy_terms(2, P, torch.as_tensor(c0), torch.as_tensor(q0), *tt, box=None).numpy()
+    _, gc_ref, gq_ref = orc.energy_and_grads(2, P, torch.as_tensor(c0), torch.as_tensor(q0), *tt, box=None)
+    gc_ref, gq_ref = gc_ref.numpy(), gq_ref.numpy()
+    for dtype, tol in ((torch.float64, 1e-5), (torch.float32, 1e-3)):
+        s = _system(2, top, dtype)
+        cd, qd = _dev(c0, dtype, s), _dev(q0, dtype, s)
+        s.build_neighbors(cd, R_CUT, 0.0)
+        e, gc, gq, _ = s.energy(cd, qd, grads=True)
+        e = e.cpu().numpy().reshape(-1)[:8]
+        assert np.abs(e - e_ref).max() <= tol * np.abs(e_ref).max(), (dtype, e, e_ref)
+        assert np.abs(gc.cpu().double().numpy().reshape(-1, 3) - gc_ref).max() <= tol * np.abs(gc_ref).max()
+        assert np.abs(gq.cpu().double().numpy().reshape(-1, 4) - gq_ref).max() <= tol * np.abs(gq_ref).max()
+    # ---- two steps of the stepping kernel (fp64, the three-per-CU instantiation: 750 workgroups)
+    s = _system(2, top, torch.float64)
+    gam_t, gam_r, seed = KT / 2.5, KT / 7.5, 0x5EED12
+    integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.1, 0.9), seed=seed)
+    integ.set_neighbor_policy(R_CUT, 0.6, 25)
+    c, q = _dev(c0, torch.float64, s), _dev(q0 / np.linalg.norm(q0, axis=1, keepdims=True), torch.float64, s)
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    tc, tq, et = integ.run(c, q, p, L, 2, save_every=1)
+    lo = LangevinOracle(2, P, tt, None, 0.005, KT, gam_t, gam_r, 1.0, (1.0, 1.1, 0.9), seed=seed)
+    for k in range(2):
+        x, qq, pp, LL, u = lo.step(x, qq, pp, LL)
+        np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-9)
+        np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-9)
+        assert abs(et[k, :8].sum().item() - u) < 1e-9 * abs(u)
+    np.testing.assert_allclose(p.cpu().numpy(), pp, atol=1e-9 * max(1.0, np.abs(pp).max()))
+    np.testing.assert_allclose(L.cpu().numpy(), LL, atol=1e-9 * max(1.0, np.abs(LL).max()))
+
+
+def test_12kbp_fp32_step_matches_oracle_forces():
+    """The fp32 stepping kernel at 12 kbp against forces and torques of the ORACLE (autograd of the pinned energies), not
+    of the HIP energy kernel: one frictionless step from rest, per nucleotide 1e-3 of its own momentum + 1e-3 of the rms."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle import oxdna_oracle as orc
+    from oracle.langevin_oracle import drift
+
+    top, c0, q0 = generators.ideal_duplex(12000, model=2, seed=1234)
+    rng = np.random.default_rng(13)
+    c0 = c0 + 0.015 * rng.standard_normal(c0.shape)
+    q0 = q0 + 0.0075 * rng.standard_normal(q0.shape)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    c0 = c0.astype(np.float32).astype(np.float64)
+    q0 = q0.astype(np.float32).astype(np.float64)
+    qn = q0 / np.linalg.norm(q0, axis=1, keepdims=True)
+    P = H.oracle_params(2, half_charged_ends=True)
+    tt = _top_tensors(top, verlet_pairs_numpy(c0, top.bonded_neighbors, R_CUT + 0.3))
+
+    def forces(x, q):
+        _, gc, gq = orc.energy_and_grads(2, P, torch.as_tensor(x), torch.as_tensor(q), *tt, box=None)
+        return -gc.numpy(), _body_torque(q, gq.numpy())
+
+    dt, inertia = 0.005, np.array([1.0, 1.0, 1.0])
+    F0, t0 = forces(c0, qn)
+    p, L = 0.5 * dt * F0, 0.5 * dt * t0
+    x, q, L = drift(c0, qn, p, L, 0.5 * dt, 1.0, inertia)
+    x, q, L = drift(x, q, p, L, 0.5 * dt, 1.0, inertia)
+    q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    F1, t1 = forces(x, q)
+    p_ref, L_ref = p + 0.5 * dt * F1, L + 0.5 * dt * t1
+    s32 = _system(2, top, torch.float32)
+    integ = LangevinIntegrator(s32, dt=dt, kT=KT, gamma_t=0.0, gamma_r=0.0, mass=1.0, inertia=(1.0, 1.0, 1.0), seed=1)
+    integ.set_neighbor_policy(R_CUT, 0.6, 25)
+    c, qd = _dev(c0, torch.float32, s32), _dev(q0, torch.float32, s32)
+    pz, Lz = torch.zeros_like(c), torch.zeros_like(c)
+    integ.run(c, qd, pz, Lz, 1)
+    for got, ref in ((pz.cpu().double().numpy(), p_ref), (Lz.cpu().double().numpy(), L_ref)):
+        rms = np.sqrt((ref**2).mean())
+        assert rms > 0.005 and np.abs(ref).max() < 200 * rms
+        err = np.abs(got - ref).max(1)
+        assert (err <= 1e-3 * (np.abs(ref).max(1) + rms)).all(), (err.max(), rms, np.abs(ref).max())
+    assert np.abs(qd.cpu().double().numpy() - q).max() <= 1e-3 * np.abs(q - qn).max() + 3e-7
+
+
+@pytest.mark.parametrize("bp", [50, 1100])
+def test_rebuild_overflow_in_front_of_the_first_launch_of_a_later_segment_resumes_there(bp):
+    """the device's progress word is cleared after every segment of queued launches, so when the FIRST
+    launch of a later segment halts (the scheduled rebuild in front of it overflowed) the word says 0 - and the host used
+    to take that for "nothing ran" and start the call again from launch 0 on the wrong frame.  Forced with the library's
+    test switches: segments of 8 launches, rebuild every 8 steps, the rebuild in front of launch 16 claims an overflow.
+    The recovered run must be the undisturbed run, bit for bit, with one recovery and the full step count."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(bp, model=2, seed=77)
+    rng = np.random.default_rng(8)
+    c0 = c0 + 0.02 * rng.standard_normal(c0.shape)
+    q0 = q0 + 0.01 * rng.standard_normal(q0.shape)
+    q0 /= np.linalg.norm(q0, axis=1, keepdims=True)
+    results = []
+    for inject in (False, True):
+        s = _system(2, top, torch.float64)
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=5)
+        integ.set_neighbor_policy(R_CUT, 0.6, 8)
+        c, q = _dev(c0, torch.float64, s), _dev(q0, torch.float64, s)
+        p, L = integ.init_momenta()
+        _lib.debug_set("md_segment", 8)
+        if inject:
+            _lib.debug_set("md_overflow_at", 17)
+        try:
+            tc, tq, et = integ.run(c, q, p, L, 40, save_every=4)
+        finally:
+            _lib.debug_set("md_segment", 0)
+            _lib.debug_set("md_overflow_at", 0)
+        results.append((c.clone(), q.clone(), p.clone(), L.clone(), tc.clone(), et.clone(), integ.last_recoveries(), integ.step))
+    plain, hit = results
+    assert plain[6] == 0 and hit[6] == 1 and plain[7] == hit[7] == 40
+    for a, b in zip(plain[:6], hit[:6]):
+        assert torch.equal(a, b)
+
+
 def _nicked_duplex(model):
     """16 bp duplex whose second strand is two 8-mers: the two bases either side of the nick stack coaxially.  (The
     reference's dna1/simple-coax trajectory has a non-zero coaxial term only in its initial configuration, which is

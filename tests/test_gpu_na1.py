@@ -142,21 +142,21 @@ def test_random_dimers(bonded):
 
 @pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("name", ["simple-helix-dna-rna", "simple-coax-dna-dna-rna", "simple-helix-rna-rna"])
-def test_langevin_steps_match_the_oracle(name, unfused, monkeypatch):
+def test_langevin_steps_match_the_oracle(name, unfused):
     """The fused step kernel's oxNA instantiation (per row entry: the parameter set of the pair's kind; sites by the type of
-    each nucleotide), and the two-launch path behind MYTHOS_NA1_UNFUSED=1 (the energy kernel's forces + an integrator
+    each nucleotide), and the two-launch path behind LangevinIntegrator.set_unfused (the energy kernel's forces + an integrator
     kernel): six fp64 steps against LangevinOracle on the same Philox stream - positions, quaternions, potential and kinetic
     energies of every step, final momenta; then the same trajectory in two advances."""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle
 
-    if unfused:
-        monkeypatch.setenv("MYTHOS_NA1_UNFUSED", "1")
     top, traj, _, is_rna = H.load_golden_na1(name)
     kT = 296.15 * 0.1 / 300.0
     gam_t, gam_r, seed = kT / 2.5, kT / 7.5, 0xBADC0FFEE
     s = _system(top, is_rna, traj.box_size, torch.float64)
     integ = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    if unfused:
+        integ.set_unfused()
     c = torch.as_tensor(traj.center[2], device=s.device).contiguous()
     q = torch.as_tensor(traj.quaternions[2], device=s.device).contiguous()
     p, L = integ.init_momenta()
@@ -177,6 +177,8 @@ def test_langevin_steps_match_the_oracle(name, unfused, monkeypatch):
     assert integ.step == 6
     # resident: load; advance(2); advance(4); store == run(6), bit for bit (one force evaluation per step either way)
     integ2 = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    if unfused:
+        integ2.set_unfused()
     c2, q2, p2, L2 = [t.clone() for t in start]
     integ2.load(c2, q2, p2, L2)
     integ2.advance(2)
@@ -231,8 +233,9 @@ def test_what_the_boundary_refuses():
     s.set_pseq(np.full((top.n_nucleotides, 4), 0.25), np.full(top.n_nucleotides, -1), np.zeros((0, 4)), terms=2)
     c1 = torch.as_tensor(traj.center[:1], device=s.device)
     q1 = torch.as_tensor(traj.quaternions[:1], device=s.device)
-    with pytest.raises(ValueError, match="not available for oxNA"):  # dU/d(distribution): oxDNA / oxRNA2 systems only
-        s.energy(c1, q1, param_grads=True, pseq_grads=True)
+    # dU/d(distribution) is there for oxNA systems too (round 3; checked against the oracle further down): shapes only here
+    out = s.energy(c1, q1, param_grads=True, pseq_grads=True)
+    assert tuple(out[4].shape) == (1, top.n_nucleotides, 4) and tuple(out[5].shape) == (1, 1, 4)
     s.set_pseq()
     other = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
     with pytest.raises(ValueError, match="only an oxNA system"):
@@ -358,3 +361,49 @@ def test_probabilistic_sequence_through_the_hydrogen_bonding_term():
     np.testing.assert_allclose(e_soft, want, rtol=1e-10, atol=1e-10)
     assert np.abs(e_soft[:, 4] - e_d[:, 4]).max() > 1e-2   # the distribution matters ...
     np.testing.assert_allclose(np.delete(e_soft, 4, axis=1), np.delete(e_d, 4, axis=1), rtol=0, atol=1e-12)  # ... to hydrogen bonding only
+
+
+def test_gradient_with_respect_to_the_distribution_of_a_hybrid_system():
+    """dU/d(pseq) for oxNA (na1/hydrogen_bonding.py:127-128, 243-304: the distribution reaches the hydrogen-bonding weight of
+    whichever parameter set a pair takes): the kernel's dU/d(marginals), dU/d(type probabilities) of the model-4
+    instantiation (mythos_oxdna_energy_dpseq), carried to the (unpaired, base-pair) arrays by autograd, against oracle
+    autograd through compute_seq_dep_weight on the DNA-RNA golden; three frames weighted differently, a parameter
+    gradient in the same backward pass."""
+    from mythos_amd.input import sequence_constraints as scm
+
+    top, traj, _, is_rna = H.load_golden_na1("simple-helix-dna-rna")
+    disp, _ = space.periodic(20.0)
+    n = top.n_nucleotides
+    sc = scm.from_bps(n, np.array([[1, 14], [3, 12], [6, 9]]))
+    rng = np.random.default_rng(17)
+
+    def dist(rows):
+        a = rng.random((rows, 4)) + 0.05
+        return a / a.sum(1, keepdims=True)
+
+    up0, bp0 = dist(sc.n_unpaired), dist(sc.n_bp)
+    frames = [3, 41, 88]
+    states = _states(traj)
+    sub = RigidBody(center=states.center[frames], orientation=Quaternion(vec=states.orientation.vec[frames]))
+    up_h, bp_h = (torch.tensor(a, requires_grad=True) for a in (up0, bp0))
+    eps_h = torch.tensor(0.97, dtype=torch.float64, requires_grad=True)
+    ef = na1.create_default_energy_fn(top, disp)
+    u_h = ef.with_params({"drh_eps_hb": eps_h}, pseq=(up_h, bp_h), pseq_constraints=sc).map(sub)
+    coef = torch.tensor([1.0, -0.5, 2.0], dtype=torch.float64, device=u_h.device)
+    g_h = torch.autograd.grad((u_h * coef).sum(), [up_h, bp_h, eps_h])
+    up_o, bp_o = (torch.tensor(a, requires_grad=True) for a in (up0, bp0))
+    eps_o = torch.tensor(0.97, dtype=torch.float64, requires_grad=True)
+    sim, cfg = defaults.default_configs_for("na1")
+    for which in cfg:
+        cfg[which]["hydrogen_bonding"].update(pseq=(up_o, bp_o), pseq_constraints=sc)
+    cfg["drh"]["hydrogen_bonding"]["eps_hb"] = eps_o
+    P = orc.init_all_na1(cfg["dna"], cfg["rna"], cfg["drh"], kt=sim["kT"], salt_conc=0.5, half_charged_ends=False)
+    seq, is_end, b, u = H.topo_tensors(top)
+    u_o = torch.stack([orc.energy_terms_na1(P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, torch.as_tensor(is_rna),
+                                            is_end, b, u, box=traj.box_size).sum() for f in frames])
+    np.testing.assert_allclose(u_h.detach().cpu().numpy(), u_o.detach().numpy(), rtol=1e-10)
+    g_o = torch.autograd.grad((u_o * coef.cpu()).sum(), [up_o, bp_o, eps_o])
+    for got, want, name in zip(g_h, g_o, ("unpaired", "base pairs", "drh_eps_hb")):
+        got, want = got.detach().cpu().numpy(), want.detach().numpy()
+        assert np.abs(want).max() > 1e-3, name
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9 * max(1.0, np.abs(want).max()), err_msg=name)

@@ -149,6 +149,75 @@ def test_rows_from_the_energy_launch_equal_the_stand_alone_rows():
     torch.testing.assert_close(obs[1](traj), OO.Rise(quartets, disp, cfg["geometry"])(_cpu64(traj)).cuda(), rtol=0, atol=1e-10)
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_hip_observables_reproduce_the_references_own_known_answers(dtype):
+    """mythos/observables/tests/test_rise.py:14-33 (14.753608), :42-83 (11.065206), test_propeller.py:39-80 (120) through
+    the HIP kernels (stand-alone launch): site offsets 0, so a base site is a centre as in the reference's mocks."""
+    dev = torch.device("cuda", 0)
+    disp = space.free()[0]
+
+    def traj(centers, quats, frames):
+        c = torch.as_tensor(np.repeat(np.asarray(centers, dtype=np.float64)[None], frames, 0), dtype=dtype, device=dev)
+        q = torch.as_tensor(np.repeat(np.asarray(quats, dtype=np.float64)[None], frames, 0), dtype=dtype, device=dev)
+        return SimulatorTrajectory(center=c, orientation=Quaternion(vec=q))
+
+    ident = [[1.0, 0, 0, 0]] * 4
+    tol = 1e-7 if dtype == torch.float64 else 1e-6
+    r1 = Rise(np.asarray(H.RISE_SINGLE["quartets"]), disp, H.ZERO_GEOMETRY)(traj(H.RISE_SINGLE["centers"], ident, 1))
+    np.testing.assert_allclose(r1.cpu().numpy(), [H.RISE_SINGLE["expected"]], rtol=tol)
+    r2 = Rise(np.asarray(H.RISE_CALL["quartets"]), disp, H.ZERO_GEOMETRY)(traj(H.RISE_CALL["centers"], ident, H.RISE_CALL["frames"]))
+    np.testing.assert_allclose(r2.cpu().numpy(), [H.RISE_CALL["expected"]] * H.RISE_CALL["frames"], rtol=tol)
+    pt = PropellerTwist(np.asarray(H.PROPELLER_CALL["pairs"]))(traj([[0.0, 0, 0]] * 4, H.PROPELLER_CALL["quats"], H.PROPELLER_CALL["frames"]))
+    # (fp32 input: the quaternion components sqrt(1/2) are rounded, |a3|^2 = 1 - 1e-7, and the pair of EQUAL normals sits
+    #  where acos has no derivative: its angle comes out as 0.02 degrees instead of 0)
+    np.testing.assert_allclose(pt.cpu().numpy(), [H.PROPELLER_CALL["expected"]] * H.PROPELLER_CALL["frames"],
+                               rtol=tol if dtype == torch.float64 else 2e-4)
+
+
+def test_remembered_rows_never_serve_another_trajectory():
+    """The rows remembered from an energy launch belong to ONE pair of tensors: a second trajectory of the same
+    shape - allocated after the first was dropped, where the caching allocator would hand out the same address - and a
+    buffer the integrator refills through raw pointers must both get rows of their own."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    bp = 16
+    top, traj = _thermal_duplex(bp, 6, seed=9)
+    _, cfg = defaults.default_configs_for("dna2")
+    disp = space.free()[0]
+    pairs = np.stack([np.arange(bp), 2 * bp - 1 - np.arange(bp)], axis=1)[1:-1]
+    ptw = PropellerTwist(pairs)
+    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp).with_observables(ptw)
+    PB.clear_fused()
+    ef.map(traj)
+    first = ptw(traj).clone()
+    shape_c, shape_q = traj.center.shape, traj.orientation.vec.shape
+    c2 = traj.center.flip(0).contiguous() + 0.05
+    q2 = traj.orientation.vec.flip(0).contiguous()
+    del traj
+    torch.cuda.empty_cache()
+    other = SimulatorTrajectory(center=torch.empty(shape_c, dtype=c2.dtype, device=c2.device).copy_(c2),
+                                orientation=Quaternion(vec=torch.empty(shape_q, dtype=q2.dtype, device=q2.device).copy_(q2)))
+    got = ptw(other)
+    PB.clear_fused()
+    want = ptw(other)  # nothing remembered: the stand-alone launch
+    assert torch.equal(got, want) and not torch.equal(got, first)
+    # state tensors the integrator updates in place carry a new version afterwards
+    sim, _ = defaults.default_configs_for("dna2")
+    from mythos_amd import _lib as L
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.hip_system import OxdnaSystem
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, dtype=torch.float32, device=other.center.device)
+    s.set_params(fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], half_charged_ends=True), L.param_names()))
+    integ = LangevinIntegrator(s, dt=sim["dt"], kT=sim["kT"], gamma_t=sim["kT"] / 2.5, gamma_r=sim["kT"] / 7.5, seed=3)
+    integ.set_neighbor_policy(3.25, 0.6, 25)
+    c = other.center[0].to(torch.float32).contiguous()
+    q = other.orientation.vec[0].to(torch.float32).contiguous()
+    p, ang = integ.init_momenta()
+    v0 = (c._version, q._version)
+    integ.run(c, q, p, ang, 5)
+    assert c._version > v0[0] and q._version > v0[1]
+
+
 def test_difftre_loss_and_gradient_are_unchanged_by_fusing_the_observable():
     top, traj, _, _ = H.load_golden(1, "simple-helix")
     dev = torch.device("cuda", 0)

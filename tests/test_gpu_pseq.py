@@ -6,7 +6,8 @@ bonding weight of every pair is formed inside the kernel from per-nucleotide mar
  * the reference's own check, brute-force enumeration over every allowed sequence with the DISCRETE kernel
    (dna1/tests/test_expected_energies.py:162-328, atol 1e-4), in both precisions;
  * energies, forces and dU/dtheta against the oracle's restatement of compute_seq_dep_weight (energy/utils.py:45-132);
- * the integrator refuses a system with a sequence distribution.
+ * dynamics with a sequence distribution: the stepping kernel's PSEQ instantiation against LangevinOracle, and
+   through HipMDSimulator (one-hot == discrete; replicas).
 """
 
 import numpy as np
@@ -168,35 +169,113 @@ def test_gradient_with_respect_to_the_distribution(model):
         assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * b.abs().max().item()
 
 
-def test_dynamics_refuse_a_sequence_distribution():
+@pytest.mark.parametrize(("model", "save_every"), [(1, 1), (2, 1), (2, 0)])
+def test_langevin_steps_with_a_soft_distribution_match_the_oracle(model, save_every):
+    """A probabilistic sequence inside the dynamics (the reference's stacking / hydrogen-bonding configurations
+    carry pseq into whatever energy function a simulator steps with, dna1/stacking.py:261-285, hydrogen_bonding.py:310-331):
+    md_step_kernel's PSEQ instantiation, six fp64 steps on dna1/helix-4bp with a soft distribution - three constrained
+    base pairs, two free nucleotides, random weight tables - against LangevinOracle on the same Philox stream (the
+    oracle's energy takes the expectation through compute_seq_dep_weight); with and without stored steps (the two
+    instantiations), and the run split in two advances."""
+    from mythos_amd.hip_system import LangevinIntegrator
+    from oracle.langevin_oracle import LangevinOracle
+    from tests.test_gpu_md_at_size import _system
+
+    top, traj = _helix4()
+    sc = scm.from_bps(8, np.array([[0, 7], [1, 6], [2, 5]]))
+    rng = np.random.default_rng(31)
+
+    def dist(rows):
+        a = rng.random((rows, 4)) + 0.05
+        return a / a.sum(1, keepdims=True)
+
+    up, bp, w_st, w_hb = dist(sc.n_unpaired), dist(sc.n_bp), rng.random((4, 4)) + 0.5, rng.random((4, 4)) + 0.2
+    kT = 296.15 * 0.1 / 300.0
+    from mythos_amd import _lib
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.hip_system import OxdnaSystem
+    from mythos_amd.input import defaults
+
+    sim, cfg = defaults.default_configs_for(f"dna{model}")
+    cfg["stacking"]["ss_stack_weights"] = torch.as_tensor(w_st)
+    cfg["hydrogen_bonding"]["ss_hb_weights"] = torch.as_tensor(w_hb)
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=False), _lib.param_names())
+    s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=torch.float64)
+    s.set_params(flat)
+    s.set_neighbors(top.unbonded_neighbors)
+    s.set_pseq(*scm.kernel_tables((up, bp), sc), 3)
+    gam_t, gam_r, seed = kT / 2.5, kT / 7.5, 0xFACE
+    integ = LangevinIntegrator(s, dt=0.004, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    c = torch.as_tensor(traj.center[3], device=s.device).contiguous()
+    q = torch.as_tensor(traj.quaternions[3], device=s.device).contiguous()
+    p, L = integ.init_momenta()
+    x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
+    start = [t.clone() for t in (c, q, p, L)]
+    tc, tq, et = integ.run(c, q, p, L, 6, save_every=save_every)
+    P = H.oracle_params(model, half_charged_ends=False, overrides={
+        "stacking": {"ss_stack_weights": w_st, "pseq": (up, bp), "pseq_constraints": sc},
+        "hydrogen_bonding": {"ss_hb_weights": w_hb, "pseq": (up, bp), "pseq_constraints": sc}})
+    lo = LangevinOracle(model, P, H.topo_tensors(top), traj.box_size, 0.004, kT, gam_t, gam_r, 1.0, (1.0, 1.2, 0.9), seed=seed)
+    P_d = H.oracle_params(model, half_charged_ends=False, overrides={"stacking": {"ss_stack_weights": w_st}, "hydrogen_bonding": {"ss_hb_weights": w_hb}})
+    lo_d = LangevinOracle(model, P_d, H.topo_tensors(top), traj.box_size, 0.004, kT, gam_t, gam_r, 1.0, (1.0, 1.2, 0.9), seed=seed)
+    xd, qd, pd, Ld = x.copy(), qq.copy(), pp.copy(), LL.copy()
+    for k in range(6):
+        x, qq, pp, LL, u = lo.step(x, qq, pp, LL)
+        xd, qd, pd, Ld, _ = lo_d.step(xd, qd, pd, Ld)
+        if save_every:
+            np.testing.assert_allclose(tc[k].cpu().numpy(), x, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(tq[k].cpu().numpy(), qq, rtol=0, atol=1e-10)
+            assert abs(et[k, :8].sum().item() - u) < 1e-8 * abs(u)
+    np.testing.assert_allclose(c.cpu().numpy(), x, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(p.cpu().numpy(), pp, atol=1e-9)
+    np.testing.assert_allclose(L.cpu().numpy(), LL, atol=1e-9)
+    assert np.abs(pp - pd).max() > 1e-5  # the distribution matters: the discrete sequence goes elsewhere
+    # the same six steps as load / advance(2) / advance(4) / store
+    c2, q2, p2, L2 = (t.clone() for t in start)
+    integ2 = LangevinIntegrator(s, dt=0.004, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed)
+    integ2.load(c2, q2, p2, L2)
+    integ2.advance(2)
+    integ2.advance(4)
+    integ2.store(c2, q2, p2, L2)
+    for a, b in zip((c2, q2, p2, L2), (c, q, p, L)):
+        assert torch.equal(a, b)
+    # back to the discrete sequence on the same system: the plain instantiation again
+    s.set_pseq()
+    c3, q3, p3, L3 = (t.clone() for t in start)
+    LangevinIntegrator(s, dt=0.004, kT=kT, gamma_t=gam_t, gamma_r=gam_r, mass=1.0, inertia=(1.0, 1.2, 0.9), seed=seed).run(c3, q3, p3, L3, 6)
+    np.testing.assert_allclose(p3.cpu().numpy(), pd, atol=1e-9)
+
+
+def test_simulator_runs_with_a_sequence_distribution():
+    """HipMDSimulator with a pseq energy function (the reference's plugin surface: the same energy function object goes
+    to the simulator): a one-hot distribution steps exactly as the discrete sequence does, fp32, dynamic list, and two
+    replicas of a soft distribution run in one launch per step (each replica its own copy of the base pairs)."""
+    import dataclasses as dc
+
     from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
     from mythos_amd.simulators.neighbors import NoNeighborList
 
     top, traj, _, _ = H.load_golden(2, "simple-helix")
     disp, shift = space.free()
-    sc = scm.from_bps(top.n_nucleotides, np.zeros((0, 2), dtype=np.int32))
-    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp).with_params(pseq=scm.dseq_to_pseq(top.seq, sc), pseq_constraints=sc)
+    n = top.n_nucleotides
+    sc = scm.from_bps(n, np.array([[0, 15], [3, 12]]))
+    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp)
+    hot = ef.with_params(pseq=scm.dseq_to_pseq(top.seq, sc), pseq_constraints=sc)
     kT = 296.15 * 0.1 / 300.0
     sp = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(kT / 2.5, kT / 7.5), bonded_neighbors=top.bonded_neighbors,
                                checkpoint_every=0, dt=0.005, kT=kT)
-    sim = HipMDSimulator(energy_fn=ef, simulator_params=sp, space=(disp, shift), simulator_init=nvt_langevin,
-                         neighbors=NoNeighborList(unbonded_nbrs=top.unbonded_neighbors))
-    with pytest.raises(ValueError, match="probabilistic sequence"):
-        sim.run({}, _states(traj, 0, torch.float32), 10, key=0)
-    # and the C ABI itself
-    from mythos_amd import _lib
-    from mythos_amd.hip_system import LangevinIntegrator
-    from tests.test_gpu_md_at_size import _system
-
-    s = _system(2, top, torch.float32, hce=False)
-    s.set_neighbors(top.unbonded_neighbors)
-    marg, unit, bp = scm.kernel_tables(scm.dseq_to_pseq(top.seq, sc), sc)
-    s.set_pseq(marg, unit, bp, 3)
-    integ = LangevinIntegrator(s, dt=0.005, kT=kT, gamma_t=kT / 2.5, gamma_r=kT / 7.5)
-    c = torch.as_tensor(traj.center[0], dtype=torch.float32, device=s.device).contiguous()
-    q = torch.as_tensor(traj.quaternions[0], dtype=torch.float32, device=s.device).contiguous()
-    p, L = torch.zeros_like(c), torch.zeros_like(c)
-    with pytest.raises(_lib.MythosHipError, match="probabilistic sequence"):
-        integ.run(c, q, p, L, 5)
-    s.set_pseq()
-    integ.run(c, q, p, L, 5)
+    base = HipMDSimulator(energy_fn=ef, simulator_params=sp, space=(disp, shift), simulator_init=nvt_langevin,
+                          neighbors=NoNeighborList(unbonded_nbrs=top.unbonded_neighbors), save_every=10)
+    st = _states(traj, 0, torch.float32)
+    a = base.run({}, st, 40, key=3).observables[0]
+    b = dc.replace(base, energy_fn=hot).run({}, st, 40, key=3).observables[0]
+    np.testing.assert_allclose(b.center.cpu().numpy(), a.center.cpu().numpy(), rtol=0, atol=2e-5)
+    rng = np.random.default_rng(2)
+    up = rng.random((sc.n_unpaired, 4)) + 0.1
+    bp = rng.random((sc.n_bp, 4)) + 0.1
+    soft = ef.with_params(pseq=(up / up.sum(1, keepdims=True), bp / bp.sum(1, keepdims=True)), pseq_constraints=sc)
+    two = dc.replace(base, energy_fn=soft, n_replicas=2).run({}, st, 40, key=3).observables[0]
+    assert two.center.shape[0] == 2 * 4 and torch.isfinite(two.center).all()
+    one = dc.replace(base, energy_fn=soft).run({}, st, 40, key=3).observables[0]
+    # replica 0 of the pair is the single run (same Philox stream per nucleotide index, same distribution)
+    np.testing.assert_allclose(two.center[:4].cpu().numpy(), one.center.cpu().numpy(), rtol=0, atol=5e-4)

@@ -147,3 +147,25 @@ def test_product_observables_need_a_gpu_and_share_the_host_side_pieces():
     top, traj = _duplex(6, frames=2)
     with pytest.raises(_lib.MythosHipError, match="GPU"):
         PO.PropellerTwist(np.array([[0, 11]]))(traj)
+
+
+def _known_answer_traj(centers, quats, frames):
+    c = torch.as_tensor(np.repeat(np.asarray(centers, dtype=np.float64)[None], frames, 0))
+    q = torch.as_tensor(np.repeat(np.asarray(quats, dtype=np.float64)[None], frames, 0))
+    return Traj(center=c, orientation=Quaternion(vec=q))
+
+
+def test_oracle_reproduces_the_references_own_known_answers():
+    """mythos/observables/tests/test_rise.py:14-33 (14.753608), :42-83 (11.065206), test_propeller.py:39-80 (120): the
+    values the reference's tests pin, through the oracle with site offsets 0 (tests/helpers.py says how the mocks map)."""
+    from tests import helpers as H
+
+    disp, _ = space.free()
+    ident = [[1.0, 0, 0, 0]] * 4
+    r1 = Rise(torch.as_tensor(H.RISE_SINGLE["quartets"]), disp, H.ZERO_GEOMETRY)(_known_answer_traj(H.RISE_SINGLE["centers"], ident, 1))
+    np.testing.assert_allclose(r1.numpy(), [H.RISE_SINGLE["expected"]], rtol=1e-7)
+    r2 = Rise(torch.as_tensor(H.RISE_CALL["quartets"]), disp, H.ZERO_GEOMETRY)(_known_answer_traj(H.RISE_CALL["centers"], ident, H.RISE_CALL["frames"]))
+    np.testing.assert_allclose(r2.numpy(), [H.RISE_CALL["expected"]] * H.RISE_CALL["frames"], rtol=1e-7)
+    pt = PropellerTwist(torch.as_tensor(H.PROPELLER_CALL["pairs"]))(
+        _known_answer_traj([[0.0, 0, 0]] * 4, H.PROPELLER_CALL["quats"], H.PROPELLER_CALL["frames"]))
+    np.testing.assert_allclose(pt.numpy(), [H.PROPELLER_CALL["expected"]] * H.PROPELLER_CALL["frames"], rtol=1e-7)
