@@ -7,7 +7,7 @@ Langevin) per GPU, one independent replica per GPU (BASELINE.json metric / confi
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --gpus N ...      (no launcher: starts the N ranks itself as child processes)
 
-A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin.hip).
+A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin_core.inc).
 The timed region is one ``mythos_langevin_advance`` call of exactly K steps with the state resident in HBM
 (loaded into the integrator before the clock starts), bracketed by barrier + synchronize, MAX over ranks.
 It is measured ``--repeats`` times back to back (default 5; the trajectory continues from sample to sample);

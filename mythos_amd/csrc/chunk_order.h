@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void chunk_keys_kernel(const V4* __restrict__ 
   }
 }
 
-__global__ void chunk_rank_kernel(const unsigned long long* __restrict__ keys, int blocks, int* __restrict__ order) {
+static __global__ void chunk_rank_kernel(const unsigned long long* __restrict__ keys, int blocks, int* __restrict__ order) {
   __shared__ unsigned long long tile[256];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long mine = c < blocks ? keys[c] : 0ull;

