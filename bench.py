@@ -379,7 +379,10 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
 def _timed_region(args, m, m2) -> str:
     """What the timed region held, in under 120 characters: steps, launches, list rebuilds inside the median sample,
     and the rate at the other precision."""
-    txt = (f"{args.steps} steps = {args.steps + 1} launches + {m['rebuilds_in_median']} list rebuilds + 1 sync; "
+    # (an advance call is one force evaluation per step: the closing half kick of its last step rides on the next call's
+    #  first launch - or on store's - see advance_typed in mythos_amd/csrc/langevin_core.inc)
+    closes = args.save_every > 0 and args.steps % args.save_every == 0
+    txt = (f"{args.steps} steps = {args.steps + (1 if closes else 0)} launches + {m['rebuilds_in_median']} list rebuilds + 1 sync; "
            f"median of {len(m['samples_ms'])}")
     if m2 is not None:
         other = "f64" if args.dtype == "f32" else "f32"

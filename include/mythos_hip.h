@@ -219,7 +219,13 @@ int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin
  *            needs the host to see the control words before the steps count as taken), nothing else between calls
  *   store    resident state -> caller's arrays (asynchronous on the stream); the state stays resident
  * mythos_langevin_run(...) == load; advance; store.  advance after advance continues bit for bit like one advance
- * of the summed length.  An advance that ends in MYTHOS_ERR_NUMERIC drops the resident state. */
+ * of the summed length.  An advance that ends in MYTHOS_ERR_NUMERIC drops the resident state.
+ * One force evaluation per step: advance(n) is n launches of the step kernel and leaves the resident momenta short of
+ * the closing half kick of step n, which needs the forces at x_n - the evaluation the next advance starts with anyway
+ * (as the reference's carry holds the force of the last step for the next one, jax_md simulate.nvt_langevin).  store
+ * supplies it with one more launch when the frame is still open, so what store hands back is always (x_n, p_n); an
+ * advance whose last step saves a trace row closes while it evaluates that row.  The mythos_langevin_last_* figures
+ * describe the last call that launched step kernels, store's closing launch included. */
 int mythos_langevin_load(mythos_sim_t* sim, const void* center, const void* quat, const void* p_lin, const void* p_ang,
                          mythos_stream_t stream);
 int mythos_langevin_advance(mythos_sim_t* sim, int n_steps, int save_every, void* traj_center, void* traj_quat,
@@ -286,7 +292,9 @@ enum mythos_debug_key {
   MYTHOS_DEBUG_MD_SEGMENT = 2,      /* step launches queued between two looks at the halt word (default 8192) */
   MYTHOS_DEBUG_MD_OVERFLOW_AT = 3,  /* k + 1: the scheduled list rebuild in front of step launch k reports a row
                                        overflow although its rows fit (one shot: cleared when it fires) */
-  MYTHOS_DEBUG_KEYS = 4
+  MYTHOS_DEBUG_MD_DENSE = 4,        /* 1: every fp32 oxDNA1/2 stepping launch takes the DENSE instantiation (normally
+                                       grids of more than four workgroups per CU), 2: none does */
+  MYTHOS_DEBUG_KEYS = 5
 };
 int mythos_debug_set(int key, int64_t value);
 int64_t mythos_debug_get(int key);

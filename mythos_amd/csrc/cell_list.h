@@ -69,28 +69,36 @@ __device__ __forceinline__ double cell_index_as_real(int i, double) { return (do
 __device__ __forceinline__ int cell_index_of(float w) { return __float_as_int(w); }
 __device__ __forceinline__ int cell_index_of(double w) { return (int)w; }
 
+// With sites (oxDNA rows built from MD frames): two more arrays of the same shape behind the first, the particle's
+// backbone offset and base vector - what the row builder's site criteria need of a candidate.  They used to be gathered
+// by index once the candidate's place had arrived (a second dependent round trip per sweep, 16-byte gathers that do not
+// coalesce); now the three records of a candidate sit at the same offset of three streams and are requested together.
 struct CellBins {
-  void* place = nullptr;    // [H * cap] CellPlace<R>: (x, y, z, index) of the particles of a slot
+  void* place = nullptr;    // [H * cap] CellPlace<R>: (x, y, z, index) of the particles of a slot; sites: [3][H * cap]
   int* cnt_cur = nullptr;   // [H + 1] this build's counters (zero on entry); [H] counts the spill list
   int* cnt_next = nullptr;  // [H + 1] cleared by this build
   int* bucket = nullptr;    // [H * cap] the indices alone (sorting, home lookups)
   int* spill = nullptr;     // [kCellSpill] particles that found their bucket full: candidates for everybody
   int H = 0, cap = 0;
+  bool sites = false;
   static size_t half(int H) { return (size_t)4 * ((H + 1 + 3) / 4); }
-  static size_t place_ints(int H, int cap, size_t real_bytes) { return (size_t)H * cap * real_bytes; }  // 4 reals / 4 B
-  static size_t ints(int H, int cap, size_t real_bytes) {
-    return place_ints(H, cap, real_bytes) + 2 * half(H) + (size_t)H * cap + kCellSpill;
+  static size_t place_ints(int H, int cap, size_t real_bytes, bool sites = false) {  // 4 reals / 4 B
+    return (size_t)H * cap * real_bytes * (sites ? 3 : 1);
+  }
+  static size_t ints(int H, int cap, size_t real_bytes, bool sites = false) {
+    return place_ints(H, cap, real_bytes, sites) + 2 * half(H) + (size_t)H * cap + kCellSpill;
   }
   // view on one allocation of ints(H, cap, sizeof(R)) ints whose counter halves were zeroed when it was made (see
   // zero_offset / zero_ints); phase flips per build
-  CellBins(int* base, int H_, int cap_, size_t real_bytes, int phase) : place(base), H(H_), cap(cap_) {
-    int* c = base + place_ints(H_, cap_, real_bytes);
+  CellBins(int* base, int H_, int cap_, size_t real_bytes, int phase, bool sites_ = false)
+      : place(base), H(H_), cap(cap_), sites(sites_) {
+    int* c = base + place_ints(H_, cap_, real_bytes, sites_);
     cnt_cur = c + (phase & 1) * half(H_);
     cnt_next = c + ((phase & 1) ^ 1) * half(H_);
     bucket = c + 2 * half(H_);
     spill = bucket + (size_t)H_ * cap_;
   }
-  static size_t zero_offset(int H, int cap, size_t real_bytes) { return place_ints(H, cap, real_bytes); }
+  static size_t zero_offset(int H, int cap, size_t real_bytes, bool sites = false) { return place_ints(H, cap, real_bytes, sites); }
   static size_t zero_ints(int H) { return 2 * half(H); }
 };
 
@@ -121,7 +129,9 @@ static __global__ __launch_bounds__(256) void cell_bin_kernel(int n, const R* __
                                                              int* __restrict__ cnt_next, int* __restrict__ bucket,
                                                              int cap, int* __restrict__ spill,
                                                              typename CellPlace<R>::type* __restrict__ place,
-                                                             int* __restrict__ overflow) {
+                                                             int* __restrict__ overflow,
+                                                             const typename CellPlace<R>::type* __restrict__ off,
+                                                             const typename CellPlace<R>::type* __restrict__ a1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63;
   if (i <= H) cnt_next[i] = 0;
@@ -145,6 +155,11 @@ static __global__ __launch_bounds__(256) void cell_bin_kernel(int n, const R* __
     typename CellPlace<R>::type pl;
     pl.x = x, pl.y = y, pl.z = z, pl.w = cell_index_as_real(i, R(0));
     place[(size_t)h * cap + p] = pl;
+    if (off) {  // (real4 per particle, as the MD frames hold them)
+      const size_t HC = (size_t)H * cap;
+      place[HC + (size_t)h * cap + p] = off[i];
+      place[2 * HC + (size_t)h * cap + p] = a1[i];
+    }
   } else {
     const int q = atomicAdd(&cnt_cur[H], 1);
     if (q < kCellSpill)
@@ -222,13 +237,17 @@ static inline int next_pow2(int v) {
 
 // bins n particles at pos (stride 3 or 4 reals) into b; overflow: int[3] of the caller ([0] rows, [1] spill list over
 // capacity, [2] fullest bucket if over half its capacity), not cleared here.  sort_buckets: order every bucket by particle index afterwards (one more launch).
+// off, a1 (with b.sites; real4 per particle): copied into the two site streams; the bucket sort moves the first stream only
 template <typename R, bool VEC4>
 static inline void cell_bins_build(int n, const R* pos, CellGrid<R>& g, const CellBins& b, int* overflow,
-                                   bool sort_buckets, hipStream_t st) {
+                                   bool sort_buckets, hipStream_t st, const R* off = nullptr, const R* a1 = nullptr) {
   if (!g.direct) g.hmask = b.H - 1;
   const int threads = n > b.H + 1 ? n : b.H + 1;
+  using PL = typename CellPlace<R>::type;
+  const bool sites = b.sites && off && a1 && !sort_buckets;
   hipLaunchKernelGGL((cell_bin_kernel<R, VEC4>), dim3((threads + 255) / 256), dim3(256), 0, st, n, pos, g, b.H, b.cnt_cur,
-                     b.cnt_next, b.bucket, b.cap, b.spill, (typename CellPlace<R>::type*)b.place, overflow);
+                     b.cnt_next, b.bucket, b.cap, b.spill, (PL*)b.place, overflow, sites ? (const PL*)off : nullptr,
+                     sites ? (const PL*)a1 : nullptr);
   if (sort_buckets)
     hipLaunchKernelGGL((cell_sort_bins_kernel<R, VEC4>), dim3((b.H + 1 + 3) / 4), dim3(256), 0, st, b.H, b.cnt_cur, b.bucket, b.cap,
                        b.spill, pos, (typename CellPlace<R>::type*)b.place);

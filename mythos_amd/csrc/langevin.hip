@@ -141,9 +141,9 @@ int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st)
   return s->sys->dtype == MYTHOS_F32 ? mythos_md_load<float>(s, c, q, p, l, st) : mythos_md_load<double>(s, c, q, p, l, st);
 }
 
-int md_advance(mythos_sim_t* s, int n_steps, int save_every, void* tc, void* tq, double* e_trace, hipStream_t st) {
-  return s->sys->dtype == MYTHOS_F32 ? mythos_md_advance<float>(s, n_steps, save_every, tc, tq, e_trace, st)
-                                     : mythos_md_advance<double>(s, n_steps, save_every, tc, tq, e_trace, st);
+int md_advance(mythos_sim_t* s, int n_steps, int save_every, bool close, void* tc, void* tq, double* e_trace, hipStream_t st) {
+  return s->sys->dtype == MYTHOS_F32 ? mythos_md_advance<float>(s, n_steps, save_every, close, tc, tq, e_trace, st)
+                                     : mythos_md_advance<double>(s, n_steps, save_every, close, tc, tq, e_trace, st);
 }
 
 int md_store(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st) {
@@ -162,7 +162,7 @@ int mythos_langevin_run(mythos_sim_t* s, void* center, void* quat, void* p_lin, 
   if (int rc = md_ready(s, "mythos_langevin_run")) return rc;
   hipStream_t st = (hipStream_t)stream;
   if (int rc = md_load(s, center, quat, p_lin, p_ang, st)) return rc;
-  const int rc = md_advance(s, n_steps, save_every, traj_center, traj_quat, e_trace, st);
+  const int rc = md_advance(s, n_steps, save_every, true, traj_center, traj_quat, e_trace, st);
   // the state of the last valid step goes back to the caller whatever the run reported
   if (int rs = md_store(s, center, quat, p_lin, p_ang, st)) return rc ? rc : rs;
   return rc;
@@ -190,7 +190,7 @@ int mythos_langevin_advance(mythos_sim_t* s, int n_steps, int save_every, void* 
     return MYTHOS_ERR_NOT_READY;
   }
   if (int rc = md_ready(s, "mythos_langevin_advance")) return rc;
-  return md_advance(s, n_steps, save_every, traj_center, traj_quat, e_trace, (hipStream_t)stream);
+  return md_advance(s, n_steps, save_every, false, traj_center, traj_quat, e_trace, (hipStream_t)stream);
 }
 
 int mythos_langevin_store(mythos_sim_t* s, void* center, void* quat, void* p_lin, void* p_ang, mythos_stream_t stream) {
@@ -202,7 +202,7 @@ int mythos_langevin_store(mythos_sim_t* s, void* center, void* quat, void* p_lin
     set_error("mythos_langevin_store: no resident state");
     return MYTHOS_ERR_NOT_READY;
   }
-  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  if (int rc = md_ready(s, "mythos_langevin_store")) return rc;  // (an open frame is closed by one more launch)
   return md_store(s, center, quat, p_lin, p_ang, (hipStream_t)stream);
 }
 

@@ -77,6 +77,7 @@ struct mythos_system {
   size_t cell_cap = 0;        // ints allocated at d_cell
   int cell_H = 0;             // table slots of the current allocation
   int cell_alloc_bucket_cap = 0;  // places per slot the allocation was laid out for
+  bool cell_sites = false;    // the allocation carries the two site streams (cell_list.h CellBins::sites)
   int cell_bucket_cap = 32;   // places per slot
   int cell_phase = 0;         // which counter half the next build counts into
   void* d_ref_pos = nullptr;  // [n] real4 positions at the last build (MD displacement check)

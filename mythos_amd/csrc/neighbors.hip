@@ -79,23 +79,21 @@ struct SiteCrit {
   R g_ba, g_st;  // site positions along a1
 };
 
-template <typename R>
-__device__ __forceinline__ bool far_in_range(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
-  if (!sc.off) return true;
-  const R* oi = sc.off + 4 * i;
-  const R* oj = sc.off + 4 * j;
+// (the _v forms take the four vectors; the index forms fetch them)
+template <typename R, class A>
+__device__ __forceinline__ bool far_in_range_v(const SiteCrit<R>& sc, const A& oi, const A& oj, const V3<R>& d) {
   const V3<R> e{d.x + oj[0] - oi[0], d.y + oj[1] - oi[1], d.z + oj[2] - oi[2]};
   return dot(e, e) < sc.rbb2;
 }
+template <typename R>
+__device__ __forceinline__ bool far_in_range(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
+  if (!sc.off) return true;
+  return far_in_range_v(sc, sc.off + 4 * i, sc.off + 4 * j, d);
+}
 
 // d = centre_j - centre_i (minimum image), already known to be inside the centre range of the close segment
-template <typename R>
-__device__ __forceinline__ bool site_close(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
-  if (!sc.off) return true;
-  const R* ai = sc.a1 + 4 * i;
-  const R* aj = sc.a1 + 4 * j;
-  const R* oi = sc.off + 4 * i;
-  const R* oj = sc.off + 4 * j;
+template <typename R, class A>
+__device__ __forceinline__ bool site_close_v(const SiteCrit<R>& sc, const A& ai, const A& oi, const A& aj, const A& oj, const V3<R>& d) {
   const V3<R> da{aj[0] - ai[0], aj[1] - ai[1], aj[2] - ai[2]};
   V3<R> e = d;
   axpy(e, sc.g_ba, da);
@@ -107,6 +105,11 @@ __device__ __forceinline__ bool site_close(const SiteCrit<R>& sc, int i, int j, 
   if (dot(e, e) < sc.rkb2) return true;
   e = V3<R>{d.x + oj[0] - sc.g_ba * ai[0], d.y + oj[1] - sc.g_ba * ai[1], d.z + oj[2] - sc.g_ba * ai[2]};  // back_j - base_i
   return dot(e, e) < sc.rkb2;
+}
+template <typename R>
+__device__ __forceinline__ bool site_close(const SiteCrit<R>& sc, int i, int j, const V3<R>& d) {
+  if (!sc.off) return true;
+  return site_close_v(sc, sc.a1 + 4 * i, sc.off + 4 * i, sc.a1 + 4 * j, sc.off + 4 * j, d);
 }
 
 template <typename R, bool VEC4>
@@ -185,8 +188,9 @@ __device__ __forceinline__ void group_sort_to_row(const int* buf, int cnt, int* 
 
 // ------------------------------------------------------------------------------------------------
 // Cell-list builder: G lanes per nucleotide (kRowG = 16: four nucleotides per wavefront).  A row is the end of a
-// chain of dependent reads (own position -> 27 cell counters -> bucket entries -> candidate positions -> candidate
-// sites) and a wavefront spends its life waiting on them; a 12 kbp duplex has ~57 candidates per nucleotide, so a
+// chain of dependent reads (own position -> 27 cell counters -> bucket entries: position, index and - from the site
+// streams of the cell table, cell_list.h - backbone offset and base vector of the candidate, requested together) and a
+// wavefront spends its life waiting on them; a 12 kbp duplex has ~57 candidates per nucleotide, so a
 // full wavefront per nucleotide filled the machine three times over with waves that each wait the whole chain.
 // Four nucleotides per wavefront fit all of them on the chip at once.  The group's lanes look up the 27 neighbour
 // cells and the spill list, the candidate lists are concatenated by a prefix sum and swept G at a time with ballot
@@ -206,6 +210,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
                                                                 const int* __restrict__ cell_cnt,
                                                                 const typename CellPlace<R>::type* __restrict__ place,
                                                                 int cell_cap, const int* __restrict__ spill, int cell_H,
+                                                                size_t site_stride,  // H * cap when the table carries the site streams, else 0
                                                                 int* __restrict__ rows,
                                                                 int* __restrict__ row_len, int* __restrict__ row_close,
                                                                 int row_stride, int* __restrict__ overflow,
@@ -223,10 +228,21 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
   int* s_far = s_close + row_stride;
   constexpr int S = VEC4 ? 4 : 3;
   const V3<R> ci{pos[S * i], pos[S * i + 1], pos[S * i + 2]};
+  using PL = typename CellPlace<R>::type;
+  R oi[3] = {R(0), R(0), R(0)}, ai[3] = {R(0), R(0), R(0)};  // own backbone offset and base vector
+  if (sc.off) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) oi[a] = sc.off[4 * (size_t)i + a], ai[a] = sc.a1[4 * (size_t)i + a];
+  }
   int cx, cy, cz;
   cell_of(g, ci.x, ci.y, ci.z, cx, cy, cz);
-  for (int k = l; k < 28; k += G) {
-    int cnt;
+  // the 27 cells' counters and the spill list's, G at a time, with their running sum (an inclusive scan over the group's
+  // lanes through the cross-lane network; one lane adding up 28 LDS words was 1.5 us of every row's chain)
+  int carry = 0;
+  if (l == 0) s_pre[grp][0] = 0;
+  for (int k0 = 0; k0 < 28; k0 += G) {
+    const int k = k0 + l;
+    int cnt = 0;
     if (k < 27) {
       int c[3] = {cx + k % 3 - 1, cy + (k / 3) % 3 - 1, cz + k / 9 - 1};
 #pragma unroll
@@ -236,20 +252,17 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
       cnt = min(cell_cnt[h], cell_cap);
       s_st[grp][k] = h * cell_cap;
       s_c[grp][k][0] = c[0], s_c[grp][k][1] = c[1], s_c[grp][k][2] = c[2];
-    } else {  // the spill list: particles whose bucket was full, candidates for every row
+    } else if (k == 27) {  // the spill list: particles whose bucket was full, candidates for every row
       cnt = min(cell_cnt[cell_H], kCellSpill);
     }
-    s_pre[grp][k + 1] = cnt;
-  }
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  if (l == 0) {
-    int run = 0;
-    s_pre[grp][0] = 0;
-    for (int k = 1; k <= 28; ++k) {
-      run += s_pre[grp][k];
-      s_pre[grp][k] = run;
+    int run = cnt;
+#pragma unroll
+    for (int d = 1; d < G; d <<= 1) {
+      const int o = __shfl_up(run, d, G);
+      if (l >= d) run += o;
     }
+    if (k < 28) s_pre[grp][k + 1] = carry + run;
+    carry += __shfl(run, G - 1, G);
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -267,13 +280,23 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
     if (t < total) {
       while (s_pre[grp][lo + 1] <= t) ++lo;
       R xj, yj, zj;
-      if (lo < 27) {  // position and index of the candidate arrive together, as a contiguous stream per cell
-        const typename CellPlace<R>::type pl = place[s_st[grp][lo] + (t - s_pre[grp][lo])];
+      R oj[3] = {R(0), R(0), R(0)}, aj[3] = {R(0), R(0), R(0)};
+      if (lo < 27) {  // everything about the candidate arrives together, as contiguous streams per cell
+        const size_t at = (size_t)s_st[grp][lo] + (t - s_pre[grp][lo]);
+        const PL pl = place[at];
+        if (site_stride) {
+          const PL po = place[site_stride + at], pa = place[2 * site_stride + at];
+          oj[0] = po.x, oj[1] = po.y, oj[2] = po.z, aj[0] = pa.x, aj[1] = pa.y, aj[2] = pa.z;
+        }
         xj = pl.x, yj = pl.y, zj = pl.z;
         j = cell_index_of(pl.w);
       } else {
         j = spill[t - s_pre[grp][27]];
         xj = pos[S * j], yj = pos[S * j + 1], zj = pos[S * j + 2];
+        if (site_stride) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) oj[a] = sc.off[4 * (size_t)j + a], aj[a] = sc.a1[4 * (size_t)j + a];
+        }
       }
       if (j != i && j != bp.x && j != bp.y && j != bp.z && j != bp.w) {
         bool mine = true;  // hashed table: a bucket may mix cells, a candidate counts for the cell it lies in
@@ -287,8 +310,13 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
           d = min_image(d, box);
           const R r2 = dot(d, d);
           if (r2 < rc2) {
-            hit_c = r2 < rcl2 && site_close(sc, i, j, d);
-            hit_f = !hit_c && far_in_range(sc, i, j, d);
+            if (site_stride) {
+              hit_c = r2 < rcl2 && site_close_v(sc, ai, oi, aj, oj, d);
+              hit_f = !hit_c && far_in_range_v(sc, oi, oj, d);
+            } else {
+              hit_c = r2 < rcl2 && site_close(sc, i, j, d);
+              hit_f = !hit_c && far_in_range(sc, i, j, d);
+            }
           }
         }
       }
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(256) void build_rows_cells_kernel(int n, const R* _
         R* ro = ref_off + 4 * (size_t)i;
         R* ra = ref_a1 + 4 * (size_t)i;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ro[k] = sc.off[4 * i + k], ra[k] = sc.a1[4 * i + k];
+        for (int k = 0; k < 4; ++k) ro[k] = sc.off[4 * (size_t)i + k], ra[k] = sc.a1[4 * (size_t)i + k];
       }
     }
   }
@@ -406,23 +434,26 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const int H = next_pow2(2 * n);
   if (cell_cap_override()) sys->cell_bucket_cap = cell_cap_override();
   const int cap = sys->cell_bucket_cap;
-  const size_t need = CellBins::ints(H, cap, sizeof(R));
-  if (need > sys->cell_cap || H != sys->cell_H || cap != sys->cell_alloc_bucket_cap) {
+  const bool sites = sc.off != nullptr && vec4;  // MD frames: offsets and base vectors ride in the cell table
+  const size_t need = CellBins::ints(H, cap, sizeof(R), sites);
+  if (need > sys->cell_cap || H != sys->cell_H || cap != sys->cell_alloc_bucket_cap || sites != sys->cell_sites) {
     if (sys->d_cell) (void)hipFree(sys->d_cell);
     sys->d_cell = nullptr;
     sys->cell_cap = 0;
     MYTHOS_HIP_TRY(hipMalloc((void**)&sys->d_cell, need * sizeof(int)));
-    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_cell + CellBins::zero_offset(H, cap, sizeof(R)), 0, CellBins::zero_ints(H) * sizeof(int), st));
+    MYTHOS_HIP_TRY(hipMemsetAsync(sys->d_cell + CellBins::zero_offset(H, cap, sizeof(R), sites), 0, CellBins::zero_ints(H) * sizeof(int), st));
     sys->cell_cap = need;
+    sys->cell_sites = sites;
     sys->cell_H = H;
     sys->cell_alloc_bucket_cap = cap;
     sys->cell_phase = 0;
   }
-  const CellBins bins(sys->d_cell, H, cap, sizeof(R), sys->cell_phase);
+  const CellBins bins(sys->d_cell, H, cap, sizeof(R), sys->cell_phase, sites);
   sys->cell_phase ^= 1;
+  const size_t site_stride = sites ? (size_t)H * cap : 0;
   // the row builder orders its rows itself: no bucket sort
   if (vec4)
-    cell_bins_build<R, true>(n, pos, g, bins, sys->d_overflow, false, st);
+    cell_bins_build<R, true>(n, pos, g, bins, sys->d_overflow, false, st, sc.off, sc.a1);
   else
     cell_bins_build<R, false>(n, pos, g, bins, sys->d_overflow, false, st);
   constexpr int kPerBlock = 256 / kRowG;
@@ -430,11 +461,11 @@ static int build_cells_typed(mythos_system* sys, const R* pos, bool vec4, double
   const size_t far_lds = (size_t)kPerBlock * 2 * sys->row_stride * sizeof(int);
   if (vec4)
     hipLaunchKernelGGL((build_rows_cells_kernel<R, true, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, site_stride, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   else
     hipLaunchKernelGGL((build_rows_cells_kernel<R, false, kRowG>), dim3(wb), dim3(256), far_lds, st, n, pos, box, g, R(rl * rl),
-                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
+                       R(rcl * rcl), sc, d_partners, bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, site_stride, sys->d_rows, sys->d_row_len, d_close, sys->row_stride,
                        sys->d_overflow, ref_pos, ref_off, ref_a1);
   return 0;
 }

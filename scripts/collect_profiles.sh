@@ -6,8 +6,10 @@
 # --stats table.  The program after `--` is python itself.  Copy gpurun_out/<tag>/profiles/* into profiles/ afterwards.
 set -eo pipefail
 tag=${1:-r03}
+part=${2:-all}   # "md", "rest" or "all": the whole collection is ~20 profiled runs, two gpurun calls fit it comfortably
 out=gpurun_out/$tag
-rm -rf "$out"; mkdir -p "$out/profiles"
+[ "$part" = rest ] || rm -rf "$out"
+mkdir -p "$out/profiles"
 export TMPDIR=/tmp
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES"
 one() {  # name, "alg-bytes args", command...
@@ -16,17 +18,22 @@ one() {  # name, "alg-bytes args", command...
   rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $out/${name}_pmc -- "$@" > $out/${name}_pmc.log 2>&1
   python scripts/profile_summary.py $out/${name}_trace $out/${name}_pmc $out/profiles/${tag}_${name}.json --command "$*" $alg > $out/${name}_summary.txt
   cat $out/${name}_summary.txt
+  cp "$(find $out/${name}_trace -name '*kernel_stats.csv' | head -n 1)" $out/profiles/${tag}_${name}_kernel_stats.csv
+  rm -rf $out/${name}_trace $out/${name}_pmc   # (gpurun_out/ travels back only while it is small)
   echo "[profiles] $name done"
 }
 short="--steps 500 --warmup 100 --cpu-steps 0 --no-second-dtype --repeats 1"
 # algorithmic bytes per launch: n (2 * 14 * s + 13 + 4 * nbar), nbar = 20.84 at skin 0.6 (bench.py prints it)
+if [ "$part" != rest ]; then
 one md_12kbp_f32 "--alg-bytes md_step_kernel<float=5000744" python bench.py $short
 one md_12kbp_f64 "--alg-bytes md_step_kernel<double=7688736" python bench.py $short --dtype f64
 one md_100kbp_f32 "" python bench.py --bp 100000 --steps 150 --warmup 30 --cpu-steps 0 --no-second-dtype --repeats 1
-one martini_md "" python bench.py --workload martini-bilayer --steps 500 --warmup 100
-one energy_difftre "" python scripts/bench_energy.py
 one md_rna2 "" python scripts/bench_rna2.py 500
 one md_na1 "" python scripts/bench_na1.py
+fi
+[ "$part" = md ] && exit 0
+one martini_md "" python bench.py --workload martini-bilayer --steps 500 --warmup 100
+one energy_difftre "" python scripts/bench_energy.py
 one observables "" python scripts/bench_observables.py
 # the headline kernel: trace of the DEFAULT bench command (what the driver's number comes from) + HBM traffic passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --cpu-steps 0 > $out/bench_profiled.log 2>&1
@@ -34,5 +41,7 @@ cp "$(find $out/stats -name '*kernel_stats.csv' | head -n 1)" $out/profiles/${ta
 grep '^{' $out/bench_profiled.log | tail -n 1 > $out/profiles/${tag}_bench_profiled_line.json || true
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python bench.py $short > $out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python bench.py $short > $out/pmc_write.log 2>&1
+rm -rf $out/stats
 python scripts/collect_traffic.py $out/pmc_fetch $out/pmc_write --n 24000 --kernel 'md_step_kernel<float' --out $out/profiles/traffic.json
+rm -rf $out/pmc_fetch $out/pmc_write
 echo "[profiles] written to $out/profiles"

@@ -88,13 +88,15 @@ def _body_torque(q, gq):
     return orc.quat_grad_to_body_torque(torch.as_tensor(q), torch.as_tensor(gq)).numpy()
 
 
-def test_12kbp_fp32_step_matches_energy_kernel_forces():
+@pytest.mark.parametrize("bp", [12000, 17000])
+def test_12kbp_fp32_step_matches_energy_kernel_forces(bp):
     """One step from rest, no friction, no noise: p1 = dt/2 (F(x0) + F(x1)), x1 = x0 + dt^2/2 F(x0), the rotor likewise.
-    The reference arithmetic: oracle/langevin_oracle.py's drift on forces from the fp64 energy kernel."""
+    The reference arithmetic: oracle/langevin_oracle.py's drift on forces from the fp64 energy kernel.
+    17 kbp: 1 063 workgroups, more than four per CU of a 256-CU device - the DENSE instantiation of the step kernel."""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import drift
 
-    top, c0, q0 = generators.ideal_duplex(12000, model=2, seed=1234)
+    top, c0, q0 = generators.ideal_duplex(bp, model=2, seed=1234)
     rng = np.random.default_rng(11)
     c0 = c0 + 0.015 * rng.standard_normal(c0.shape)  # off the symmetric point: forces of order 10, a few of order 100
     q0 = q0 + 0.0075 * rng.standard_normal(q0.shape)
@@ -503,3 +505,83 @@ def test_resident_advances_equal_one_run_bitwise():
         res.append([t.clone() for t in (c, q, p, L)])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_advance_leaves_the_frame_open_and_store_closes_it(dtype):
+    """mythos_langevin_advance(n) is n launches: the closing half kick of step n comes with the next force evaluation -
+    the next advance's first launch, or one launch inside mythos_langevin_store.  Whatever the sequence of calls, the
+    state handed back is the one mythos_langevin_run(total) hands back, bit for bit; a second store changes nothing."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(400, model=2, seed=77)
+    s = _system(2, top, dtype)
+
+    def fresh():
+        integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=9)
+        integ.set_neighbor_policy(R_CUT, 0.6, 25)
+        integ.set_timing(1)
+        return integ, _dev(c0, dtype, s), _dev(q0, dtype, s)
+
+    integ, c, q = fresh()
+    p, L = integ.init_momenta()
+    integ.run(c, q, p, L, 60)
+    assert integ.last_kernel_ms()["launches"] == 61
+    want = [t.clone() for t in (c, q, p, L)]
+
+    integ, c, q = fresh()
+    p, L = integ.init_momenta()
+    integ.load(c, q, p, L)
+    integ.advance(20)
+    assert integ.last_kernel_ms()["launches"] == 20
+    out = [torch.empty_like(t) for t in (c, q, p, L)]
+    integ.store(*out)  # closes: one launch, no step
+    assert integ.last_kernel_ms()["launches"] == 1 and integ.step == 20
+    again = [torch.empty_like(t) for t in (c, q, p, L)]
+    integ.store(*again)  # already closed: a copy
+    for a, b in zip(out, again):
+        assert torch.equal(a, b)
+    integ.advance(15)  # from a closed frame
+    integ.advance(5)   # from an open one
+    assert integ.last_kernel_ms()["launches"] == 5
+    _, _, et = integ.advance(20, save_every=10)  # the last step saves a row: evaluated at x_n, closed while there
+    assert integ.last_kernel_ms()["launches"] == 21 and et.shape[0] == 2
+    integ.store(c, q, p, L)
+    assert integ.step == 60
+    for a, b in zip(want, (c, q, p, L)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("model", [1, 2])
+def test_dense_instantiation_steps_like_the_fixed_row_one(model):
+    """The DENSE fp32 instantiation (result rows out of the workgroup's pool, five workgroups per CU) serves grids of
+    more than four workgroups per CU; forced on a small system through mythos_debug_set it steps the trajectory of the
+    fixed-row instantiation to fp32 rounding (two compilations of the same arithmetic: not bit for bit), and a thin
+    skin takes both through halts and out-of-turn rebuilds."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(700, model=model, seed=4)
+    s = _system(model, top, torch.float32)
+    res = []
+    try:
+        for mode in (2, 1):
+            _lib.debug_set("md_dense", mode)
+            integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=21)
+            integ.set_neighbor_policy(R_CUT, 0.25, 30)  # a thin skin: some rebuilds come out of turn
+            c, q = _dev(c0, torch.float32, s), _dev(q0, torch.float32, s)
+            p, L = integ.init_momenta()
+            integ.load(c, q, p, L)
+            integ.advance(10)
+            integ.advance(15)
+            integ.store(c, q, p, L)
+            near = [t.clone() for t in (c, q, p, L)]
+            integ.advance(200)
+            rec = integ.last_recoveries()
+            integ.store(c, q, p, L)
+            res.append((near, rec, torch.isfinite(c).all().item() and torch.isfinite(p).all().item()))
+    finally:
+        _lib.debug_set("md_dense", 0)
+    assert res[0][1] >= 1 and res[1][1] >= 1 and res[0][2] and res[1][2]
+    for a, b in zip(res[0][0], res[1][0]):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-4 * scale + 2e-6
