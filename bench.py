@@ -71,6 +71,8 @@ def parse_args():
                     help="oxdna2-12kbp is the headline (BASELINE.json metric); martini-bilayer is BASELINE configs[2] "
                          "(20 480-bead DMPC bilayer, LJ + bonds + angles, Langevin) and prints its own line")
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the measurement at the other precision (config.f64 / config.f32)")
+    ap.add_argument("--instrument-steps", type=int, default=512,
+                    help="least length of the untimed, event-instrumented pass behind the timed region (dev: short runs of wrong-physics bounds)")
     ap.add_argument("--repeats", type=int, default=5,
                     help="the timed region (exactly --steps steps) is run this many times back to back, each bracketed by barrier + "
                          "synchronize; value = steps / the MEDIAN sample, every sample is in config.samples_ms")
@@ -359,7 +361,7 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     # ---- instrumented pass (untimed): duration of the step kernel from HIP events attached to sampled dispatches on
     #      the launch stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
     integ.set_timing(16)
-    integ.advance(max(args.steps, 512))  # sampled dispatches far apart: a bracketed one disturbs the few behind it
+    integ.advance(max(args.steps, args.instrument_steps))  # sampled dispatches far apart: a bracketed one disturbs the few behind it
     timing = integ.last_kernel_ms()
     integ.set_timing(0)
     integ.store(c, q, p, L)

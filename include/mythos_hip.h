@@ -162,8 +162,9 @@ int mythos_oxdna_energy(mythos_system_t* sys, const void* center, const void* qu
  * Output row per frame, mythos_observables_width() = 4 + n_corr doubles (n_corr = n_q - 4 with skip_ends, else n_q):
  *   [0] propeller twist (deg)  [1] rise (Angstrom)  [2] pitch angle (rad)  [3] mean base-pair spacing <l0>
  *   [4 + d] autocorrelation C(d) of the local helical axes.   Entries whose list is empty are 0.
- * mythos_observables_eval is the stand-alone launch; mythos_oxdna_energy_obs evaluates the same rows in the epilogue of
- * the energy launch (one read of the trajectory for energies, dU/dparams and observables: the DiffTRe data path). */
+ * mythos_observables_eval is the stand-alone launch; mythos_oxdna_energy_obs returns the same rows with the energies - the
+ * same kernel, queued behind the energy launch of that call while the frames are still in L2 (energies, dU/dparams and
+ * observables from one call: the DiffTRe data path). */
 mythos_obs_t* mythos_observables_create(int model, int n, const double* geometry, const double* box, int n_bp,
                                         const int32_t* base_pairs, int n_quartets, const int32_t* quartets, int skip_ends,
                                         int dtype, int device);

@@ -1,8 +1,8 @@
 // Per-frame structural observables of oxDNA duplex trajectories, evaluated by ONE workgroup per frame:
 // propeller twist, helical rise, pitch angle and the persistence-length partials (mean base-pair spacing and the
-// autocorrelation of the local helical axes).  Called from two places: the stand-alone kernel behind
-// mythos_observables_eval, and the epilogue of oxdna_energy_kernel (workgroup 0 of every frame), so that a DiffTRe
-// evaluation - energies, dU/dtheta and the observable it reweights - reads the stored trajectory once.
+// autocorrelation of the local helical axes).  Launched from two places: mythos_observables_eval, and
+// mythos_oxdna_energy_obs (behind its energy launch, while the frames are still in L2), so that a DiffTRe evaluation -
+// energies, dU/dtheta and the observable it reweights - is one call.
 //
 // What is computed follows the reference function by function:
 //   propeller twist  mythos/observables/propeller.py:19-71   mean over the listed base pairs of 180 - acos(a3_i . a3_j) [deg]

@@ -1,6 +1,5 @@
 // Observable sets behind the C ABI (mythos_observables_*): see observables.h for what is computed and where the
-// reference defines it.  The stand-alone kernel runs one workgroup per frame; the fused path is the epilogue of
-// oxdna_energy_kernel (oxdna_kernels.hip).
+// reference defines it.  One workgroup per frame; mythos_oxdna_energy_obs (oxdna_kernels.hip) queues the same kernel behind its energy launch.
 #include "observables.h"
 
 #include "mythos_internal.h"
@@ -31,11 +30,15 @@ int obs_view_for(mythos_obs* o, int n_frames, ObsView* out) {
 
 int observables_launch(mythos_obs* o, const ObsView& v, const void* center, const void* quat, int n_frames, double* out,
                        hipStream_t st) {
+  // one workgroup per frame; a frame whose lists fit one wavefront (the DiffTRe systems: 30 base pairs, 31 quartets) gets
+  // a workgroup of one - its sums are the first wavefront's sums of the wider workgroup bit for bit (the other partials
+  // are zeros), its barriers cost nothing, and four times as many frames are in flight
+  const int threads = (v.n_bp <= 64 && v.n_q <= 64) ? 64 : 256;
   if (o->dtype == MYTHOS_F32)
-    hipLaunchKernelGGL(observables_kernel<float>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const float*)center,
+    hipLaunchKernelGGL(observables_kernel<float>, dim3(n_frames), dim3(threads), 0, st, v, o->n, (const float*)center,
                        (const float*)quat, out);
   else
-    hipLaunchKernelGGL(observables_kernel<double>, dim3(n_frames), dim3(256), 0, st, v, o->n, (const double*)center,
+    hipLaunchKernelGGL(observables_kernel<double>, dim3(n_frames), dim3(threads), 0, st, v, o->n, (const double*)center,
                        (const double*)quat, out);
   MYTHOS_HIP_TRY(hipGetLastError());
   return 0;

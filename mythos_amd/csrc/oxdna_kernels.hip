@@ -70,16 +70,14 @@ constexpr int energy_blocks_per_cu() {
 }
 
 // SEG: rows longer than the LDS lists are walked in segments (gather_row)
-// OBS: the instantiation carries the observables epilogue.  A template parameter, not a run-time branch: the epilogue's
-// fp64 site algebra would otherwise set the register count of every launch (energy-only fp32: 96 -> 128 VGPRs + scratch).
 // MODE 0 energy, 1 + gradients, 2 + parameter partials, 3 + dU/d(sequence distribution) (mythos_oxdna_energy_dpseq: its
 // own instantiation - as run-time branches of MODE 2 the atomics cost the ordinary dU/dtheta call 1.3 - 1.5 % in fp64)
-template <typename R, int MODEL, int MODE, int G, bool SEG, bool OBS>
+template <typename R, int MODEL, int MODE, int G, bool SEG>
 __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) void oxdna_energy_kernel(
     const R* __restrict__ Pg, const BoxT<R> box, int n, const R* __restrict__ center, const R* __restrict__ quat,
     const int* __restrict__ meta, const int* __restrict__ rows, const int* __restrict__ row_len, int row_stride,
     double* __restrict__ e_part, R* __restrict__ dU_dcenter, R* __restrict__ dU_dquat,
-    double* __restrict__ pg_part, R rnear2, const PseqView<R> pseq, const ObsView obs, double* __restrict__ obs_out, int list_cap) {
+    double* __restrict__ pg_part, R rnear2, const PseqView<R> pseq, int list_cap) {
   constexpr int PPB = kBlock / G;
   constexpr bool GRAD = MODE >= 1;
   __shared__ double e_lds[PPB][T_COUNT];
@@ -241,15 +239,6 @@ __global__ __launch_bounds__(kBlock, (energy_blocks_per_cu<R, MODE, MODEL>())) v
       pg_part[bo * kPgUsed + k] = s;
     }
   }
-  // ---- epilogue: the frame's structural observables, by the first workgroup of the frame (observables.h).  The
-  //      frame was just read by this launch, so the second look at it comes out of L2, not HBM.
-  if constexpr (OBS) {
-    if (obs.width > 0 && blockIdx.x == 0) {
-    __shared__ double obs_red[kBlock / 64];
-    frame_observables<R>(obs, center + fo * 3, quat + fo * 4, obs_out + (size_t)frame * obs.width,
-                         obs.axis + (size_t)frame * obs.n_q * 3, obs_red);
-    }
-  }
 }
 
 // out[frame][k] = sum_b part[frame][b][k] for k < width; 0 for width <= k < out_width.  Grid (frames, ceil(out_width / 16)),
@@ -356,7 +345,7 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
   if (const long long v = debug_value(MYTHOS_DEBUG_ENERGY_LIST_CAP)) {  // test hook: short segments on small systems
     if (v >= 8 && v <= kEnergyListCap) list_cap = std::min(list_cap, (int)v);
   }
-  ObsView obs;  // width 0: no epilogue
+  ObsView obs;  // width 0: no observables asked for
   if (oset && obs_out) {
     if (int rc = obs_view_for(oset, n_frames, &obs)) return rc;
   }
@@ -375,26 +364,23 @@ static int launch_typed(mythos_system* sys, const R* center, const R* quat, int 
       MYTHOS_HIP_TRY(hipMemsetAsync(pseq.gmarg, 0, (size_t)nf * n * 4 * sizeof(double), stream));
       MYTHOS_HIP_TRY(hipMemsetAsync(pseq.gbp, 0, (size_t)nf * pseq.bp_rows * 4 * sizeof(double), stream));
     }
-    // the epilogue rides on the energy-only and the dU/dtheta launches (what a DiffTRe evaluation issues); a forces
-    // launch with observables is followed by the stand-alone observables kernel instead (rare, and it keeps the
-    // forces instantiation at four workgroups per CU)
-    const bool fuse = obs.width > 0 && mode != 1 && mode != 3;
-    auto launch = [&](auto mode_tag, auto seg_tag, auto obs_tag) {
-      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, decltype(mode_tag)::value, G, decltype(seg_tag)::value, decltype(obs_tag)::value>),
+    auto launch = [&](auto mode_tag, auto seg_tag) {
+      hipLaunchKernelGGL((oxdna_energy_kernel<R, MODEL, decltype(mode_tag)::value, G, decltype(seg_tag)::value>),
                          grid, dim3(kBlock), (size_t)PPB * 2 * list_cap * sizeof(int), stream, P, box, n, c, q, sys->d_meta, sys->d_rows,
-                         sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq, sys->d_pgpart, rnear2, pseq, obs,
-                         obs_out ? obs_out + (size_t)f0 * obs.width : nullptr, list_cap);
+                         sys->d_row_len, sys->row_stride, sys->d_epart, gc, gq, sys->d_pgpart, rnear2, pseq, list_cap);
     };
-    auto by_seg = [&](auto mode_tag, auto obs_tag) {
-      if (sys->row_stride > list_cap) launch(mode_tag, std::true_type{}, obs_tag); else launch(mode_tag, std::false_type{}, obs_tag);
+    auto by_seg = [&](auto mode_tag) {
+      if (sys->row_stride > list_cap) launch(mode_tag, std::true_type{}); else launch(mode_tag, std::false_type{});
     };
-    using T = std::true_type;
-    using F = std::false_type;
-    if (mode == 0) { if (fuse) by_seg(std::integral_constant<int, 0>{}, T{}); else by_seg(std::integral_constant<int, 0>{}, F{}); }
-    else if (mode == 1) by_seg(std::integral_constant<int, 1>{}, F{});
-    else if (mode == 3) by_seg(std::integral_constant<int, 3>{}, F{});
-    else { if (fuse) by_seg(std::integral_constant<int, 2>{}, T{}); else by_seg(std::integral_constant<int, 2>{}, F{}); }
-    if (obs.width > 0 && !fuse) {
+    if (mode == 0) by_seg(std::integral_constant<int, 0>{});
+    else if (mode == 1) by_seg(std::integral_constant<int, 1>{});
+    else if (mode == 3) by_seg(std::integral_constant<int, 3>{});
+    else by_seg(std::integral_constant<int, 2>{});
+    // The observables of the same frames: the stand-alone kernel queued right behind the energy launch (the frames it
+    // reads were just read: L2).  Through round 3 they rode in an epilogue of the energy kernel (OBS instantiations, the
+    // first workgroup of every frame); measured against this form on the DiffTRe shape the epilogue was 3 - 10 % SLOWER
+    // per call (its fp64 site algebra cost every workgroup of the launch registers and occupancy).
+    if (obs.width > 0) {
       MYTHOS_HIP_TRY(hipGetLastError());
       if (int rc = observables_launch(oset, obs, c, q, nf, obs_out + (size_t)f0 * obs.width, stream)) return rc;
     }

@@ -492,7 +492,7 @@ class ComposedEnergyFunction(EnergyFunction):
 
     def with_observables(self, *observables) -> "ComposedEnergyFunction":
         """The same energy function whose ``map`` / ``__call__`` on a batch of frames also evaluates these structural
-        observables in the epilogue of its launch (mythos_oxdna_energy_obs): a later ``observable(trajectory)`` on the
+        observables in the same call (mythos_oxdna_energy_obs: the observables kernel queued behind the energy launch): a later ``observable(trajectory)`` on the
         same frames returns those rows instead of launching again.  What DiffTRe needs per iteration - energies,
         dU/dtheta, the observable - then costs one read of the stored trajectory.  (No counterpart in the reference,
         whose observables are separate jitted functions over the trajectory, mythos/observables/*.py.)"""
@@ -624,7 +624,7 @@ class ComposedEnergyFunction(EnergyFunction):
         pseq_leaves = pseq_tensors(self.energy_fns)
         try:
             if pseq_leaves is not None:
-                entry["observe"] = None  # the distribution gradient comes from its own entry point, without the epilogue
+                entry["observe"] = None  # the distribution gradient comes from its own entry point, without the observables
                 total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w, *pseq_leaves)
             else:
                 total, terms = _EnergyOp.apply(center, quat, flat, entry, term_w)

@@ -159,7 +159,7 @@ class OxdnaSystem:
         """Term energies (F, 8) [float64] and optionally dU/dcenter, dU/dquat, dU/dflat.
 
         ``center`` (F, N, 3) or (N, 3); ``quat`` likewise with 4.  ``observables``: an
-        ``mythos_amd.observables.ObservableSet`` evaluated in the epilogue of the same launch; its (F, width) rows are
+        ``mythos_amd.observables.ObservableSet`` evaluated in the same call (the observables kernel queued right behind the energy launch); its (F, width) rows are
         then returned as a fifth value.  ``pseq_grads`` (with ``param_grads``, after ``set_pseq``): also
         dU/d(marginals) (F, N, 4) and dU/d(base-pair type probabilities) (F, max(n_bp, 1), 4), as a fifth and sixth value.
         """

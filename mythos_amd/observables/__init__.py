@@ -1,5 +1,5 @@
 """Per-frame observables used by DiffTRe objectives (a small part of mythos/observables/: SURVEY.md 8f-3), evaluated
-by the HIP library - stand-alone, or in the epilogue of the energy launch (``energy_fn.with_observables``)."""
+by the HIP library - stand-alone, or in the same call as the energy launch (``energy_fn.with_observables``)."""
 
 from mythos_amd.observables.base import ObservableSet, get_duplex_quartets
 from mythos_amd.observables.persistence_length import PersistenceLength, persistence_length_fit

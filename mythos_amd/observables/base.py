@@ -3,7 +3,7 @@ HIP evaluation every observable class goes through.
 
 An observable object describes WHAT to measure (index lists, geometry, displacement); the numbers come from one
 workgroup per frame on the GPU (mythos_amd/csrc/observables.h) - either a stand-alone launch, or, when the energy
-function was built ``with_observables(...)``, the epilogue of the same launch that evaluates the energies and
+function was built ``with_observables(...)``, the same library call that evaluates the energies and
 dU/dtheta of the frames (``mythos_oxdna_energy_obs``), so a DiffTRe iteration reads its trajectory once.
 """
 
@@ -95,7 +95,7 @@ def _frames(trajectory):
     return c, q.to(c.dtype)
 
 
-# Rows computed in the epilogue of an energy launch, remembered together with the frames they belong to.  An entry
+# Rows computed alongside an energy launch (mythos_oxdna_energy_obs), remembered together with the frames they belong to.  An entry
 # HOLDS its two tensors: while it lives their memory cannot go back to the allocator and be handed to another trajectory
 # of the same shape, so "same address, same shape, same version counters" does identify the frames (an entry keyed on
 # data_ptr alone would serve the rows of a freed trajectory to the next one allocated in its place).  The library

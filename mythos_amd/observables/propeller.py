@@ -1,6 +1,6 @@
 """Propeller twist (mythos/observables/propeller.py:19-71): per frame, the mean over the listed H-bonded base
 pairs of 180 - acos(n_i . n_j) in degrees, n = base normal a3.  Evaluated by the HIP library
-(mythos_amd/csrc/observables.h), stand-alone or in the epilogue of the energy launch."""
+(mythos_amd/csrc/observables.h), stand-alone or in the same call as the energy launch."""
 
 from __future__ import annotations
 

@@ -33,7 +33,8 @@ one md_na1 "" python scripts/bench_na1.py
 fi
 [ "$part" = md ] && exit 0
 one martini_md "" python bench.py --workload martini-bilayer --steps 500 --warmup 100
-one energy_difftre "" python scripts/bench_energy.py
+one energy_difftre "" python scripts/bench_energy.py --difftre
+one energy_difftre_obs "" python scripts/bench_energy.py --obs
 one observables "" python scripts/bench_observables.py
 # the headline kernel: trace of the DEFAULT bench command (what the driver's number comes from) + HBM traffic passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python bench.py --cpu-steps 0 > $out/bench_profiled.log 2>&1

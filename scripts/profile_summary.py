@@ -42,7 +42,7 @@ for name, g in sorted(tr.groupby("name"), key=lambda kv: -kv[1].us.sum()):
     if g.us.sum() < a.min_share * total:
         continue
     row = {"kernel": name, "dispatches": int(len(g)), "mean_us": float(g.us.mean()), "median_us": float(g.us.median()),
-           "share_of_gpu_time": float(g.us.sum() / total), "vgpr": int(g.VGPR_Count.iloc[0]) if "VGPR_Count" in g else None,
+           "share_of_gpu_time": float(g.us.sum() / total), "rocprof_vgpr_count": int(g.VGPR_Count.iloc[0]) if "VGPR_Count" in g else None,
            "lds_bytes": int(g.LDS_Block_Size.iloc[0]) if "LDS_Block_Size" in g else None,
            "scratch_bytes": int(g.Scratch_Size.iloc[0]) if "Scratch_Size" in g else None}
     c = pm[pm.name == name]

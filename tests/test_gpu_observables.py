@@ -4,7 +4,7 @@ into the energy launch.
  * propeller twist, rise, pitch angle, <l0> and the axis autocorrelation of thermal frames == oracle (1e-10 in fp64;
    fp32 inputs are read as they are and the arithmetic is fp64, so the same tolerance holds on the same inputs);
  * free and periodic displacement, oxDNA1 and oxDNA2 site geometry, skip_ends on / off, empty lists;
- * ``energy_fn.with_observables(...)``: the rows written by the epilogue of the energy launch are the rows of the
+ * ``energy_fn.with_observables(...)``: the rows that come back with the energies (mythos_oxdna_energy_obs) are the rows of the
    stand-alone launch, bit for bit, and the observable calls that follow do not launch again;
  * DiffTRe end to end with the fused path gives the same loss and gradient as without it.
 """
@@ -140,7 +140,7 @@ def test_rows_from_the_energy_launch_equal_the_stand_alone_rows():
         assert launches["n"] == 1
     finally:
         PB.ObservableSet.eval = orig
-    # gradient modes carry the epilogue too (the DiffTRe evaluation asks for dU/dtheta)
+    # gradient modes carry the observables too (the DiffTRe evaluation asks for dU/dtheta)
     PB._FUSED.clear()
     par = {"eps_hb": torch.tensor(1.0678, dtype=torch.float64, requires_grad=True)}
     e = ef.with_observables(*obs).with_params(par).map(traj)
