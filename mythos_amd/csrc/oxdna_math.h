@@ -105,6 +105,7 @@ __host__ __device__ __forceinline__ void axpy(V3<R>& y, R a, V3<R> x) {
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float m_rsqrt(float x) { return rsqrtf(x); }
+// (the library's rsqrt - v_rsq_f64 + refinement - measured 1.4 % SLOWER per fp64 MD step than this form)
 __device__ __forceinline__ double m_rsqrt(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float m_exp(float x) { return __expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
