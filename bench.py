@@ -10,7 +10,9 @@ Langevin) per GPU, one independent replica per GPU (BASELINE.json metric / confi
 A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csrc/langevin_core.inc).
 The timed region is one ``mythos_langevin_advance`` call of exactly K steps with the state resident in HBM
 (loaded into the integrator before the clock starts), bracketed by barrier + synchronize, MAX over ranks.
-It is measured ``--repeats`` times back to back (default 5; the trajectory continues from sample to sample);
+It is measured ``--repeats`` times back to back (the trajectory continues from sample to sample; default 5, or 21
+when K < 500: a 20-step sample lasts a third of a millisecond, and on a GPU that sat idle until the clock started the
+first few samples run at clocks still coming up - 0.345 ms against 0.325 ms a few milliseconds later, measured);
 value = N_gpus * K / the MEDIAN sample, all samples are in ``config.samples_ms`` and the number of scheduled
 list rebuilds that fell inside each in ``config.scheduled_rebuilds_per_sample``.  Nothing else is inside a
 sample: the per-dispatch HIP events behind ``roofline.kernel_ms`` are taken in a second, untimed pass.  For
@@ -73,13 +75,17 @@ def parse_args():
     ap.add_argument("--no-second-dtype", action="store_true", help="skip the measurement at the other precision (config.f64 / config.f32)")
     ap.add_argument("--instrument-steps", type=int, default=512,
                     help="least length of the untimed, event-instrumented pass behind the timed region (dev: short runs of wrong-physics bounds)")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=None,
                     help="the timed region (exactly --steps steps) is run this many times back to back, each bracketed by barrier + "
-                         "synchronize; value = steps / the MEDIAN sample, every sample is in config.samples_ms")
+                         "synchronize; value = steps / the MEDIAN sample, every sample is in config.samples_ms "
+                         "(default 5; 21 for timed regions under 500 steps)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
                          "between ranks); the printed line is then marked as a rehearsal, not a measurement")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.repeats is None:
+        args.repeats = 5 if args.steps >= 500 else 21
+    return args
 
 
 def algorithmic_bytes_per_step(n: int, nbar: float, word: int) -> float:
