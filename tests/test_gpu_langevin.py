@@ -71,6 +71,47 @@ def test_step_by_step_parity_with_oracle_fp64(model, name, salt):
     assert integ.step == n_steps
 
 
+@pytest.mark.parametrize(("spin", "steps", "tol"), [(30.0, 3, 1e-13), (300.0, 1, 1e-12), (1200.0, 1, 3e-8)])
+def test_fast_spinning_free_nucleotides_take_the_rotor_beyond_its_series(spin, steps, tol):
+    """The fp64 rotor evaluates sin / cos of a sub-step's half angle by a short Taylor series (|x| < 1/32, where thermal
+    motion keeps it by a factor of fifteen) and halves a larger angle until it fits.  Free asymmetric tops (no
+    neighbours: zero forces, no friction, no noise) with angular momenta of 30 - 60, 300 - 600 and 1 200 - 2 400 put the
+    half angle of the long factor at 0.04 - 0.08, 0.4 - 0.8 and 1.5 - 3 rad: up to two halvings, six, eight.  Against the
+    oracle's drift (numpy sin / cos).  A top that turns by radians per sub-step is a chaotic map - the angle of every
+    factor is the angular momentum the previous one left - so the comparison is over one step there, and the
+    tolerance is what a numpy emulation of the kernel's arithmetic shows against the oracle (1e-15, 1e-14, 3e-10),
+    with a margin."""
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+    from oracle.langevin_oracle import drift
+
+    n = 1024
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    s = OxdnaSystem(2, np.arange(n, dtype=np.int32) % 4, np.ones(n, dtype=np.int32), np.zeros((0, 2), dtype=np.int32), dtype=torch.float64)
+    s.set_params(flat)
+    s.set_neighbors(np.zeros((0, 2), dtype=np.int32))
+    rng = np.random.default_rng(int(spin))
+    x = rng.uniform(-20.0, 20.0, size=(n, 3))
+    q = rng.standard_normal((n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    p0 = 0.3 * rng.standard_normal((n, 3))
+    L0 = spin * (1.0 + rng.random((n, 3))) * rng.choice([-1.0, 1.0], size=(n, 3))
+    inertia = np.array([1.0, 1.3, 0.8])
+    integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=0.0, gamma_r=0.0, mass=1.0, inertia=tuple(inertia), seed=7)
+    c, qd = _state(x, q, torch.float64, s.device)
+    p, L = torch.as_tensor(p0, device=s.device).contiguous(), torch.as_tensor(L0, device=s.device).contiguous()
+    integ.run(c, qd, p, L, steps)
+    LL = L0.copy()
+    for _ in range(steps):
+        x, q, LL = drift(x, q, p0, LL, 0.0025, 1.0, inertia)
+        x, q, LL = drift(x, q, p0, LL, 0.0025, 1.0, inertia)
+        q = q / np.linalg.norm(q, axis=1, keepdims=True)
+    np.testing.assert_allclose(qd.cpu().numpy(), q, rtol=0, atol=tol)
+    assert (np.abs(L.cpu().numpy() - LL).max(1) <= tol * np.linalg.norm(LL, axis=1)).all()
+    np.testing.assert_allclose(c.cpu().numpy(), x, rtol=0, atol=1e-12)
+    np.testing.assert_array_equal(p.cpu().numpy(), p0)
+
+
 def test_fp32_tracks_fp64_over_short_run():
     from mythos_amd.hip_system import LangevinIntegrator
 
