@@ -64,8 +64,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--bp", type=int, default=12000, help="base pairs of the duplex (12000 = headline config)")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
-    ap.add_argument("--skin", type=float, default=None, help="Verlet skin (default: 0.6 oxDNA length units / 0.4 nm MARTINI)")
-    ap.add_argument("--rebuild-every", type=int, default=None, help="steps between list rebuilds (default: 25 oxDNA / 8 MARTINI)")
+    ap.add_argument("--skin", type=float, default=None, help="Verlet skin (default: 0.9 oxDNA length units / 0.4 nm MARTINI)")
+    ap.add_argument("--rebuild-every", type=int, default=None, help="steps between list rebuilds (default: 50 oxDNA / 8 MARTINI)")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="CPU-baseline sample size in steps (-1: auto, 0: skip)")
@@ -405,8 +405,12 @@ def main():
         raise SystemExit(spawn_ranks(args))  # no GPU call has been made in this process
     if args.workload == "martini-bilayer":
         return martini_main(args)
-    args.skin = 0.6 if args.skin is None else args.skin
-    args.rebuild_every = 25 if args.rebuild_every is None else args.rebuild_every
+    # skin 0.9, rebuild every 50 steps: scanned on MI355X in round 3 (0.6 / 25, the round-2 choice: 67.1 k steps/s; 0.7 / 36
+    # 68.7 k; 0.8 / 44 69.5 k; 0.9 / 52 70.1 k; 1.0 / 60 70.2 k; 1.2 / 90 66.0 k with out-of-turn rebuilds) - a site of the
+    # thermalised 24 000-nt duplex first leaves half of a 0.9 skin after ~57 steps: 300 000 steps at 50 without one
+    # out-of-turn rebuild, fp64 and 100 kbp likewise.  (The CPU port keeps its own optimum, 0.6 / 25.)
+    args.skin = 0.9 if args.skin is None else args.skin
+    args.rebuild_every = 50 if args.rebuild_every is None else args.rebuild_every
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:

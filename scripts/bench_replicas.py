@@ -23,8 +23,10 @@ params = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(
                                bonded_neighbors=top.bonded_neighbors, checkpoint_every=0, dt=5e-3, kT=KT)
 init = RigidBody(center=torch.as_tensor(c0, dtype=torch.float32), orientation=Quaternion(vec=torch.as_tensor(q0, dtype=torch.float32)))
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+skin = float(sys.argv[2]) if len(sys.argv) > 2 else 0.9    # (bench.py's policy; 0.6 / 25 was round 2's)
+every = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 base = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin,
-                      neighbors=VerletNeighborList(3.25, 0.6, 25), save_every=100)
+                      neighbors=VerletNeighborList(3.25, skin, every), save_every=100)
 for reps in (1, 8, 64, 256):
     sim = dc.replace(base, n_replicas=reps)
     sim.run({}, init, 200, key=1)

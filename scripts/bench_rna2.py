@@ -27,7 +27,7 @@ for model, mod, name in ((3, rna2, "simple-helix-12bp"), (2, dna2, "simple-helix
     init = RigidBody(center=torch.as_tensor(traj.center[0], dtype=torch.float32), orientation=Quaternion(vec=torch.as_tensor(traj.quaternions[0], dtype=torch.float32)))
     for dtype in (torch.float32, torch.float64):
         sim = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin,
-                             neighbors=VerletNeighborList(3.25, 0.6, 25), save_every=0, dtype=dtype, n_replicas=reps)
+                             neighbors=VerletNeighborList(3.25, 0.9, 50), save_every=0, dtype=dtype, n_replicas=reps)
         sim.run({}, init, 300, key=1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -23,10 +23,10 @@ one() {  # name, "alg-bytes args", command...
   echo "[profiles] $name done"
 }
 short="--steps 500 --warmup 100 --cpu-steps 0 --no-second-dtype --repeats 1"
-# algorithmic bytes per launch: n (2 * 14 * s + 13 + 4 * nbar), nbar = 20.84 at skin 0.6 (bench.py prints it)
+# algorithmic bytes per launch: n (2 * 14 * s + 13 + 4 * nbar), nbar = 24.61 at skin 0.9 (bench.py prints it)
 if [ "$part" != rest ]; then
-one md_12kbp_f32 "--alg-bytes md_step_kernel<float=5000744" python bench.py $short
-one md_12kbp_f64 "--alg-bytes md_step_kernel<double=7688736" python bench.py $short --dtype f64
+one md_12kbp_f32 "--alg-bytes md_step_kernel<float=5362560" python bench.py $short
+one md_12kbp_f64 "--alg-bytes md_step_kernel<double=8050560" python bench.py $short --dtype f64
 one md_100kbp_f32 "" python bench.py --bp 100000 --steps 150 --warmup 30 --cpu-steps 0 --no-second-dtype --repeats 1
 one md_rna2 "" python scripts/bench_rna2.py 500
 one md_na1 "" python scripts/bench_na1.py
