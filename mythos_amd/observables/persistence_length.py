@@ -2,8 +2,8 @@
 
 Per frame (HIP, mythos_amd/csrc/observables.h): the unit vectors l_k between the midpoints of adjacent base pairs (the
 local helical axis of each quartet), their autocorrelation C(d) = mean_k l_k . l_(k+d) and the mean midpoint spacing
-<l0>.  Over a trajectory (optionally with DiffTRe weights): log C(d) = offset - d <l0> / Lp, fitted by least squares on
-the host-side torch tensors - a (n_lags, 2) system.  Lp comes back in the length unit of the trajectory (oxDNA units;
+<l0>.  Over a trajectory (optionally with DiffTRe weights): log C(d) = offset - d <l0> / Lp, fitted by least squares (the
+closed form of a straight-line fit, on torch tensors: differentiable with respect to the weights).  Lp comes back in the length unit of the trajectory (oxDNA units;
 x 0.8518 for nm).
 """
 
@@ -19,11 +19,17 @@ TARGETS = {"oxDNA": 47.5}  # nm (persistence_length.py:15-17)
 
 def persistence_length_fit(correlations: torch.Tensor, l0_av):
     """Lp and offset of the line log C(d) = offset - d l0 / Lp (persistence_length.py:21-44)."""
+    # the normal equations of a straight line, written out: n, sum d and sum d^2 are numbers known on the host, the two
+    # sums over y are the only device work (differentiable with respect to the DiffTRe weights behind ``correlations``).
+    # Through round 3 this was torch.linalg.lstsq on the (n_lags, 2) system: a QR solver launch chain of ~0.5 ms for a
+    # two-parameter fit, on the path of every DiffTRe iteration that reweights the persistence length.
     y = torch.log(correlations)
-    d = torch.arange(correlations.shape[0], dtype=y.dtype, device=y.device)
-    design = torch.stack([torch.ones_like(d), d], dim=1)
-    sol = torch.linalg.lstsq(design, y[:, None]).solution[:, 0]
-    offset, slope = sol[0], sol[1]
+    n = int(y.shape[0])
+    d = torch.arange(n, dtype=y.dtype, device=y.device)
+    sd, sdd = n * (n - 1) / 2.0, (n - 1) * n * (2 * n - 1) / 6.0
+    sy, sdy = y.sum(), (d * y).sum()
+    slope = (n * sdy - sd * sy) / (n * sdd - sd * sd)
+    offset = (sy - slope * sd) / n
     return -l0_av / slope, offset
 
 

@@ -136,16 +136,16 @@ def vector_autocorrelate(vecs: torch.Tensor) -> torch.Tensor:
 def persistence_length_fit(correlations: torch.Tensor, l0_av):
     """Lp and offset of the line log C(d) = offset - d l0 / Lp (persistence_length.py:21-44).
 
-    Written as the textbook closed form of a straight-line fit (slope = cov(d, y) / var(d)) so that it is NOT the product's
-    arithmetic (mythos_amd/observables/persistence_length.py solves the (n, 2) least-squares system with a QR solver):
-    comparing the two is a check, not a self-comparison."""
-    y = torch.log(correlations.detach().double().cpu())
-    d = torch.arange(y.shape[0], dtype=torch.float64)
-    dm, ym = d.mean(), y.mean()
-    slope = ((d - dm) * (y - ym)).sum() / ((d - dm) ** 2).sum()
-    offset = ym - slope * dm
+    Solved as the (n, 2) least-squares system with numpy's SVD-based solver, so that it is NOT the product's arithmetic
+    (mythos_amd/observables/persistence_length.py writes out the normal equations of a straight line): comparing the
+    two is a check, not a self-comparison."""
+    import numpy as np
+
+    y = np.log(correlations.detach().double().cpu().numpy())
+    d = np.arange(y.shape[0], dtype=np.float64)
+    (offset, slope), *_ = np.linalg.lstsq(np.stack([np.ones_like(d), d], axis=1), y, rcond=None)
     l0 = l0_av.detach().double().cpu() if isinstance(l0_av, torch.Tensor) else torch.tensor(float(l0_av), dtype=torch.float64)
-    return -l0 / slope, offset
+    return -l0 / slope, torch.tensor(offset, dtype=torch.float64)
 
 
 class PersistenceLength:
