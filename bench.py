@@ -16,8 +16,9 @@ first few samples run at clocks still coming up - 0.345 ms against 0.325 ms a fe
 value = N_gpus * K / the MEDIAN sample, all samples are in ``config.samples_ms`` and the number of scheduled
 list rebuilds that fell inside each in ``config.scheduled_rebuilds_per_sample``.  Nothing else is inside a
 sample: the per-dispatch HIP events behind ``roofline.kernel_ms`` are taken in a second, untimed pass.  For
-N > 1 the replicas' observables (energy trace) are all-gathered over RCCL inside the timed region (one
-collective).  The headline precision is fp32 (north_star: fp32 forces at 1e-3); the same measurement in the
+N > 1 every rank steps its own replica (weak scaling; the MD data path has no collective): barrier + synchronize, the
+rank's clock around its K steps, synchronize + barrier, MAX over ranks.  With ``--save-every`` the replicas' energy
+traces are all-gathered over RCCL inside the timed region (one collective).  The headline precision is fp32 (north_star: fp32 forces at 1e-3); the same measurement in the
 reference's fp64 is ``config.f64``, ``f64_steps_per_s`` and the tail of ``config.timed_region``.
 
 Rank 0 prints ONE JSON line with the fields of the driver contract plus
@@ -335,7 +336,6 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     # ---- timed region: exactly args.steps steps, measured args.repeats times back to back (the trajectory simply
     #      continues); every sample has its own barrier + synchronize on both sides and its own MAX over ranks
     world = 1 if dist is None else dist.get_world_size()
-    zeros_obs = torch.zeros((1, 10), dtype=torch.float64, device=dev)
     samples, rebuilds, recoveries = [], [], 0
     for _ in range(max(1, args.repeats)):
         if dist is not None:
@@ -343,17 +343,17 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         _, _, et = integ.advance(args.steps, save_every=args.save_every)
-        if dist is not None:
-            # per-replica observables (energy trace, or one row of zeros without --save-every), replica id = rank: ONE
-            # all-gather over RCCL / xGMI - the only collective, the MD data path has none - and no host read-back
-            obs = (et if et is not None else zeros_obs).reshape(1, -1)
+        if dist is not None and et is not None:
+            # a run that saves observables (--save-every) gathers them inside the timed region: per-replica energy trace,
+            # replica id = rank, ONE all-gather over RCCL / xGMI and no host read-back.  Without --save-every a replica
+            # produces nothing to exchange: the MD data path has no collective, and none is invented for the clock.
+            obs = et.reshape(1, -1)
             gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs, n_total=world)
             assert gathered.shape[0] == world
         torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's
         if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
+            dist.barrier()  # (the closing bracket; its own latency is not part of anybody's K steps)
             t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
