@@ -202,7 +202,11 @@ int mythos_langevin_store(mythos_sim_t* s, void* center, void* quat, void* p_lin
     set_error("mythos_langevin_store: no resident state");
     return MYTHOS_ERR_NOT_READY;
   }
-  if (int rc = md_ready(s, "mythos_langevin_store")) return rc;  // (an open frame is closed by one more launch)
+  if (s->open) {  // one more launch closes the frame: what a launch needs has to be there (it was, for the advance before)
+    if (int rc = md_ready(s, "mythos_langevin_store")) return rc;
+  } else {  // a copy: load; store round-trips a state whether or not neighbours were ever set
+    MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  }
   return md_store(s, center, quat, p_lin, p_ang, (hipStream_t)stream);
 }
 

@@ -585,3 +585,24 @@ def test_dense_instantiation_steps_like_the_fixed_row_one(model):
     for a, b in zip(res[0][0], res[1][0]):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 1e-4 * scale + 2e-6
+
+
+def test_load_then_store_round_trips_a_state_without_any_neighbour_setup():
+    """mythos_langevin_store launches only when it has an open frame to close: a state that was merely loaded comes
+    back bit for bit from an integrator that has neither a neighbour list nor a policy for one."""
+    from mythos_amd.hip_system import LangevinIntegrator
+
+    top, c0, q0 = generators.ideal_duplex(40, model=2, seed=3)
+    s = _system(2, top, torch.float64)
+    integ = LangevinIntegrator(s, dt=0.005, kT=KT, gamma_t=KT / 2.5, gamma_r=KT / 7.5, seed=2)
+    c, q = _dev(c0, torch.float64, s), _dev(q0, torch.float64, s)
+    q = q / q.norm(dim=1, keepdim=True)
+    p, L = integ.init_momenta()
+    integ.load(c, q, p, L)
+    out = [torch.empty_like(t) for t in (c, q, p, L)]
+    integ.store(*out)
+    for a, b in zip((c, p, L), (out[0], out[2], out[3])):
+        assert torch.equal(a, b)
+    assert (out[1] - q).abs().max() < 1e-15
+    with pytest.raises(_lib.MythosHipError, match="neighbour"):
+        integ.advance(1)
