@@ -532,7 +532,11 @@ def test_advance_leaves_the_frame_open_and_store_closes_it(dtype):
     integ, c, q = fresh()
     p, L = integ.init_momenta()
     integ.load(c, q, p, L)
-    integ.advance(20)
+    _lib.debug_set("md_segment", 7)  # segments of seven launches: the open frame crosses segment ends as well
+    try:
+        integ.advance(20)
+    finally:
+        _lib.debug_set("md_segment", 0)
     assert integ.last_kernel_ms()["launches"] == 20
     out = [torch.empty_like(t) for t in (c, q, p, L)]
     integ.store(*out)  # closes: one launch, no step
