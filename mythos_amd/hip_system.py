@@ -280,14 +280,12 @@ class LangevinIntegrator:
         tc = torch.empty((n_save, s.n, 3), dtype=s.dtype, device=s.device) if n_save else None
         tq = torch.empty((n_save, s.n, 4), dtype=s.dtype, device=s.device) if n_save else None
         et = torch.zeros((n_save, TRACE_WIDTH), dtype=torch.float64, device=s.device) if (n_save and want_energy) else None
-        _lib.check(
-            self._lib.mythos_langevin_run(
-                self._h, _lib.ptr(center), _lib.ptr(quat), _lib.ptr(p_lin), _lib.ptr(p_ang), int(n_steps),
-                int(save_every), _lib.ptr(tc), _lib.ptr(tq), _lib.ptr(et), _stream(s.device),
-            ),
-            "langevin_run",
+        rc = self._lib.mythos_langevin_run(
+            self._h, _lib.ptr(center), _lib.ptr(quat), _lib.ptr(p_lin), _lib.ptr(p_ang), int(n_steps),
+            int(save_every), _lib.ptr(tc), _lib.ptr(tq), _lib.ptr(et), _stream(s.device),
         )
-        _touched(center, quat, p_lin, p_ang)
+        _touched(center, quat, p_lin, p_ang)  # (a run that fails still hands back the state of its last valid step)
+        _lib.check(rc, "langevin_run")
         return tc, tq, et
 
     # ---- resident form: the state stays in the integrator's layout on the device between calls ----------
@@ -318,8 +316,9 @@ class LangevinIntegrator:
 
     def store(self, center, quat, p_lin, p_ang) -> None:
         """Copy the resident state out (mythos_langevin_store, asynchronous on the current stream)."""
-        _lib.check(self._lib.mythos_langevin_store(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device)), "langevin_store")
-        _touched(center, quat, p_lin, p_ang)
+        rc = self._lib.mythos_langevin_store(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device))
+        _touched(center, quat, p_lin, p_ang)  # (the arrays are written even when closing an open frame failed)
+        _lib.check(rc, "langevin_store")
 
     @property
     def step(self) -> int:
