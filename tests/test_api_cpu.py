@@ -226,3 +226,22 @@ def test_objective_protocol_without_a_gpu():
     spent = DiffTReObjective(name="d", required_observables=("t",), grad_or_loss_fn=lambda *a: None, energy_fn=object(),
                              max_valid_opt_steps=2).calculate({}, opt_params={}, opt_steps=2)
     assert not spent.is_ready and spent.needs_update == ("t",) and spent.state == {"opt_steps": 0}
+
+
+def test_bench_strings_fit_the_drivers_parsed_record():
+    """The driver keeps 120 characters of a string: workload, timed_region and the CPU baseline's sample must say what
+    was measured within that."""
+    import argparse
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("bench_module", Path(__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for steps, save_every, n in ((20, 0, 21), (2000, 0, 5), (100000, 1000, 5)):
+        args = argparse.Namespace(steps=steps, save_every=save_every, dtype="f32")
+        m = {"rebuilds_in_median": steps // 50, "samples_ms": [0.3] * n}
+        txt = bench._timed_region(args, m, {"steps_per_s": 40714.2})
+        assert len(txt) <= 120 and f"{steps} steps" in txt and "f64 40.7k" in txt and f"median of {n}" in txt
+        launches = steps + (1 if save_every and steps % save_every == 0 else 0)
+        assert f"= {launches} launches" in txt
