@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--rebuild-every", type=int, default=None, help="steps between list rebuilds (default: 50 oxDNA / 12 MARTINI)")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
+    ap.add_argument("--trace-energy", action="store_true",
+                    help="with --save-every: also the 8 term + 2 kinetic energies of the saved steps (the energy-trace instantiation); "
+                         "without it the saved steps are positions only, the reference's run (jaxmd.py:84-99)")
     ap.add_argument("--cpu-steps", type=int, default=-1, help="CPU-baseline sample size in steps (-1: auto, 0: skip)")
     ap.add_argument("--workload", choices=["oxdna2-12kbp", "martini-bilayer"], default="oxdna2-12kbp",
                     help="oxdna2-12kbp is the headline (BASELINE.json metric); martini-bilayer is BASELINE configs[2] "
@@ -345,7 +348,7 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
             dist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        _, _, et = integ.advance(args.steps, save_every=args.save_every)
+        _, _, et = integ.advance(args.steps, save_every=args.save_every, want_energy=args.trace_energy)
         if dist is not None and et is not None:
             # a run that saves observables (--save-every) gathers them inside the timed region: per-replica energy trace,
             # replica id = rank, ONE all-gather over RCCL / xGMI and no host read-back.  Without --save-every a replica
@@ -392,7 +395,7 @@ def _timed_region(args, m, m2) -> str:
     and the rate at the other precision."""
     # (an advance call is one force evaluation per step: the closing half kick of its last step rides on the next call's
     #  first launch - or on store's - see advance_typed in mythos_amd/csrc/langevin_core.inc)
-    closes = args.save_every > 0 and args.steps % args.save_every == 0
+    closes = args.trace_energy and args.save_every > 0 and args.steps % args.save_every == 0
     txt = (f"{args.steps} steps = {args.steps + (1 if closes else 0)} launches + {m['rebuilds_in_median']} list rebuilds + 1 sync; "
            f"median of {len(m['samples_ms'])}")
     if m2 is not None:

@@ -17,7 +17,8 @@
  *     float64.
  *   - every function returning int returns 0 on success or a negative mythos_status; the text
  *     is available from mythos_last_error() (thread-local).
- *   - handles are independent: one handle per thread / stream, no global state.
+ *   - handles are independent: one handle per thread / stream.  The one piece of process-wide state is the table of
+ *     test switches behind mythos_debug_set (tests only; all zero by default, never read per launch).
  *   - nucleotides are in oxDNA-classic 3'->5' memory order; quaternions are [w, x, y, z].
  */
 #ifndef MYTHOS_HIP_H
@@ -78,7 +79,8 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
  *             forms - and every nucleotide the sites of its own type.  Such a system needs
  *             mythos_oxdna_set_nucleotide_types, takes 3 x mythos_oxdna_param_count() parameters (the oxDNA2, oxRNA2 and
  *             hybrid vectors one after the other; dU_dparams rows have the same layout).  No structural observables for it;
- *             a probabilistic sequence for hydrogen bonding only (mythos_oxdna_set_pseq terms = 2), no dU/d(distribution).  The Langevin integrator has an oxNA instantiation of its fused step kernel
+ *             a probabilistic sequence for hydrogen bonding only (mythos_oxdna_set_pseq terms = 2), with dU/d(distribution)
+ *             through mythos_oxdna_energy_dpseq like the other models.  The Langevin integrator has an oxNA instantiation of its fused step kernel
  *             (about half the oxDNA2 rate: a parameter set is chosen per row entry).
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
@@ -199,9 +201,13 @@ int mythos_langevin_init_momenta(mythos_sim_t* sim, void* p_lin, void* p_ang, my
 
 /* Run n_steps; state arrays are updated in place.
  *   center dev real[n][3], quat dev real[n][4], p_lin dev real[n][3], p_ang dev real[n][3] (body frame)
- *   save_every > 0: traj_center dev real[n_steps/save_every][n][3], traj_quat [..][n][4] receive the
- *   state after steps save_every, 2*save_every, ...; e_trace dev double[n_steps/save_every][10] receives
+ *   save_every > 0: traj_center dev real[n_steps/save_every][n][3], traj_quat [..][n][4] (aligned to 4 elements)
+ *   receive the state after steps save_every, 2*save_every, ...; e_trace dev double[n_steps/save_every][10] receives
  *   the 8 term energies + translational + rotational kinetic energy (any of the three may be NULL).
+ *   e_trace == NULL is the reference's own run (mythos/simulators/jax_md/jaxmd.py:84-99 stores state.position of every
+ *   step and nothing else): the step launch that produces a saved state writes it to its row too - 7 more words per
+ *   nucleotide and saved step, no other cost.  e_trace != NULL selects the energy-trace instantiation of the step
+ *   kernel for the saved steps plus one small reduction launch per row.
  * A site that outruns the Verlet skin before the scheduled rebuild, or rows / cell buckets that outgrow their
  * allocation, halt the queued launches; the run rebuilds at the last valid state and resumes (not an error; counted
  * by mythos_langevin_last_recoveries).  MYTHOS_ERR_OVERFLOW only after 64 such rebuilds in one run, or when one
@@ -225,7 +231,10 @@ int mythos_langevin_run(mythos_sim_t* sim, void* center, void* quat, void* p_lin
  * the closing half kick of step n, which needs the forces at x_n - the evaluation the next advance starts with anyway
  * (as the reference's carry holds the force of the last step for the next one, jax_md simulate.nvt_langevin).  store
  * supplies it with one more launch when the frame is still open, so what store hands back is always (x_n, p_n); an
- * advance whose last step saves a trace row closes while it evaluates that row.  The mythos_langevin_last_* figures
+ * advance whose last step saves an ENERGY row (e_trace != NULL) closes while it evaluates that row.  An open frame is
+ * closed with the parameters / sequence distribution in force WHEN IT IS CLOSED: a caller that replaces them between
+ * two advances (mythos_oxdna_set_params, mythos_oxdna_set_pseq) and wants step n finished under the old ones calls store
+ * first.  The mythos_langevin_last_* figures
  * describe the last call that launched step kernels, store's closing launch included. */
 int mythos_langevin_load(mythos_sim_t* sim, const void* center, const void* quat, const void* p_lin, const void* p_ang,
                          mythos_stream_t stream);
@@ -236,6 +245,9 @@ int mythos_langevin_store(mythos_sim_t* sim, void* center, void* quat, void* p_l
 /* absolute step counter (RNG stream position); settable for checkpoint/resume */
 int64_t mythos_langevin_get_step(const mythos_sim_t* sim);
 int mythos_langevin_set_step(mythos_sim_t* sim, int64_t step);
+/* the key of the noise (Philox key; init_momenta draws from it too): what a new `key` argument of the reference's
+ * run(opt_params, init_state, n_steps, key) is (mythos/simulators/jax_md/jaxmd.py:60-68), without a new integrator */
+int mythos_langevin_set_seed(mythos_sim_t* sim, uint64_t seed);
 
 /* Integrator options.  MYTHOS_LANGEVIN_UNFUSED (oxNA systems only, value 0 / 1): step through the two-launch path -
  * the energy kernel's forces launch + a one-thread-per-nucleotide integrator - instead of the fused step kernel.  A

@@ -75,6 +75,7 @@ def load() -> C.CDLL:
         "mythos_langevin_store": (C.c_int, [V, V, V, V, V, V]),
         "mythos_langevin_get_step": (C.c_int64, [V]),
         "mythos_langevin_set_step": (C.c_int, [V, C.c_int64]),
+        "mythos_langevin_set_seed": (C.c_int, [V, C.c_uint64]),
         "mythos_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mythos_langevin_set_option": (C.c_int, [V, C.c_int, C.c_int64]),
         "mythos_langevin_set_timing": (C.c_int, [V, C.c_int]),
@@ -141,6 +142,7 @@ DECLARED_SYMBOLS = (
     "mythos_langevin_store",
     "mythos_langevin_get_step",
     "mythos_langevin_set_step",
+    "mythos_langevin_set_seed",
     "mythos_langevin_last_kernel_ms",
     "mythos_langevin_last_recoveries",
     "mythos_langevin_last_rebuilds",

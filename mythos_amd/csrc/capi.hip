@@ -234,6 +234,7 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
   MYTHOS_HIP_TRY(hipDeviceSynchronize());  // no kernel in flight reads a half-written table
   if (terms == 0) {
     s->pseq_terms = 0;
+    ++s->list_epoch;  // integrators drop forces cached from the old distribution (the unfused oxNA path keeps some)
     return MYTHOS_OK;
   }
   const int n = s->n;
@@ -309,6 +310,7 @@ int mythos_oxdna_set_pseq(mythos_system_t* s, const double* marginals, const int
   MYTHOS_HIP_TRY(hipMemcpy(s->d_ps_unit, unit, (size_t)n * sizeof(int), hipMemcpyHostToDevice));
   s->pseq_terms = terms;
   s->ps_n_bp = n_bp;
+  ++s->list_epoch;
   return MYTHOS_OK;
 }
 

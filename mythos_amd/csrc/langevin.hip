@@ -142,6 +142,12 @@ int md_load(mythos_sim_t* s, void* c, void* q, void* p, void* l, hipStream_t st)
 }
 
 int md_advance(mythos_sim_t* s, int n_steps, int save_every, bool close, void* tc, void* tq, double* e_trace, hipStream_t st) {
+  // quaternion rows are written as one 4-vector per nucleotide
+  const size_t q_align = s->sys->dtype == MYTHOS_F32 ? sizeof(float4) : sizeof(double4);
+  if (save_every > 0 && tq && (reinterpret_cast<uintptr_t>(tq) % q_align) != 0) {
+    set_error("mythos_langevin_run / advance: traj_quat must be aligned to 4 elements (" + std::to_string(q_align) + " bytes)");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
   return s->sys->dtype == MYTHOS_F32 ? mythos_md_advance<float>(s, n_steps, save_every, close, tc, tq, e_trace, st)
                                      : mythos_md_advance<double>(s, n_steps, save_every, close, tc, tq, e_trace, st);
 }
@@ -218,6 +224,15 @@ int mythos_langevin_set_step(mythos_sim_t* s, int64_t step) {
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   s->step = step;
+  return MYTHOS_OK;
+}
+
+int mythos_langevin_set_seed(mythos_sim_t* s, uint64_t seed) {
+  if (!s) {
+    set_error("mythos_langevin_set_seed: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->seed = seed;
   return MYTHOS_OK;
 }
 

@@ -76,6 +76,7 @@ class OxdnaSystem:
             raise _lib.MythosHipError(f"mythos_oxdna_create: {_lib.last_error()}")
         self._lib = lib
         self._pseq_n_bp = 0
+        self._pseq_terms = 0
         # oxNA (model 4): three vectors - oxDNA2, oxRNA2, hybrid - one after the other; dU/dparams rows likewise
         self.n_params = lib.mythos_oxdna_param_count() * (3 if self.model == 4 else 1)
         if self.model == 4:
@@ -109,6 +110,7 @@ class OxdnaSystem:
         """Probabilistic sequence (mythos_oxdna_set_pseq); ``terms`` = 0 or no arguments: back to the discrete sequence."""
         if not terms:
             _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, None, None, 0, None, 0), "set_pseq")
+            self._pseq_terms = 0
             return
         marg = np.ascontiguousarray(marginals, dtype=np.float64)
         unit = np.ascontiguousarray(unit, dtype=np.int32)
@@ -123,6 +125,7 @@ class OxdnaSystem:
             raise ValueError("bp_probs has fewer rows than the base pairs named in unit")
         _lib.check(self._lib.mythos_oxdna_set_pseq(self._h, marg.ctypes.data_as(_lib.c_double_p), unit.ctypes.data_as(_lib.c_int_p),
                                                    n_bp, bp.ctypes.data_as(_lib.c_double_p), int(terms)), "set_pseq")
+        self._pseq_terms = int(terms)
 
     def set_neighbors(self, pairs) -> None:
         pairs = np.ascontiguousarray(pairs, dtype=np.int32)
@@ -327,6 +330,10 @@ class LangevinIntegrator:
     @step.setter
     def step(self, value: int) -> None:
         _lib.check(self._lib.mythos_langevin_set_step(self._h, int(value)), "set_step")
+
+    def set_seed(self, seed: int) -> None:
+        """Key of the noise from the next launch / init_momenta on (mythos_langevin_set_seed)."""
+        _lib.check(self._lib.mythos_langevin_set_seed(self._h, C.c_uint64(int(seed) & (2**64 - 1))), "set_seed")
 
     def set_timing(self, samples: int) -> None:
         """Bracket ``samples`` dispatches per run with HIP event pairs (0 = off, the default; see last_kernel_ms)."""

@@ -6,8 +6,17 @@
                          simulator_init=nvt_langevin, neighbors=NoNeighborList(top.unbonded_neighbors))
     out = sim.run(opt_params, init_state, n_steps, key)      # SimulatorOutput([SimulatorTrajectory])
 
-The reference scans ``step_fn`` and stores the state after EVERY step; ``run`` does the same by
-default (``save_every=1``) but takes a cadence, and the whole loop is one C-ABI call.
+The reference scans ``step_fn`` and stores the state after EVERY step - ``state.position`` and nothing else
+(jaxmd.py:84-99); ``run`` does the same by default (``save_every=1``, positions only: the step launch that produces a
+saved state writes it to its row, no other cost) but takes a cadence, and the whole loop is one C-ABI call.
+``trace_energy=True`` adds the term and kinetic energies of the saved steps (``metadata``), at the price of the
+energy-trace instantiation of the step kernel; the reference's way to the energies of a trajectory is ``energy_fn.map``.
+
+The device-side objects of a run - the system handle with its neighbour rows, the integrator with its frames - are kept
+on the simulator between calls, keyed by everything they were built from (topology, model, precision, device, replica
+count, list, integrator constants).  A later ``run`` with other parameters uploads the 2 KB parameter vector, sets the
+key and the step counter, and steps (the reference: "parameter update: negligible", docs/source/energy_functions.rst:51-54;
+its own run re-traces nothing when only ``opt_params`` change, jaxmd.py:60-68).
 """
 
 from __future__ import annotations
@@ -74,8 +83,12 @@ class HipMDSimulator(Simulator):
     simulator_init: Callable = nvt_langevin
     neighbors: Any = None
     save_every: int = 1
+    # The reference computes in fp64 (jax_enable_x64).  The default here is fp32 - north_star's "fp32 forces at 1e-3", with
+    # centres carried as hi + lo pairs - because sampling does not need more and runs 1.7x faster;
+    # pass dtype=torch.float64 for the reference's precision (the step-by-step oracle tests run there).
     dtype: torch.dtype = torch.float32
     device: Any = None
+    trace_energy: bool = False  # energies of the saved steps in trajectory.metadata (the energy-trace instantiation)
     # defaults for callers that only pass parameters (SimpleOptimizer.step: simulator.run(params, **state))
     init_state: Any = None
     n_steps: int | None = None
@@ -85,6 +98,24 @@ class HipMDSimulator(Simulator):
     # system, not 64 steps.  Every nucleotide has its own Philox stream, so replicas are statistically independent.
     # The reference runs replicas as separate simulator instances (mythos/simulators/base.py MultiSimulator, Ray).
     n_replicas: int = 1
+    # device-side objects kept between calls: {key: (OxdnaSystem, LangevinIntegrator, pinned python objects)}
+    _resident: dict = dc.field(default_factory=dict, init=False, repr=False, compare=False)
+
+    def __getstate__(self):  # (the reference's simulators travel through Ray: handles stay behind)
+        d = {f.name: getattr(self, f.name) for f in dc.fields(self) if f.name != "_resident"}
+        return d
+
+    def __setstate__(self, d):
+        for k, v in d.items():
+            object.__setattr__(self, k, v)
+        object.__setattr__(self, "_resident", {})
+
+    def release(self) -> None:
+        """Free the device-side objects kept from earlier runs."""
+        for system, integ, _ in self._resident.values():
+            integ.close()
+            system.close()
+        self._resident.clear()
 
     def run(self, opt_params: dict, init_state: RigidBody | None = None, n_steps: int | None = None, key: int | None = None,
             **_) -> SimulatorOutput:
@@ -152,8 +183,48 @@ class HipMDSimulator(Simulator):
             bonded_a = np.concatenate([bonded_2 + r * n_one for r in range(n_rep)], axis=0)
         if n_rep > 1 and is_rna is not None:
             is_rna = np.tile(np.asarray(is_rna), n_rep)
-        system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev, is_rna=is_rna)
-        system.set_params(flat.detach())
+        mass, inertia = _pair(sp.mass)
+        gamma_t, gamma_r = _pair(sp.gamma)
+        mass_f = float(np.asarray(mass).reshape(-1)[0])
+        inertia_a = np.asarray(inertia, dtype=np.float64).reshape(-1)[:3]
+        nb = self.neighbors
+        pairs_obj = None if isinstance(nb, VerletNeighborList) else (nb.idx if nb is not None else first.unbonded_neighbors)
+        bts = lambda a: None if a is None else np.ascontiguousarray(a).tobytes()  # noqa: E731
+        key_res = (
+            model, n_rep, self.dtype, str(dev), bts(np.asarray(seq_a, dtype=np.int32)), bts(None if end_a is None else np.asarray(end_a, dtype=np.uint8)),
+            bts(np.asarray(bonded_a, dtype=np.int32)), None if box is None else tuple(np.asarray(box, dtype=np.float64).reshape(-1).tolist()),
+            bts(None if is_rna is None else np.asarray(is_rna, dtype=np.uint8)),
+            ("verlet", float(nb.r_cutoff), float(nb.dr_threshold), int(nb.rebuild_every)) if pairs_obj is None else ("pairs", id(pairs_obj)),
+            float(sp.dt), float(sp.kT), float(gamma_t), float(gamma_r), mass_f, tuple(inertia_a.tolist()),
+        )
+        entry = self._resident.get(key_res)
+        if entry is None:
+            system = OxdnaSystem(model, seq_a, end_a, bonded_a, box=box, dtype=self.dtype, device=dev, is_rna=is_rna)
+            integ = LangevinIntegrator(system, dt=sp.dt, kT=sp.kT, gamma_t=float(gamma_t), gamma_r=float(gamma_r), mass=mass_f,
+                                       inertia=inertia_a, seed=int(key))
+            system.set_params(flat.detach())
+            if pairs_obj is None:
+                integ.set_neighbor_policy(nb.r_cutoff, nb.dr_threshold, nb.rebuild_every)
+            else:
+                from mythos_amd.energy.base import _pairs_2xP
+
+                p2 = _pairs_2xP(pairs_obj, n_one)
+                if n_rep > 1:
+                    p2 = np.concatenate([np.asarray(p2).reshape(-1, 2) + r * n_one for r in range(n_rep)], axis=0)
+                system.set_neighbors(p2)
+            while len(self._resident) >= 4:  # (a simulator serves one system; a few variants at most)
+                old_system, old_integ, _ = self._resident.pop(next(iter(self._resident)))
+                old_integ.close()
+                old_system.close()
+            # (pairs_obj is pinned: its id is part of the key)
+            self._resident[key_res] = (system, integ, pairs_obj)
+            had_pseq = False
+        else:
+            system, integ, _ = entry
+            system.set_params(flat.detach())  # 2 KB; everything derived from it on the device follows (param_epoch)
+            integ.set_seed(int(key))
+            integ.step = 0  # a run starts its noise stream at (key, step 0), as a new integrator would
+            had_pseq = system._pseq_terms != 0
         if pseq is not None:
             marg, unit, bp, terms = pseq
             if n_rep > 1:  # every replica its own copy of the base pairs
@@ -161,22 +232,8 @@ class HipMDSimulator(Simulator):
                 unit = np.concatenate([np.where(unit >= 0, unit + 2 * n_bp * r, -1) for r in range(n_rep)])
                 marg, bp = np.tile(marg, (n_rep, 1)), (np.tile(bp, (n_rep, 1)) if n_bp > 0 else bp)
             system.set_pseq(marg, unit, bp, terms)
-        mass, inertia = _pair(sp.mass)
-        gamma_t, gamma_r = _pair(sp.gamma)
-        integ = LangevinIntegrator(system, dt=sp.dt, kT=sp.kT, gamma_t=float(gamma_t), gamma_r=float(gamma_r),
-                                   mass=float(np.asarray(mass).reshape(-1)[0]),
-                                   inertia=np.asarray(inertia, dtype=np.float64).reshape(-1)[:3], seed=int(key))
-        nb = self.neighbors
-        if isinstance(nb, VerletNeighborList):
-            integ.set_neighbor_policy(nb.r_cutoff, nb.dr_threshold, nb.rebuild_every)
-        else:
-            pairs = nb.idx if nb is not None else first.unbonded_neighbors
-            from mythos_amd.energy.base import _pairs_2xP
-
-            p2 = _pairs_2xP(pairs, n_one)
-            if n_rep > 1:
-                p2 = np.concatenate([np.asarray(p2).reshape(-1, 2) + r * n_one for r in range(n_rep)], axis=0)
-            system.set_neighbors(p2)
+        elif had_pseq:
+            system.set_pseq()
         c = init_state.center.to(device=dev, dtype=self.dtype).contiguous().clone()
         q = init_state.orientation.vec.to(device=dev, dtype=self.dtype).contiguous().clone()
         offsets = None
@@ -196,7 +253,7 @@ class HipMDSimulator(Simulator):
             c = (c + offsets).reshape(n_rep * n_one, 3).contiguous()
             q = q.reshape(n_rep * n_one, 4).contiguous()
         p, ang = integ.init_momenta()
-        tc, tq, et = integ.run(c, q, p, ang, int(n_steps), save_every=self.save_every)
+        tc, tq, et = integ.run(c, q, p, ang, int(n_steps), save_every=self.save_every, want_energy=self.trace_energy)
         if n_rep > 1:
             # states of all replicas, replica-major: (R * S, n, .); the offsets of the grid come off again
             def unbatch(t, width, off):

@@ -239,7 +239,7 @@ def test_bench_strings_fit_the_drivers_parsed_record():
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     for steps, save_every, n in ((20, 0, 21), (2000, 0, 5), (100000, 1000, 5)):
-        args = argparse.Namespace(steps=steps, save_every=save_every, dtype="f32")
+        args = argparse.Namespace(steps=steps, save_every=save_every, dtype="f32", trace_energy=save_every > 0)
         m = {"rebuilds_in_median": steps // 50, "samples_ms": [0.3] * n}
         txt = bench._timed_region(args, m, {"steps_per_s": 40714.2})
         assert len(txt) <= 120 and f"{steps} steps" in txt and "f64 40.7k" in txt and f"median of {n}" in txt

@@ -180,7 +180,8 @@ def test_simulator_run_surface():
     )
     init = _states(traj, torch.float32)[0]
     for nb in (NoNeighborList(unbonded_nbrs=top.unbonded_neighbors), VerletNeighborList(3.25, 0.6, 20)):
-        sim = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin, neighbors=nb)
+        sim = HipMDSimulator(energy_fn=ef, simulator_params=params, space=(disp, shift), simulator_init=nvt_langevin, neighbors=nb,
+                             trace_energy=True)
         assert sim.exposes()[0].startswith("trajectory.HipMDSimulator.")
         out = sim.run({"eps_hb": 1.05}, init, 50, key=3)
         tr = out.observables[0]
