@@ -360,6 +360,19 @@ int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* sim, doubl
 int mythos_martini_langevin_init_velocities(mythos_martini_sim_t* sim, void* vel, mythos_stream_t stream);
 int mythos_martini_langevin_run(mythos_martini_sim_t* sim, void* pos, void* vel, const double* box, int n_steps,
                                 int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream);
+/* Resident form, as mythos_langevin_load / advance / store: the state stays in the integrator's layout on the device
+ * between calls, the list and its rebuild schedule carry over, advance(n) is n launches of the step kernel and leaves the
+ * frame open (velocities short of the closing half kick of step n; the next advance or store supplies it).
+ * mythos_martini_langevin_run == load; advance; store.  advance(a); advance(b) == advance(a + b), bit for bit.
+ * e_trace == NULL with traj_pos != NULL: positions-only rows, written by the step launch that produces the saved state. */
+int mythos_martini_langevin_load(mythos_martini_sim_t* sim, const void* pos, const void* vel, const double* box,
+                                 mythos_stream_t stream);
+int mythos_martini_langevin_advance(mythos_martini_sim_t* sim, int n_steps, int save_every, void* traj_pos, double* e_trace,
+                                    mythos_stream_t stream);
+int mythos_martini_langevin_store(mythos_martini_sim_t* sim, void* pos, void* vel, mythos_stream_t stream);
+int64_t mythos_martini_langevin_get_step(const mythos_martini_sim_t* sim);
+/* scheduled list rebuilds inside the last advance (as mythos_langevin_last_rebuilds) */
+int mythos_martini_langevin_last_rebuilds(const mythos_martini_sim_t* sim, int* scheduled);
 int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* sim, double* kernel_ms,
                                            double* loop_ms_per_launch, int* launches, int* samples);
 int mythos_martini_langevin_set_timing(mythos_martini_sim_t* sim, int samples); /* as mythos_langevin_set_timing */

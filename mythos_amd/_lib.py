@@ -97,6 +97,11 @@ def load() -> C.CDLL:
         "mythos_martini_langevin_set_neighbor_policy": (C.c_int, [V, C.c_double, C.c_int]),
         "mythos_martini_langevin_init_velocities": (C.c_int, [V, V, V]),
         "mythos_martini_langevin_run": (C.c_int, [V, V, V, c_double_p, C.c_int, C.c_int, V, V, V]),
+        "mythos_martini_langevin_load": (C.c_int, [V, V, V, c_double_p, V]),
+        "mythos_martini_langevin_advance": (C.c_int, [V, C.c_int, C.c_int, V, V, V]),
+        "mythos_martini_langevin_store": (C.c_int, [V, V, V, V]),
+        "mythos_martini_langevin_get_step": (C.c_int64, [V]),
+        "mythos_martini_langevin_last_rebuilds": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_martini_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mythos_martini_langevin_last_recoveries": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_martini_langevin_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
@@ -160,6 +165,11 @@ DECLARED_SYMBOLS = (
     "mythos_martini_langevin_set_neighbor_policy",
     "mythos_martini_langevin_init_velocities",
     "mythos_martini_langevin_run",
+    "mythos_martini_langevin_load",
+    "mythos_martini_langevin_advance",
+    "mythos_martini_langevin_store",
+    "mythos_martini_langevin_get_step",
+    "mythos_martini_langevin_last_rebuilds",
     "mythos_martini_langevin_last_kernel_ms",
     "mythos_martini_langevin_neighbor_stats",
     "mythos_martini_langevin_last_recoveries",

@@ -210,18 +210,25 @@ __global__ __launch_bounds__(256) void martini_bonded_kernel(
 // LJ: dU/dsigma[a][b] and dU/deps[a][b] per frame for the ORDERED type pair (type of the owner, type of the
 // partner); every pair is visited from both ends with weight 1/2, so the derivative with respect to a
 // symmetric table entry is out[a][b] + out[b][a] - which is what differentiating through the host's
-// symmetric table construction yields.  Workgroup tables in LDS (fp64 atomics), then one fp64 atomic per
-// touched entry into the frame's table.
+// symmetric table construction yields.
+// Reproducible bit for bit (round 4; until then the tables were one LDS copy shared by the four wavefronts and fp64
+// global atomics per touched entry): every WAVEFRONT accumulates into its own LDS copy of the two tables - what a copy
+// receives comes from one instruction stream in program order, colliding lanes of an instruction are served in lane
+// order -, the four copies are added in a fixed order into the workgroup's partial tables in HBM, and a second kernel
+// adds the workgroups' partials of a frame in index order.  No atomic touches global memory.
 // ------------------------------------------------------------------------------------------------
+constexpr int kLjWaves = kLjBlock / 64;
 template <typename R>
 __global__ __launch_bounds__(kLjBlock) void martini_lj_pgrad_kernel(
     int n, const R* __restrict__ pos, const R* __restrict__ box, const int* __restrict__ types,
     const R* __restrict__ sigma, const R* __restrict__ eps, const int* __restrict__ excl, MartiniConst<R> K,
-    int n_tiles, double* __restrict__ d_sigma, double* __restrict__ d_eps) {
+    int n_tiles, double* __restrict__ part /* [frame][workgroup][2 tt] */) {
   extern __shared__ unsigned char smem_raw[];
-  double* s_ds = reinterpret_cast<double*>(smem_raw);
-  double* s_de = s_ds + K.n_types * K.n_types;
-  R* s_sig = reinterpret_cast<R*>(s_de + K.n_types * K.n_types);
+  const int tt = K.n_types * K.n_types;
+  double* s_tab = reinterpret_cast<double*>(smem_raw);  // [kLjWaves][2 tt]: dU/dsigma | dU/deps, one copy per wavefront
+  double* s_ds = s_tab + (size_t)(threadIdx.x >> 6) * 2 * tt;
+  double* s_de = s_ds + tt;
+  R* s_sig = reinterpret_cast<R*>(s_tab + (size_t)kLjWaves * 2 * tt);
   R* s_eps = s_sig + K.n_types * K.n_types;
   R* s_x = s_eps + K.n_types * K.n_types;
   R* s_y = s_x + kLjBlock;
@@ -234,14 +241,12 @@ __global__ __launch_bounds__(kLjBlock) void martini_lj_pgrad_kernel(
   const R* __restrict__ p = pos + (size_t)frame * n * 3;
   const R lx = box[frame * 3], ly = box[frame * 3 + 1], lz = box[frame * 3 + 2];
   const R ilx = R(1) / lx, ily = R(1) / ly, ilz = R(1) / lz;
-  const int tt = K.n_types * K.n_types;
   const R irc2 = R(1) / K.rc2;
   for (int k = threadIdx.x; k < tt; k += kLjBlock) {
     s_sig[k] = sigma[k];
     s_eps[k] = eps[k];
-    s_ds[k] = 0.0;
-    s_de[k] = 0.0;
   }
+  for (int k = threadIdx.x; k < kLjWaves * 2 * tt; k += kLjBlock) s_tab[k] = 0.0;
   R xi = 0, yi = 0, zi = 0;
   int ti = 0;
   int ex[kMaxExcl];
@@ -286,10 +291,26 @@ __global__ __launch_bounds__(kLjBlock) void martini_lj_pgrad_kernel(
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < tt; k += kLjBlock) {
-    if (s_ds[k] != 0.0) atomicAdd(&d_sigma[(size_t)frame * tt + k], s_ds[k]);
-    if (s_de[k] != 0.0) atomicAdd(&d_eps[(size_t)frame * tt + k], s_de[k]);
+  // the workgroup's partial tables: the wavefronts' copies added in wavefront order
+  double* __restrict__ out = part + ((size_t)frame * gridDim.x * gridDim.y + (size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * tt;
+  for (int k = threadIdx.x; k < 2 * tt; k += kLjBlock) {
+    double acc = 0.0;
+#pragma unroll
+    for (int w = 0; w < kLjWaves; ++w) acc += s_tab[(size_t)w * 2 * tt + k];
+    out[k] = acc;
   }
+}
+
+// d_sigma[frame][k], d_eps[frame][k] = the sum over the frame's workgroups, in index order, of their partial tables
+__global__ __launch_bounds__(256) void martini_lj_pgrad_reduce_kernel(const double* __restrict__ part, int n_wg, int tt,
+                                                                      double* __restrict__ d_sigma, double* __restrict__ d_eps) {
+  const int frame = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= 2 * tt) return;
+  const double* p = part + (size_t)frame * n_wg * 2 * tt + k;
+  double acc = 0.0;
+  for (int w = 0; w < n_wg; ++w) acc += p[(size_t)w * 2 * tt];
+  if (k < tt) d_sigma[(size_t)frame * tt + k] = acc; else d_eps[(size_t)frame * tt + (k - tt)] = acc;
 }
 
 // one thread per bond / per angle: dE/dk and dE/dr0 (dE/dtheta0), E as in martini_bonded_kernel
@@ -452,18 +473,26 @@ static int martini_pgrad_typed(mythos_martini* m, const R* pos, const R* box, in
       set_error("mythos_martini_param_grads: d_sigma and d_eps come as a pair");
       return MYTHOS_ERR_INVALID_ARGUMENT;
     }
-    MYTHOS_HIP_TRY(hipMemsetAsync(d_sigma, 0, (size_t)n_frames * tt * sizeof(double), st));
-    MYTHOS_HIP_TRY(hipMemsetAsync(d_eps, 0, (size_t)n_frames * tt * sizeof(double), st));
-    const size_t lds = 2 * tt * sizeof(double) + 2 * tt * sizeof(R) + 3 * kLjBlock * sizeof(R) + kLjBlock * sizeof(int);
+    const size_t lds = (size_t)kLjWaves * 2 * tt * sizeof(double) + 2 * tt * sizeof(R) + 3 * kLjBlock * sizeof(R) + kLjBlock * sizeof(int);
+    if (lds > 160 * 1024) {
+      set_error("mythos_martini_param_grads: too many bead types for the per-wavefront gradient tables (" + std::to_string(m->n_types) + ")");
+      return MYTHOS_ERR_INVALID_ARGUMENT;
+    }
     MYTHOS_HIP_TRY(hipFuncSetAttribute((const void*)martini_lj_pgrad_kernel<R>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int n_js = std::min(nbx, std::max(1, 768 / std::max(1, nbx)));
-    for (int f0 = 0; f0 < n_frames; f0 += 4096) {
-      const int nf = std::min(n_frames - f0, 4096);
-      hipLaunchKernelGGL(martini_lj_pgrad_kernel<R>, dim3(nbx, nf > 16 ? std::max(1, n_js / 4) : n_js, nf),
+    const int n_js_all = std::min(nbx, std::max(1, 768 / std::max(1, nbx)));
+    const int n_js = n_frames > 16 ? std::max(1, n_js_all / 4) : n_js_all;
+    const int n_wg = nbx * n_js;  // workgroups, and partial tables, per frame
+    // frames per chunk: at most 256 MB of partial tables
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>(4096, (size_t(256) << 20) / ((size_t)n_wg * 2 * tt * sizeof(double))));
+    if (int rc = grow(m->d_ljpart, m->ljpart_cap, (size_t)std::min(chunk, n_frames) * n_wg * 2 * tt)) return rc;
+    for (int f0 = 0; f0 < n_frames; f0 += chunk) {
+      const int nf = std::min(n_frames - f0, chunk);
+      hipLaunchKernelGGL(martini_lj_pgrad_kernel<R>, dim3(nbx, n_js, nf),
                          dim3(kLjBlock), lds, st, n, pos + (size_t)f0 * n * 3, box + (size_t)f0 * 3, m->d_types,
-                         (const R*)m->d_sigma, (const R*)m->d_eps, m->d_excl, K, nbx, d_sigma + (size_t)f0 * tt,
-                         d_eps + (size_t)f0 * tt);
+                         (const R*)m->d_sigma, (const R*)m->d_eps, m->d_excl, K, nbx, m->d_ljpart);
+      hipLaunchKernelGGL(martini_lj_pgrad_reduce_kernel, dim3((unsigned)((2 * tt + 255) / 256), nf), dim3(256), 0, st,
+                         (const double*)m->d_ljpart, n_wg, (int)tt, d_sigma + (size_t)f0 * tt, d_eps + (size_t)f0 * tt);
     }
   }
   if (d_bk || d_br || d_ak || d_at) {
@@ -559,7 +588,7 @@ void mythos_martini_destroy(mythos_martini_t* m) {
   (void)hipSetDevice(m->device);
   void* ptrs[] = {m->d_types, m->d_excl,   m->d_bead_bonds, m->d_bead_angles, m->d_bonds,  m->d_angles, m->d_sigma,
                   m->d_eps,   m->d_bond_k, m->d_bond_r0,    m->d_angle_k,     m->d_angle_t0, m->d_fpart, m->d_epart,
-                  m->d_ebpart};
+                  m->d_ebpart, m->d_ljpart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete m;

@@ -35,8 +35,8 @@ struct mythos_martini {
        *d_angle_t0 = nullptr;
   void* d_fpart = nullptr;
   size_t fpart_cap = 0;
-  double *d_epart = nullptr, *d_ebpart = nullptr;
-  size_t epart_cap = 0, ebpart_cap = 0;
+  double *d_epart = nullptr, *d_ebpart = nullptr, *d_ljpart = nullptr;  // d_ljpart: per-workgroup dU/dsigma | dU/deps tables
+  size_t epart_cap = 0, ebpart_cap = 0, ljpart_cap = 0;
 };
 
 #endif  // MYTHOS_MARTINI_INTERNAL_H

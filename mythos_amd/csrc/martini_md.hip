@@ -293,6 +293,11 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     }
     out[ib] = V4{x[0], x[1], x[2], x0.w};
     vel[ib] = V4{v[0], v[1], v[2], im};
+    if constexpr (!SAVE) {
+      // positions-only trajectory (e_trace == NULL): the launch that produces x_{k+1} writes it to the caller's row too
+      // (md_step_kernel does the same, langevin_core.inc) - no energy-trace instantiation, no reduction, no closing launch
+      if (traj) traj[3 * (size_t)ib] = x[0], traj[3 * (size_t)ib + 1] = x[1], traj[3 * (size_t)ib + 2] = x[2];
+    }
   }
   if constexpr (SAVE) {
     __syncthreads();
@@ -572,6 +577,16 @@ struct mythos_martini_sim {
   double last_kernel_ms = 0, last_avg_ms = 0;
   int last_launches = 0, last_samples = 0, last_max_row = 0, last_recoveries = 0;
   bool list_fitted = false;  // a synchronising, growing build has sized rows and buckets for this integrator
+  // resident state (mythos_martini_langevin_load / advance / store): the frames hold a state between calls
+  double box[3] = {0, 0, 0};
+  bool resident = false;    // frame[cur] + vel hold a state
+  bool list_valid = false;  // the rows were built from this state's history and the rebuild schedule continues
+  bool open = false;        // x_n with velocities short of the closing half kick of step n (advance)
+  int cur = 0;
+  int since_build = 0;      // steps taken since the rows were built
+  int last_rebuilds = 0;    // scheduled rebuilds inside the last advance
+  int* h_ctl = nullptr;     // pinned: [0..3] d_flags, [4..6] d_overflow as the device published them
+  int* d_ctl = nullptr;     // device address of h_ctl
 };
 
 namespace mythos {
@@ -633,14 +648,17 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
   return 0;
 }
 
+// End of a segment: hand the control words to the host (pinned memory), as the oxDNA integrator does (langevin_core.inc).
+static __global__ void mm_publish_ctl_kernel(const int* __restrict__ flags, const int* __restrict__ overflow, int* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  out[0] = flags[0], out[1] = flags[1], out[2] = flags[2], out[3] = flags[3];
+  out[4] = overflow[0], out[5] = overflow[1], out[6] = overflow[2];
+}
+
 template <typename R>
-static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[3], int n_steps, int save_every,
-                        R* traj_pos, double* e_trace, hipStream_t st) {
-  using V4 = typename Real4<R>::type;
-  mythos_martini* m = sim->sys;
-  const int n = m->n;
-  const int blocks = (n + kMmPPB - 1) / kMmPPB, grid = 8 * ((blocks + 7) / 8);
-  const int tb = (n + 255) / 256;
+static MmConst<R> mm_const(const mythos_martini_sim* sim) {
+  const mythos_martini* m = sim->sys;
+  const double* box = sim->box;
   MmConst<R> K;
   K.lx = R(box[0]), K.ly = R(box[1]), K.lz = R(box[2]);
   K.ilx = R(1.0 / box[0]), K.ily = R(1.0 / box[1]), K.ilz = R(1.0 / box[2]);
@@ -648,15 +666,57 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
   K.dt = R(sim->dt), K.half_dt = R(0.5 * sim->dt), K.c1 = R(std::exp(-sim->gamma * sim->dt)), K.kT = R(sim->kT);
   K.skin_half_sq = R(0.25 * sim->skin * sim->skin);
   K.n_types = m->n_types, K.angle_kind = m->angle_kind;
+  return K;
+}
+
+// caller's (n, 3) arrays -> the resident frame; the list of a previous state does not carry over
+template <typename R>
+static int mm_load_typed(mythos_martini_sim* sim, const R* pos, const R* v, const double box[3], hipStream_t st) {
+  using V4 = typename Real4<R>::type;
+  mythos_martini* m = sim->sys;
+  const int n = m->n, tb = (n + 255) / 256;
+  for (int k = 0; k < 3; ++k) sim->box[k] = box[k];
+  hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
+                     (V4*)sim->frame[0], (V4*)sim->vel);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  sim->cur = 0;
+  sim->resident = true;
+  sim->list_valid = false;
+  sim->open = false;
+  sim->since_build = 0;
+  return MYTHOS_OK;
+}
+
+// n_steps on the resident state (the protocol of advance_typed in langevin_core.inc).  Launch k evaluates the forces at
+// x_k, closes step k - 1 with them (second half kick) and takes step k up to its drift.  close = true: n_steps + 1
+// launches, the last one only closes.  close = false (mythos_martini_langevin_advance): n_steps launches, the frame is
+// left OPEN and whoever comes next supplies the closing half kick with the force evaluation it needs anyway - the next
+// advance in its first launch (advance(a); advance(b) is advance(a + b) launch for launch), store through a zero-step
+// closing call.  Rows with energies (e_trace != NULL) come from the energy-trace instantiation at x_k plus a reduction
+// launch; rows without are written by the launch that produces the saved state.
+template <typename R>
+static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every, bool close, R* traj_pos, double* e_trace,
+                            hipStream_t st) {
+  using V4 = typename Real4<R>::type;
+  mythos_martini* m = sim->sys;
+  const int n = m->n;
+  const int blocks = (n + kMmPPB - 1) / kMmPPB, grid = 8 * ((blocks + 7) / 8);
+  const MmConst<R> K = mm_const<R>(sim);
+  const double* box = sim->box;
   V4* fr[2] = {(V4*)sim->frame[0], (V4*)sim->frame[1]};
   V4* vel = (V4*)sim->vel;
+  const bool energy_rows = save_every > 0 && e_trace != nullptr;
+  const bool plain_rows = save_every > 0 && e_trace == nullptr && traj_pos != nullptr;
+  const bool closes = close || (energy_rows && n_steps > 0 && n_steps % save_every == 0);
+  const int n_launch = closes ? n_steps + 1 : n_steps;
+  if (n_launch == 0) return MYTHOS_OK;
+  const bool was_open = sim->open;
+  const int cur0 = sim->cur;
+  int cur = cur0;
   MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags, 0, 4 * sizeof(int), st));
-  hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
-                     fr[0], vel);
-  int cur = 0;
   // A build that may grow: rows until the longest fits with a quarter of headroom, buckets until none is more than
-  // half full (fuller ones work, through the spill list, but slowly).  Used for the first build of the run and to
-  // recover from a halt (see below); the scheduled builds inside the run cannot stop to grow.
+  // half full (fuller ones work, through the spill list, but slowly).  Used for the first build of an integrator and to
+  // recover from a halt (see below); the scheduled builds inside a call cannot stop to grow.
   auto build_until_fit = [&](int buf) -> int {
     for (int attempt = 0;; ++attempt) {
       MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
@@ -688,36 +748,48 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       if (demand > 0) sim->cell_bucket_cap = ((2 * demand + 15) / 16) * 16;
     }
   };
-  // the first run of this integrator sizes rows and buckets with the synchronising build; later runs just rebuild
-  // (an overflow there halts the first step kernel and is recovered below)
+  // k index at which the rows in use were built (negative: so many steps before this call)
+  int built_at = 0;
   if (!sim->list_fitted) {
     if (int rc = build_until_fit(cur)) return rc;
     sim->list_fitted = true;
-  } else {
+  } else if (!sim->list_valid) {
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_overflow, 0, 3 * sizeof(int), st));
     if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
+  } else {
+    built_at = -sim->since_build;
   }
+  sim->list_valid = true;
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
-  MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
-  int launches = 0, samples = 0, recoveries = 0;
+  const bool timing = sim->timing_samples > 0;
+  if (timing) MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
+  int launches = 0, samples = 0, recoveries = 0, scheduled = 0;
   const int max_samples = std::min(sim->timing_samples, (int)mythos_martini_sim::kMaxSamples);  // 0: no dispatch is bracketed
-  const int sample_stride = std::max(1, (n_steps + 1) / std::max(1, max_samples));
+  const int sample_stride = std::max(1, n_launch / std::max(1, max_samples));
   // Segments of kSegment launches; a halted segment (a bead left its skin before the scheduled rebuild, or a rebuild
   // overflowed: the launches behind it return at once) is followed by a growing rebuild at the last valid state and
   // a resume there - the protocol of mythos_langevin_run (langevin_core.inc).
-  constexpr int kSegment = 8192, kMaxRecoveries = 64;
-  int k = 0, seg_len = kSegment;  // a run that has halted once looks more often: less queued behind the next halt
-  while (k <= n_steps) {
-    const int seg_end = std::min(n_steps, k + seg_len - 1);
+  constexpr int kMaxRecoveries = 64;
+  const long long dbg_seg = debug_value(MYTHOS_DEBUG_MD_SEGMENT);
+  const int kSegment = dbg_seg > 0 ? (int)std::min<long long>(dbg_seg, 1 << 20) : 8192;
+  int k = 0, seg_len = kSegment;  // a call that has halted once looks more often: less queued behind the next halt
+  int err_bits = 0, ovw[3] = {0, 0, 0};
+  while (k < n_launch) {
+    const int seg_end = std::min(n_launch - 1, k + seg_len - 1);
     for (; k <= seg_end; ++k) {
-      const bool last = (k == n_steps);
-      const bool save = save_every > 0 && k > 0 && (k % save_every == 0);
-      const int sidx = save ? (k / save_every - 1) : 0;
-      if (k > 0 && !last && (k % sim->rebuild_every == 0))
+      const bool last = (k == n_steps);  // (reached only by a call that closes)
+      const bool save = energy_rows && k > 0 && (k % save_every == 0);
+      const bool save_next = plain_rows && !last && ((k + 1) % save_every == 0);  // this launch's OUTPUT is a saved state
+      const int sidx = save ? (k / save_every - 1) : (save_next ? ((k + 1) / save_every - 1) : 0);
+      // (a closing-only launch rebuilds too when the schedule says so - as advance_typed in langevin_core.inc)
+      if (k - built_at >= sim->rebuild_every) {
         if (int rc = mm_rebuild<R>(sim, fr[cur], K, box, st)) return rc;
-      const R kick_close = (k == 0) ? R(0) : R(0.5);
+        built_at = k;
+        ++scheduled;
+      }
+      const R kick_close = (k == 0 && !was_open) ? R(0) : R(0.5);
       const int do_step = last ? 0 : 1;
-      R* tp = (save && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
+      R* tp = ((save || save_next) && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
       const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
 #define MM_ARGS                                                                                                    \
   n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, sim->d_rows, sim->d_row_len, sim->row_stride, (const R*)m->d_sigma,    \
@@ -727,7 +799,7 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       if (save) {
         hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
         hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
-                           e_trace ? e_trace + (size_t)sidx * kMmTrace : nullptr);
+                           e_trace + (size_t)sidx * kMmTrace);
       } else if (sampled) {
         hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
                               sim->sb[samples], 0, MM_ARGS);
@@ -739,53 +811,64 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
       ++launches;
       cur ^= 1;
     }
-    int ctl[4] = {0, 0, 0, 0}, ovs[3] = {0, 0, 0};
-    MYTHOS_HIP_TRY(hipMemcpyAsync(ctl, sim->d_flags, sizeof(ctl), hipMemcpyDeviceToHost, st));
-    MYTHOS_HIP_TRY(hipMemcpyAsync(ovs, sim->d_overflow, sizeof(ovs), hipMemcpyDeviceToHost, st));
+    if (timing && k >= n_launch) MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
+    hipLaunchKernelGGL(mm_publish_ctl_kernel, dim3(1), dim3(1), 0, st, (const int*)sim->d_flags, (const int*)sim->d_overflow, sim->d_ctl);
+    MYTHOS_HIP_TRY(hipGetLastError());
     MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-    if ((ctl[0] & 2) != 0) break;                               // NaN: reported below
-    if (ctl[1] == 0 && ovs[0] == 0 && ovs[1] == 0) continue;    // nothing halted
+    const int* ctl = sim->h_ctl;
+    err_bits |= ctl[0];
+    for (int w = 0; w < 3; ++w) ovw[w] = ctl[4 + w];
+    if ((err_bits & 2) != 0) break;                               // NaN: reported below
+    if (ctl[1] == 0 && ovw[0] == 0 && ovw[1] == 0) continue;      // nothing halted
+    const int ran = ctl[2];  // kernels 0 .. ran-1 ran; the state they left is in the frame kernel `ran` reads
     if (++recoveries > kMaxRecoveries) {
-      sim->step += ctl[2];
+      sim->cur = cur0 ^ (ran & 1);
+      sim->step += ran;
+      sim->open = was_open || ran > 0;
+      sim->list_valid = false;
+      (void)hipMemsetAsync(sim->d_flags, 0, 4 * sizeof(int), st);
       set_error("mythos_martini_langevin_run: the neighbour list had to be rebuilt out of turn more than " +
                 std::to_string(kMaxRecoveries) + " times in one run: the skin (" + std::to_string(sim->skin) +
                 ") is too small for a rebuild every " + std::to_string(sim->rebuild_every) + " steps");
       return MYTHOS_ERR_OVERFLOW;
     }
-    k = ctl[2];  // kernels 0 .. k-1 ran; the state they left is in frame (k & 1)
-    cur = k & 1;
-    seg_len = std::max(256, seg_len / 4);
+    k = ran;
+    cur = cur0 ^ (k & 1);
+    seg_len = std::max(std::min(256, kSegment), seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
     if (int rc = build_until_fit(cur)) return rc;
+    built_at = k;
+    ovw[0] = ovw[1] = 0;
   }
   sim->last_recoveries = recoveries;
-  MYTHOS_HIP_TRY(hipEventRecord(sim->ev1, st));
-  MYTHOS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(mm_unpack_kernel<R>, dim3(tb), dim3(256), 0, st, n, (const V4*)fr[cur], (const V4*)vel, pos, v);
-  int flags = 0, ovw[3] = {0, 0, 0};
-  MYTHOS_HIP_TRY(hipMemcpyAsync(&flags, sim->d_flags, sizeof(int), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipMemcpyAsync(ovw, sim->d_overflow, sizeof(ovw), hipMemcpyDeviceToHost, st));
-  MYTHOS_HIP_TRY(hipStreamSynchronize(st));
-  const int ov = ovw[0];
-  float ms = 0;
-  MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
-  sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
-  sim->last_launches = launches;
-  double acc = 0;
-  for (int k = 0; k < samples; ++k) {
-    float t = 0;
-    MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[k], sim->sb[k]));
-    acc += t;
+  sim->last_rebuilds = scheduled;
+  sim->cur = cur;
+  sim->open = !closes;
+  sim->since_build = n_steps - built_at;
+  if (timing) {
+    float ms = 0;
+    MYTHOS_HIP_TRY(hipEventElapsedTime(&ms, sim->ev0, sim->ev1));
+    sim->last_avg_ms = launches ? double(ms) / launches : 0.0;
+    double acc = 0;
+    for (int q = 0; q < samples; ++q) {
+      float t = 0;
+      MYTHOS_HIP_TRY(hipEventElapsedTime(&t, sim->sa[q], sim->sb[q]));
+      acc += t;
+    }
+    sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  } else {
+    sim->last_avg_ms = sim->last_kernel_ms = 0.0;
   }
-  sim->last_kernel_ms = samples ? acc / samples : 0.0;
+  sim->last_launches = launches;
   sim->last_samples = samples;
   sim->step += n_steps;
-  if (flags & 2) {
+  if (err_bits & 2) {
+    sim->resident = false;
     set_error("mythos_martini_langevin_run: NaN in the state (time step too large or overlapping start configuration)");
     return MYTHOS_ERR_NUMERIC;
   }
-  if (ov != 0) {
-    set_error("mythos_martini_langevin_run: neighbour row capacity exceeded (" + std::to_string(ov) + " > " +
+  if (ovw[0] != 0) {
+    set_error("mythos_martini_langevin_run: neighbour row capacity exceeded (" + std::to_string(ovw[0]) + " > " +
               std::to_string(sim->row_stride) + ")");
     return MYTHOS_ERR_OVERFLOW;
   }
@@ -795,6 +878,17 @@ static int mm_run_typed(mythos_martini_sim* sim, R* pos, R* v, const double box[
     return MYTHOS_ERR_OVERFLOW;
   }
   return MYTHOS_OK;
+}
+
+// the resident frame -> caller's arrays (asynchronous on st); an open frame gets its closing half kick first
+template <typename R>
+static int mm_store_typed(mythos_martini_sim* sim, R* pos, R* v, hipStream_t st) {
+  using V4 = typename Real4<R>::type;
+  const int n = sim->sys->n;
+  const int rc = sim->open ? mm_advance_typed<R>(sim, 0, 0, true, nullptr, nullptr, st) : MYTHOS_OK;
+  hipLaunchKernelGGL(mm_unpack_kernel<R>, dim3((n + 255) / 256), dim3(256), 0, st, n, (const V4*)sim->frame[sim->cur], (const V4*)sim->vel, pos, v);
+  MYTHOS_HIP_TRY(hipGetLastError());
+  return rc;
 }
 
 }  // namespace mythos
@@ -808,6 +902,7 @@ void mythos_martini_langevin_destroy(mythos_martini_sim_t* s) {
                   s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (s->h_ctl) (void)hipHostFree(s->h_ctl);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (int k = 0; k < mythos_martini_sim::kMaxSamples; ++k) {
@@ -851,6 +946,9 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
   ok = ok && hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&s->h_ctl, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
+       hipHostGetDevicePointer((void**)&s->d_ctl, s->h_ctl, 0) == hipSuccess && hipMemset(s->d_overflow, 0, 3 * sizeof(int)) == hipSuccess;
+  if (ok) std::fill(s->h_ctl, s->h_ctl + 8, 0);
   for (int k = 0; ok && k < mythos_martini_sim::kMaxSamples; ++k)
     ok = hipEventCreate(&s->sa[k]) == hipSuccess && hipEventCreate(&s->sb[k]) == hipSuccess;
   if (!ok) {
@@ -869,6 +967,7 @@ int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* s, double 
   s->skin = skin;
   s->rebuild_every = rebuild_every;
   s->list_fitted = false;  // another list range: size rows and buckets again at the next run
+  s->list_valid = false;
   return MYTHOS_OK;
 }
 
@@ -888,23 +987,101 @@ int mythos_martini_langevin_init_velocities(mythos_martini_sim_t* s, void* vel, 
   return MYTHOS_OK;
 }
 
-int mythos_martini_langevin_run(mythos_martini_sim_t* s, void* pos, void* vel, const double* box, int n_steps,
-                                int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream) {
-  if (!s || !pos || !vel || !box || n_steps < 0 || save_every < 0 || !(box[0] > 0) || !(box[1] > 0) || !(box[2] > 0)) {
-    set_error("mythos_martini_langevin_run: invalid argument");
+namespace {
+
+int mm_check_box(const mythos_martini_sim_t* s, const double* box, const char* who) {
+  if (!box || !(box[0] > 0) || !(box[1] > 0) || !(box[2] > 0)) {
+    set_error(std::string(who) + ": invalid argument");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
   const double rl = s->sys->r_cut + s->skin;
   if (2.0 * rl > std::min(box[0], std::min(box[1], box[2]))) {
-    set_error("mythos_martini_langevin_run: the box is smaller than twice (r_cut + skin): minimum image breaks down");
+    set_error(std::string(who) + ": the box is smaller than twice (r_cut + skin): minimum image breaks down");
     return MYTHOS_ERR_INVALID_ARGUMENT;
   }
+  return MYTHOS_OK;
+}
+
+int mm_load(mythos_martini_sim_t* s, const void* pos, const void* vel, const double* box, hipStream_t st) {
+  return s->sys->dtype == MYTHOS_F32 ? mm_load_typed<float>(s, (const float*)pos, (const float*)vel, box, st)
+                                     : mm_load_typed<double>(s, (const double*)pos, (const double*)vel, box, st);
+}
+int mm_advance(mythos_martini_sim_t* s, int n_steps, int save_every, bool close, void* traj, double* e_trace, hipStream_t st) {
+  return s->sys->dtype == MYTHOS_F32 ? mm_advance_typed<float>(s, n_steps, save_every, close, (float*)traj, e_trace, st)
+                                     : mm_advance_typed<double>(s, n_steps, save_every, close, (double*)traj, e_trace, st);
+}
+int mm_store(mythos_martini_sim_t* s, void* pos, void* vel, hipStream_t st) {
+  return s->sys->dtype == MYTHOS_F32 ? mm_store_typed<float>(s, (float*)pos, (float*)vel, st) : mm_store_typed<double>(s, (double*)pos, (double*)vel, st);
+}
+
+}  // namespace
+
+int mythos_martini_langevin_run(mythos_martini_sim_t* s, void* pos, void* vel, const double* box, int n_steps,
+                                int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream) {
+  if (!s || !pos || !vel || n_steps < 0 || save_every < 0) {
+    set_error("mythos_martini_langevin_run: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (int rc = mm_check_box(s, box, "mythos_martini_langevin_run")) return rc;
   MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
-  if (s->sys->dtype == MYTHOS_F32)
-    return mm_run_typed<float>(s, (float*)pos, (float*)vel, box, n_steps, save_every, (float*)traj_pos, e_trace,
-                               (hipStream_t)stream);
-  return mm_run_typed<double>(s, (double*)pos, (double*)vel, box, n_steps, save_every, (double*)traj_pos, e_trace,
-                              (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = mm_load(s, pos, vel, box, st)) return rc;
+  const int rc = mm_advance(s, n_steps, save_every, true, traj_pos, e_trace, st);
+  // the state of the last valid step goes back to the caller whatever the run reported
+  if (s->resident) {
+    if (int rs = mm_store(s, pos, vel, st)) return rc ? rc : rs;
+    MYTHOS_HIP_TRY(hipStreamSynchronize(st));
+  }
+  return rc;
+}
+
+int mythos_martini_langevin_load(mythos_martini_sim_t* s, const void* pos, const void* vel, const double* box, mythos_stream_t stream) {
+  if (!s || !pos || !vel) {
+    set_error("mythos_martini_langevin_load: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (int rc = mm_check_box(s, box, "mythos_martini_langevin_load")) return rc;
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  return mm_load(s, pos, vel, box, (hipStream_t)stream);
+}
+
+int mythos_martini_langevin_advance(mythos_martini_sim_t* s, int n_steps, int save_every, void* traj_pos, double* e_trace,
+                                    mythos_stream_t stream) {
+  if (!s || n_steps < 0 || save_every < 0) {
+    set_error("mythos_martini_langevin_advance: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->resident) {
+    set_error("mythos_martini_langevin_advance: no resident state (call mythos_martini_langevin_load first; a run that ended in a "
+              "numeric error drops its state)");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  return mm_advance(s, n_steps, save_every, false, traj_pos, e_trace, (hipStream_t)stream);
+}
+
+int mythos_martini_langevin_store(mythos_martini_sim_t* s, void* pos, void* vel, mythos_stream_t stream) {
+  if (!s || !pos || !vel) {
+    set_error("mythos_martini_langevin_store: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  if (!s->resident) {
+    set_error("mythos_martini_langevin_store: no resident state");
+    return MYTHOS_ERR_NOT_READY;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  return mm_store(s, pos, vel, (hipStream_t)stream);
+}
+
+int64_t mythos_martini_langevin_get_step(const mythos_martini_sim_t* s) { return s ? (int64_t)s->step : -1; }
+
+int mythos_martini_langevin_last_rebuilds(const mythos_martini_sim_t* s, int* scheduled) {
+  if (!s || !scheduled) {
+    set_error("mythos_martini_langevin_last_rebuilds: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  *scheduled = s->last_rebuilds;
+  return MYTHOS_OK;
 }
 
 int mythos_martini_langevin_last_kernel_ms(const mythos_martini_sim_t* s, double* kernel_ms, double* loop_ms_per_launch,

@@ -13,6 +13,7 @@
 #include "wave_ops.h"
 
 namespace mythos {
+inline namespace MYTHOS_MATH_NS {  // (see oxdna_math.h)
 
 template <typename R>
 struct Vec4T;
@@ -85,6 +86,25 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
   return d;
 }
 
+template <int G, typename R>
+__device__ __forceinline__ void group_reduce_v3(V3<R>& v) {
+  v.x = group_sum<G>(v.x);
+  v.y = group_sum<G>(v.y);
+  v.z = group_sum<G>(v.z);
+}
+
+template <int G, typename R, bool GRAD>
+__device__ __forceinline__ void group_reduce(R* __restrict__ e, SelfGrad<R>& sg) {
+#pragma unroll
+  for (int k = 0; k < T_COUNT; ++k) e[k] = group_sum<G>(e[k]);
+  if constexpr (GRAD) {
+    group_reduce_v3<G>(sg.dc);
+    group_reduce_v3<G>(sg.g1);
+    group_reduce_v3<G>(sg.g2);
+    group_reduce_v3<G>(sg.g3);
+  }
+}
+
 // Walk row i with the G lanes of a group.  On return every lane holds its PARTIAL sums;
 // call group_reduce() to fold them.  Every pair is visited from both ends, so energies (and
 // parameter partials, inside the sink) carry weight 1/2.
@@ -100,11 +120,20 @@ __device__ __forceinline__ V3<R> min_image(V3<R> d, const BoxT<R>& box) {
 // support) a single fused loop ran ~200 instructions of radial terms for every entry and the ~1 000-instruction
 // angular code in every iteration for a lane or two; the kernel is VALU-bound, so instructions are its time.
 // items: this group's LDS, two lists of list_cap ints (near entries, angular entries of the segment being walked).
-template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, bool SEGMENTED = false, class Loader, class PT>
+// PARK (the energy kernel's fp64 gradient instantiations): the sums of the radial stages do not ride through the angular
+// stage in registers.  In front of stage 4 they are folded over the group and added to the group's row `park` in LDS
+// (kParkWidth words, zeroed by the caller), the accumulators start again from zero, and every angular item adds its own
+// contribution to that row with LDS atomics - all lanes of a group are lanes of ONE wavefront, so what a row receives
+// comes from one instruction stream in program order (colliding lanes of an instruction are served in lane order): the
+// sums are reproducible bit for bit like the folded ones.  The caller reads the row back after the walk.  What it buys:
+// 12 gradient + 8 energy accumulators (40 registers in fp64) are not live across the ~3 000 instructions of an angular
+// item with parameter partials, which is where that instantiation spilled.
+constexpr int kParkWidth = T_COUNT + 12;
+template <typename R, int MODEL, bool GRAD, class PG, int G, bool BONDED = true, bool SEGMENTED = false, bool PARK = false, class Loader, class PT>
 __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const BoxT<R>& box,
                                            const int* __restrict__ rows, int row_stride, int len, int i,
                                            const Nuc<R>& self, int lane, R* __restrict__ e, SelfGrad<R>& sg,
-                                           PG& pg, int* __restrict__ items, R rnear2, int list_cap) {
+                                           PG& pg, int* __restrict__ items, R rnear2, int list_cap, R* __restrict__ park = nullptr) {
   static_assert(G <= 32, "group masks below are 32-bit");
   const int* __restrict__ row = rows + (size_t)i * row_stride;
   const int gshift = (threadIdx.x & 63) & ~(G - 1);
@@ -167,6 +196,45 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     // 4. angular terms
+    if constexpr (PARK) {
+      group_reduce<G, R, GRAD>(e, sg);
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < T_COUNT; ++t) park[t] += e[t];
+        if constexpr (GRAD) {
+          park[T_COUNT + 0] += sg.dc.x, park[T_COUNT + 1] += sg.dc.y, park[T_COUNT + 2] += sg.dc.z;
+          park[T_COUNT + 3] += sg.g1.x, park[T_COUNT + 4] += sg.g1.y, park[T_COUNT + 5] += sg.g1.z;
+          park[T_COUNT + 6] += sg.g2.x, park[T_COUNT + 7] += sg.g2.y, park[T_COUNT + 8] += sg.g2.z;
+          park[T_COUNT + 9] += sg.g3.x, park[T_COUNT + 10] += sg.g3.y, park[T_COUNT + 11] += sg.g3.z;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < T_COUNT; ++t) e[t] = R(0);
+      sg.dc = sg.g1 = sg.g2 = sg.g3 = V3<R>{R(0), R(0), R(0)};
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int k = lane; k < n_ang; k += G) {
+        const int entry = ang_list[k];
+        Nuc<R> other;
+        R q4[4];
+        ld.load(entry & ROW_INDEX_MASK, other, q4);
+        R ei[T_COUNT];
+#pragma unroll
+        for (int t = 0; t < T_COUNT; ++t) ei[t] = R(0);
+        SelfGrad<R> si;
+        si.dc = si.g1 = si.g2 = si.g3 = V3<R>{R(0), R(0), R(0)};
+        unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5), ei, si,
+                                             pg);
+        // (the angular terms write three of the energies: hydrogen bonding, cross-stacking, coaxial stacking)
+        atomicAdd(&park[T_HB], ei[T_HB]), atomicAdd(&park[T_CRST], ei[T_CRST]), atomicAdd(&park[T_CXST], ei[T_CXST]);
+        if constexpr (GRAD) {
+          atomicAdd(&park[T_COUNT + 0], si.dc.x), atomicAdd(&park[T_COUNT + 1], si.dc.y), atomicAdd(&park[T_COUNT + 2], si.dc.z);
+          atomicAdd(&park[T_COUNT + 3], si.g1.x), atomicAdd(&park[T_COUNT + 4], si.g1.y), atomicAdd(&park[T_COUNT + 5], si.g1.z);
+          atomicAdd(&park[T_COUNT + 6], si.g2.x), atomicAdd(&park[T_COUNT + 7], si.g2.y), atomicAdd(&park[T_COUNT + 8], si.g2.z);
+          atomicAdd(&park[T_COUNT + 9], si.g3.x), atomicAdd(&park[T_COUNT + 10], si.g3.y), atomicAdd(&park[T_COUNT + 11], si.g3.z);
+        }
+      }
+    } else {
     for (int k = lane; k < n_ang; k += G) {
       const int entry = ang_list[k];
       Nuc<R> other;
@@ -175,27 +243,9 @@ __device__ __forceinline__ void gather_row(const PT& P, const Loader& ld, const 
       unbonded_angular<R, MODEL, GRAD, PG>(P, self, other, min_image(other.c - self.c, box), (entry & ROW_ROLE_Q) == 0, R(0.5), e, sg,
                                            pg);
     }
+    }
     __builtin_amdgcn_wave_barrier();  // the lists are rewritten by the next segment
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  }
-}
-
-template <int G, typename R>
-__device__ __forceinline__ void group_reduce_v3(V3<R>& v) {
-  v.x = group_sum<G>(v.x);
-  v.y = group_sum<G>(v.y);
-  v.z = group_sum<G>(v.z);
-}
-
-template <int G, typename R, bool GRAD>
-__device__ __forceinline__ void group_reduce(R* __restrict__ e, SelfGrad<R>& sg) {
-#pragma unroll
-  for (int k = 0; k < T_COUNT; ++k) e[k] = group_sum<G>(e[k]);
-  if constexpr (GRAD) {
-    group_reduce_v3<G>(sg.dc);
-    group_reduce_v3<G>(sg.g1);
-    group_reduce_v3<G>(sg.g2);
-    group_reduce_v3<G>(sg.g3);
   }
 }
 
@@ -217,4 +267,5 @@ __device__ __forceinline__ V3<R> axes_grad_to_torque(const Nuc<R>& s, const Self
   return -t;
 }
 
+}  // inline namespace MYTHOS_MATH_NS
 }  // namespace mythos

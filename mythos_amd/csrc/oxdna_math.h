@@ -130,13 +130,6 @@ __device__ __forceinline__ double m_acos(double x) { return acos(x); }
 __device__ __forceinline__ float m_rint(float x) { return rintf(x); }
 __device__ __forceinline__ double m_rint(double x) { return rint(x); }
 
-template <typename R>
-struct FD {  // value and derivative with respect to the argument
-  R f, d;
-};
-
-constexpr double kPi = 3.14159265358979323846;
-
 // MYTHOS_LEAN_MATH (set by langevin_core.inc for the stepping kernels: 1 = the fp32 instantiations, 2 = both precisions):
 // branch-free forms of the piecewise modulation functions - all pieces computed, then selected - instead of divergent
 // three-way branches (every piece is executed anyway as soon as the lanes of a wavefront disagree, plus the exec-mask
@@ -145,6 +138,27 @@ constexpr double kPi = 3.14159265358979323846;
 #ifndef MYTHOS_LEAN_MATH
 #define MYTHOS_LEAN_MATH 0
 #endif
+// Everything below - and oxdna_pair.h, oxdna_gather.h on top of it - lives in an inline namespace named after the switch:
+// the stepping kernels' translation units (MYTHOS_LEAN_MATH = 1) and the others (0) compile different bodies for f1, f2,
+// f4, f5 and the weight look-up, and under one name that is a violation of the one-definition rule (harmless while device
+// code is inlined per translation unit, undefined as soon as anything links device code across units).  Distinct
+// entities have no such problem; unqualified names resolve as before.
+#if MYTHOS_LEAN_MATH == 0
+#define MYTHOS_MATH_NS exact_math
+#elif MYTHOS_LEAN_MATH == 1
+#define MYTHOS_MATH_NS lean_math_f32
+#else
+#define MYTHOS_MATH_NS lean_math_all
+#endif
+inline namespace MYTHOS_MATH_NS {
+
+template <typename R>
+struct FD {  // value and derivative with respect to the argument
+  R f, d;
+};
+
+constexpr double kPi = 3.14159265358979323846;
+
 template <typename R>
 constexpr bool kLeanMath = (MYTHOS_LEAN_MATH == 2) || ((MYTHOS_LEAN_MATH == 1) && sizeof(R) == 4);
 
@@ -576,4 +590,5 @@ __device__ __forceinline__ void debye_pgrad(R r, const PT& P, R mult, PG& pg) {
   }
 }
 
+}  // inline namespace MYTHOS_MATH_NS
 }  // namespace mythos

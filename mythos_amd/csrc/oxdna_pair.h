@@ -22,6 +22,7 @@
 #include "oxdna_math.h"
 
 namespace mythos {
+inline namespace MYTHOS_MATH_NS {  // (see oxdna_math.h)
 
 enum OxTerm : int {
   T_FENE = 0,
@@ -55,9 +56,9 @@ __device__ __forceinline__ void quat_axes(R q0, R q1, R q2, R q3, V3<R>& a1, V3<
 // 4x4 sequence-weight lookup: an indexed read of an LDS-staged vector, or a select chain over scalar
 // registers for the kernel-argument copy (a lane-varying index into kernel arguments would force the
 // whole block into scratch memory)
-template <typename R = void, class PT>
+template <typename R, class PT>
 __device__ __forceinline__ auto weight_lookup(const PT& P, int base, int k) {
-  if constexpr (PT::indexed || (MYTHOS_LEAN_MATH != 0)) {
+  if constexpr (PT::indexed || kLeanMath<R>) {
     // (fp32 stepping kernels, MYTHOS_LEAN_MATH: ONE vector load at a lane-varying address; the select chain below is
     // what the compiler makes of it anyway - fifteen compares and selects that compute the offset of that same load)
     return P[base + k];
@@ -69,12 +70,25 @@ __device__ __forceinline__ auto weight_lookup(const PT& P, int base, int k) {
   }
 }
 
+// What the sequence-weight look-ups read of a nucleotide, BY VALUE.  The callers choose p and q by the role of the owner;
+// choosing between two `const Nuc&` made the select one of ADDRESSES, and where the compiler could not see through it
+// (the oxNA instantiations: three inlined copies of every pair function) both nucleotides - 112 B each in fp64 - were
+// kept in scratch memory and read back through a lane-varying address: that was the 232 ... 720 B of scratch of every
+// oxNA kernel through round 3, not register pressure.
+struct SeqId {
+  int seq, idx;
+};
+template <typename R>
+__device__ __forceinline__ SeqId seq_id(bool first, const Nuc<R>& a, const Nuc<R>& b) {
+  return SeqId{first ? a.seq : b.seq, first ? a.idx : b.idx};
+}
+
 // Weight of the ordered pair (p, q) of a sequence-dependent term: table[seq_p][seq_q] (dna1/stacking.py:287,
 // dna1/hydrogen_bonding.py:333), or - under a probabilistic sequence - its expectation (energy/utils.py:45-132):
 // sum_ab P(p = a, q = b) table[a][b] with P the product of the marginals for nucleotides of different units and
 // sum_t P(type t) [a, b = members of type t] for the two members of one constrained base pair.
 template <typename R, class PT>
-__device__ __forceinline__ R seq_weight(const PT& P, int base, int term_bit, const Nuc<R>& p, const Nuc<R>& q) {
+__device__ __forceinline__ R seq_weight(const PT& P, int base, int term_bit, const SeqId p, const SeqId q) {
   if constexpr (PT::has_pseq) {
     if (P.ps.marg != nullptr && (P.ps.terms & term_bit) != 0) {
       const int up = P.ps.unit[p.idx], uq = P.ps.unit[q.idx];
@@ -95,12 +109,12 @@ __device__ __forceinline__ R seq_weight(const PT& P, int base, int term_bit, con
       return w;
     }
   }
-  return weight_lookup(P, base, p.seq * 4 + q.seq);
+  return weight_lookup<R>(P, base, p.seq * 4 + q.seq);
 }
 
 // dU/dtable[a][b] of the same weight: scale * P(p = a, q = b)
 template <typename R, class PG, class PT>
-__device__ __forceinline__ void seq_weight_pgrad(const PT& P, int base, int term_bit, const Nuc<R>& p, const Nuc<R>& q,
+__device__ __forceinline__ void seq_weight_pgrad(const PT& P, int base, int term_bit, const SeqId p, const SeqId q,
                                                  R scale, PG& pg) {
   if constexpr (PT::has_pseq) {
     if (P.ps.marg != nullptr && (P.ps.terms & term_bit) != 0) {
@@ -232,11 +246,15 @@ struct HybGeo {
     st_o = o_rna ? st_r : st_d, ba_o = o_rna ? ba_r : ba_d, k1_o = o_rna ? k1_r : k1_d, k2_o = o_rna ? k2_r : k2_d;
   }
   __device__ __forceinline__ V3<R> disp(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o, R als, R bes, R alo, R beo) const {
+    // (the second axis is selected BY VALUE, component by component: `o3 ? o.a3 : o.a2` is a select between two ADDRESSES
+    // inside the nucleotides, and that kept both of them - 112 B each in fp64 - in scratch memory in every oxNA kernel)
+    const V3<R> ob{o3 ? o.a3.x : o.a2.x, o3 ? o.a3.y : o.a2.y, o3 ? o.a3.z : o.a2.z};
+    const V3<R> sb{s3 ? s.a3.x : s.a2.x, s3 ? s.a3.y : s.a2.y, s3 ? s.a3.z : s.a2.z};
     V3<R> d = dco;
     axpy(d, alo, o.a1);
-    axpy(d, beo, o3 ? o.a3 : o.a2);
+    axpy(d, beo, ob);
     axpy(d, -als, s.a1);
-    axpy(d, -bes, s3 ? s.a3 : s.a2);
+    axpy(d, -bes, sb);
     return d;
   }
   __device__ __forceinline__ V3<R> back_back(V3<R> dco, const Nuc<R>& s, const Nuc<R>& o) const { return disp(dco, s, o, k1_s, k2_s, k1_o, k2_o); }
@@ -385,14 +403,14 @@ __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const 
     if (Bs.f == R(0)) return;
     const FD<R> Bo = f5_eval(xo, qo);
     if (Bo.f == R(0)) return;
-    const R wseq = seq_weight(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s);
+    const R wseq = seq_weight<R>(P, STCK_EPS_00, 1, seq_id(role_p, s, o), seq_id(role_p, o, s));
     const R ang = As.f * Ao.f * Avs.f * Avo.f;
     const R phi = Bs.f * Bo.f;
     const R v = F1.f * ang * phi;
     e[T_STCK] += wgt * wseq * v;
     const R w = wseq * P[TW_STCK];
     if constexpr (PG::on) {
-      seq_weight_pgrad(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s, P[TW_STCK] * v, pg);
+      seq_weight_pgrad<R>(P, STCK_EPS_00, 1, seq_id(role_p, s, o), seq_id(role_p, o, s), P[TW_STCK] * v, pg);
       f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
       f4_pgrad(ts.f, ps, w * F1.f * Ao.f * Avs.f * Avo.f * phi, pg);
       f4_pgrad(to.f, po, w * F1.f * As.f * Avs.f * Avo.f * phi, pg);
@@ -467,14 +485,14 @@ __device__ __forceinline__ void bonded_pair(const PT& P, const Nuc<R>& s, const 
     if (Bs.f == R(0)) return;
     const FD<R> Bo = f5_eval(xo, qo);
     if (Bo.f == R(0)) return;
-    const R wseq = seq_weight(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s);
+    const R wseq = seq_weight<R>(P, STCK_EPS_00, 1, seq_id(role_p, s, o), seq_id(role_p, o, s));
     const R ang = A4.f * As.f * Ao.f;
     const R phi = Bs.f * Bo.f;
     const R v = F1.f * ang * phi;
     e[T_STCK] += wgt * wseq * v;
     const R w = wseq * P[TW_STCK];  // gradients carry the term weight
     if constexpr (PG::on) {
-      seq_weight_pgrad(P, STCK_EPS_00, 1, role_p ? s : o, role_p ? o : s, P[TW_STCK] * v, pg);
+      seq_weight_pgrad<R>(P, STCK_EPS_00, 1, seq_id(role_p, s, o), seq_id(role_p, o, s), P[TW_STCK] * v, pg);
       f1_pgrad(rs, P, STCK_RLOW, w * ang * phi, pg);
       f4_pgrad(t4.f, p4, w * F1.f * As.f * Ao.f * phi, pg);
       f4_pgrad(ts.f, ps, w * F1.f * A4.f * Ao.f * phi, pg);
@@ -574,26 +592,30 @@ __device__ __forceinline__ bool unbonded_radial_geo(const PT& P, const Nuc<R>& s
 // Which parameter vector and functional form an unbonded oxNA pair takes (na1/unbonded_excluded_volume.py:140-174 and
 // the other unbonded terms): both RNA -> oxRNA2, both DNA -> oxDNA2, one of each -> the hybrid numbers in the oxDNA1
 // forms (cross-stacking with theta4, coaxial stacking with f5 of cos phi3 / phi4) plus Debye-Hueckel: "MODEL 4" below.
-#define MYTHOS_NA1_UNBONDED(FN, ...)                                                                       \
-  if (s.rna && o.rna) {                                                                                    \
-    OffsetPG<PG> opg{pg, (int)OXP_COUNT};                                                                  \
-    const UniGeo<R, 3> geo(P.rna);                                                                         \
-    return FN<R, 3, GRAD, OffsetPG<PG> __VA_ARGS__>(P.rna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
-  }                                                                                                        \
-  if (!s.rna && !o.rna) {                                                                                  \
-    OffsetPG<PG> opg{pg, 0};                                                                               \
-    const UniGeo<R, 2> geo(P.dna);                                                                         \
-    return FN<R, 2, GRAD, OffsetPG<PG> __VA_ARGS__>(P.dna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
-  }                                                                                                        \
-  OffsetPG<PG> opg{pg, 2 * (int)OXP_COUNT};                                                                \
-  const HybGeo<R> geo(P.dna, P.rna, s.rna != 0, o.rna != 0);                                               \
-  return FN<R, 4, GRAD, OffsetPG<PG> __VA_ARGS__>(P.drh, s, o, dco, role_p, wgt, e, sg, opg, geo);
+// (an if / else-if / else chain of plain calls whose result lands in RESULT: through round 3 this was three `return FN(...)`
+// inside a lambda that captured e, sg, pg by reference, and the closure kept them addressable)
+#define MYTHOS_NA1_UNBONDED(RESULT, FN, ...)                                                                 \
+  if (s.rna && o.rna) {                                                                                      \
+    OffsetPG<PG> opg{pg, (int)OXP_COUNT};                                                                    \
+    const UniGeo<R, 3> geo(P.rna);                                                                           \
+    RESULT = FN<R, 3, GRAD, OffsetPG<PG> __VA_ARGS__>(P.rna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
+  } else if (!s.rna && !o.rna) {                                                                             \
+    OffsetPG<PG> opg{pg, 0};                                                                                 \
+    const UniGeo<R, 2> geo(P.dna);                                                                           \
+    RESULT = FN<R, 2, GRAD, OffsetPG<PG> __VA_ARGS__>(P.dna, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
+  } else {                                                                                                   \
+    OffsetPG<PG> opg{pg, 2 * (int)OXP_COUNT};                                                                \
+    const HybGeo<R> geo(P.dna, P.rna, s.rna != 0, o.rna != 0);                                               \
+    RESULT = FN<R, 4, GRAD, OffsetPG<PG> __VA_ARGS__>(P.drh, s, o, dco, role_p, wgt, e, sg, opg, geo);       \
+  }
 
 template <typename R, int MODEL, bool GRAD, class PG, class PT>
 __device__ __forceinline__ bool unbonded_radial(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                 bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   if constexpr (MODEL == 4) {
-    MYTHOS_NA1_UNBONDED(unbonded_radial_geo)
+    bool angular;
+    MYTHOS_NA1_UNBONDED(angular, unbonded_radial_geo)
+    return angular;
   } else {
     const UniGeo<R, MODEL> geo(P);
     return unbonded_radial_geo<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg, geo);
@@ -622,7 +644,7 @@ __device__ __forceinline__ bool unbonded_angular_geo(const PT& P, const Nuc<R>& 
     const R r = m_sqrt(dot(d, d));
     V3<R> gd{R(0), R(0), R(0)};
     bool any = false;
-    const R whb = seq_weight(P, HYDR_EPS_00, 2, role_p ? s : o, role_p ? o : s);
+    const R whb = seq_weight<R>(P, HYDR_EPS_00, 2, seq_id(role_p, s, o), seq_id(role_p, o, s));
     const FD<R> F1 = ((TERMS & 1) && (whb != R(0) || PG::on)) ? f1_eval(r, P, HYDR_RLOW) : FD<R>{R(0), R(0)};
     const FD<R> F2 = (TERMS & 2) ? f2_eval(r, P, CRST_RLOW) : FD<R>{R(0), R(0)};
     const bool hb_on = (F1.f != R(0) || F1.d != R(0));
@@ -666,7 +688,7 @@ __device__ __forceinline__ bool unbonded_angular_geo(const PT& P, const Nuc<R>& 
           const R whg = whb * P[TW_HB];
           const R wf = whg * F1.f;
           if constexpr (PG::on) {
-            seq_weight_pgrad(P, HYDR_EPS_00, 2, role_p ? s : o, role_p ? o : s, P[TW_HB] * vhb, pg);
+            seq_weight_pgrad<R>(P, HYDR_EPS_00, 2, seq_id(role_p, s, o), seq_id(role_p, o, s), P[TW_HB] * vhb, pg);
             f1_pgrad(r, P, HYDR_RLOW, whg * ang, pg);
             f4_pgrad(t1.f, p1, wf * o1, pg);
             f4_pgrad(t4.f, p4, wf * o4, pg);
@@ -867,7 +889,9 @@ template <typename R, int MODEL, bool GRAD, class PG, int TERMS = 7, class PT>
 __device__ __forceinline__ void unbonded_angular(const PT& P, const Nuc<R>& s, const Nuc<R>& o, V3<R> dco,
                                                  bool role_p, R wgt, R* __restrict__ e, SelfGrad<R>& sg, PG& pg) {
   if constexpr (MODEL == 4) {
-    [&]() -> bool { MYTHOS_NA1_UNBONDED(unbonded_angular_geo, , TERMS) }();
+    bool done;
+    MYTHOS_NA1_UNBONDED(done, unbonded_angular_geo, , TERMS)
+    (void)done;
   } else {
     const UniGeo<R, MODEL> geo(P);
     unbonded_angular_geo<R, MODEL, GRAD, PG, TERMS>(P, s, o, dco, role_p, wgt, e, sg, pg, geo);
@@ -882,4 +906,5 @@ __device__ __forceinline__ void unbonded_pair(const PT& P, const Nuc<R>& s, cons
     unbonded_angular<R, MODEL, GRAD, PG>(P, s, o, dco, role_p, wgt, e, sg, pg);
 }
 
+}  // inline namespace MYTHOS_MATH_NS
 }  // namespace mythos

@@ -494,24 +494,61 @@ class MartiniLangevinIntegrator:
         _lib.check(self._lib.mythos_martini_langevin_init_velocities(self._h, _lib.ptr(v), _stream(self.system.device)), "init_velocities")
         return v
 
-    def run(self, pos, vel, box, n_steps: int, save_every: int = 0):
-        """Advance ``pos`` / ``vel`` (n, 3) in place -> (traj_pos (S, n, 3) or None, e_trace (S, 4) float64 or None);
-        e_trace columns: lj, bond, angle, kinetic (kJ/mol) at the saved steps."""
+    def _check_state(self, pos, vel):
         s = self.system
         for t, name in ((pos, "pos"), (vel, "vel")):
             if t.device != s.device or t.dtype != s.dtype or tuple(t.shape) != (s.n, 3) or not t.is_contiguous():
                 raise ValueError(f"{name} must be a contiguous {s.dtype} tensor of shape ({s.n}, 3) on {s.device}")
-        box = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3))
+
+    def _rows(self, n_steps: int, save_every: int, want_energy: bool):
+        s = self.system
         ns = n_steps // save_every if save_every > 0 else 0
         traj = torch.empty((ns, s.n, 3), dtype=s.dtype, device=s.device) if ns else None
-        et = torch.zeros((ns, 4), dtype=torch.float64, device=s.device) if ns else None
-        _lib.check(
-            self._lib.mythos_martini_langevin_run(
-                self._h, _lib.ptr(pos), _lib.ptr(vel), box.ctypes.data_as(_lib.c_double_p), int(n_steps), int(save_every),
-                _lib.ptr(traj), _lib.ptr(et), _stream(s.device)),
-            "martini_langevin_run",
-        )
+        et = torch.zeros((ns, 4), dtype=torch.float64, device=s.device) if (ns and want_energy) else None
         return traj, et
+
+    def run(self, pos, vel, box, n_steps: int, save_every: int = 0, want_energy: bool = True):
+        """Advance ``pos`` / ``vel`` (n, 3) in place -> (traj_pos (S, n, 3) or None, e_trace (S, 4) float64 or None);
+        e_trace columns: lj, bond, angle, kinetic (kJ/mol) at the saved steps (``want_energy=False``: positions only)."""
+        s = self.system
+        self._check_state(pos, vel)
+        box = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3))
+        traj, et = self._rows(n_steps, save_every, want_energy)
+        rc = self._lib.mythos_martini_langevin_run(
+            self._h, _lib.ptr(pos), _lib.ptr(vel), box.ctypes.data_as(_lib.c_double_p), int(n_steps), int(save_every),
+            _lib.ptr(traj), _lib.ptr(et), _stream(s.device))
+        _touched(pos, vel)
+        _lib.check(rc, "martini_langevin_run")
+        return traj, et
+
+    # ---- resident form (mythos_martini_langevin_load / advance / store) -----------------------------------
+    def load(self, pos, vel, box) -> None:
+        self._check_state(pos, vel)
+        box = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(3))
+        _lib.check(self._lib.mythos_martini_langevin_load(self._h, _lib.ptr(pos), _lib.ptr(vel), box.ctypes.data_as(_lib.c_double_p),
+                                                          _stream(self.system.device)), "martini_langevin_load")
+
+    def advance(self, n_steps: int, save_every: int = 0, want_energy: bool = True):
+        """``n_steps`` on the resident state: n launches, the frame stays open; the list and its schedule carry over."""
+        traj, et = self._rows(n_steps, save_every, want_energy)
+        _lib.check(self._lib.mythos_martini_langevin_advance(self._h, int(n_steps), int(save_every), _lib.ptr(traj), _lib.ptr(et),
+                                                             _stream(self.system.device)), "martini_langevin_advance")
+        return traj, et
+
+    def store(self, pos, vel) -> None:
+        self._check_state(pos, vel)
+        rc = self._lib.mythos_martini_langevin_store(self._h, _lib.ptr(pos), _lib.ptr(vel), _stream(self.system.device))
+        _touched(pos, vel)
+        _lib.check(rc, "martini_langevin_store")
+
+    @property
+    def step(self) -> int:
+        return int(self._lib.mythos_martini_langevin_get_step(self._h))
+
+    def last_rebuilds(self) -> int:
+        r = C.c_int(0)
+        _lib.check(self._lib.mythos_martini_langevin_last_rebuilds(self._h, C.byref(r)), "last_rebuilds")
+        return int(r.value)
 
     def set_timing(self, samples: int) -> None:
         """Bracket ``samples`` dispatches per run with HIP event pairs (0 = off, the default; see last_kernel_ms)."""

@@ -41,6 +41,15 @@ def load() -> C.CDLL:
         lib.mythos_cpu_energy.argtypes = [V, _dp, _dp, _dp, _dp, _dp, _dp]
         lib.mythos_cpu_langevin_run.argtypes = [V, _dp, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double,
                                                 C.c_double, _dp, C.c_uint64, C.c_int64, C.c_double, C.c_double, C.c_int, _dp]
+        lib.mythos_cpu_martini_create.restype = V
+        lib.mythos_cpu_martini_create.argtypes = [C.c_int, _ip, C.c_int, _dp, _dp, C.c_int, _ip, _dp, _dp, C.c_int, _ip, _dp, _dp, C.c_int,
+                                                  C.c_double, _dp]
+        lib.mythos_cpu_martini_destroy.argtypes = [V]
+        lib.mythos_cpu_martini_destroy.restype = None
+        lib.mythos_cpu_martini_energy.argtypes = [V, _dp, _dp, _dp, _dp]
+        lib.mythos_cpu_martini_energy.restype = None
+        lib.mythos_cpu_martini_run.argtypes = [V, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int64,
+                                               C.c_double, C.c_int, _dp]
         _lib = lib
     return _lib
 
@@ -111,3 +120,46 @@ def threads() -> int:
 
 def set_threads(n: int) -> None:
     load().mythos_cpu_set_threads(int(n))
+
+
+class MartiniCpuPort:
+    """One MARTINI system on the host (oracle/cpu_port/martini_cpu.cpp): LJ over a Verlet list, bonds, angles, BAOAB
+    Langevin; fp64, OpenMP.  ``angle_kind`` 0 = G96 cosine (MARTINI 2), 1 = harmonic (MARTINI 3)."""
+
+    def __init__(self, types, sigma, eps, bonds, bond_k, bond_r0, angles, angle_k, angle_t0, angle_kind=0, r_cut=1.1, mass=None):
+        lib = load()
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        types, bonds, angles = i32(types), i32(bonds).reshape(-1, 2), i32(angles).reshape(-1, 3)
+        sigma, eps = f64(sigma), f64(eps)
+        self.n = int(types.shape[0])
+        mass = None if mass is None else f64(mass)
+        ip = lambda a: a.ctypes.data_as(_ip)  # noqa: E731
+        self._h = lib.mythos_cpu_martini_create(self.n, ip(types), int(sigma.shape[0]), _d(sigma), _d(eps), int(bonds.shape[0]), ip(bonds),
+                                                _d(f64(bond_k)), _d(f64(bond_r0)), int(angles.shape[0]), ip(angles), _d(f64(angle_k)),
+                                                _d(f64(angle_t0)), int(angle_kind), float(r_cut), None if mass is None else _d(mass))
+        if not self._h:
+            raise ValueError("mythos_cpu_martini_create: invalid arguments")
+        self._lib = lib
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.mythos_cpu_martini_destroy(self._h)
+            self._h = None
+
+    def energy(self, x, box):
+        """-> ([lj, bond, angle], dU/dx (n, 3))"""
+        x, box = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(box, dtype=np.float64).reshape(3)
+        e, g = np.zeros(3), np.zeros((self.n, 3))
+        self._lib.mythos_cpu_martini_energy(self._h, _d(x), _d(box), _d(e), _d(g))
+        return e, g
+
+    def run(self, x, v, box, n_steps, *, dt, kT, gamma, seed=0, step0=0, skin=0.3, rebuild_every=5):
+        """In place on contiguous float64 arrays; returns (list builds, [lj, bond, angle, kinetic] of the final state)."""
+        for a in (x, v):
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        box = np.ascontiguousarray(box, dtype=np.float64).reshape(3)
+        e = np.zeros(4)
+        builds = self._lib.mythos_cpu_martini_run(self._h, _d(x), _d(v), _d(box), int(n_steps), float(dt), float(kT), float(gamma),
+                                                  C.c_uint64(int(seed) & (2**64 - 1)), int(step0), float(skin), int(rebuild_every), _d(e))
+        return int(builds), e

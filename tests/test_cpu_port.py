@@ -252,3 +252,70 @@ def test_sanitizers_are_clean_and_agree_with_the_plain_build(tmp_path):
                 assert abs(fu - fv) <= 1e-7 * max(1.0, abs(fu)), (x, y)  # -O1 vs -O3 -mfma: contraction differs
         fs = [float(t) for t in la[1].split()[1:]]
         assert max(abs(t) for t in fs) < 1e-8  # Newton's third law
+
+
+# ---- MARTINI (oracle/cpu_port/martini_cpu.cpp): bench.py's cpu_baseline of BASELINE configs[2] ------------------
+def _martini_port(angle_kind=0, mass=None):
+    from tests import martini_helpers as MH
+
+    s = MH.system()
+    port = cpu_port.MartiniCpuPort(s["types"], s["sigma"], s["eps"], s["top"].bonded_neighbors, s["bond_k"], s["bond_r0"], s["top"].angles,
+                                   s["angle_k"], s["angle_t0"], angle_kind=angle_kind, mass=mass)
+    return port, s
+
+
+@pytest.mark.parametrize("angle_kind", [0, 1])
+def test_martini_port_energies_and_forces_match_the_oracle_and_gromacs(angle_kind):
+    """The port's LJ / bond / angle energies against the GROMACS energies the reference ships (its own tolerance, rtol
+    1e-5) and against the torch oracle's energies and autograd forces on the same frames."""
+    from oracle import martini_oracle as mo
+    from tests import martini_helpers as MH
+
+    port, s = _martini_port(angle_kind)
+    x, box, e_lj = MH.frames("lj")
+    _, _, e_b = MH.frames("bond")
+    for f in (0, 5, 9):
+        e, g = port.energy(x[f], box[f])
+        if angle_kind == 0:
+            np.testing.assert_allclose(e[:2], [e_lj[f], e_b[f]], rtol=1e-5)
+        e_o, g_o = mo.energies_and_forces(torch.as_tensor(x[f]), torch.as_tensor(box[f]), s["types"], torch.as_tensor(s["sigma"]),
+                                          torch.as_tensor(s["eps"]), s["top"].bonded_neighbors, torch.as_tensor(s["bond_k"]),
+                                          torch.as_tensor(s["bond_r0"]), s["top"].angles, torch.as_tensor(s["angle_k"]),
+                                          torch.as_tensor(s["angle_t0"]), angle_kind == 0)
+        np.testing.assert_allclose(e, e_o.numpy(), rtol=1e-10)
+        np.testing.assert_allclose(g, g_o.numpy(), rtol=0, atol=1e-9 * np.abs(g_o.numpy()).max())
+    if angle_kind == 0:
+        xa, ba, e_a = MH.frames("angle")
+        np.testing.assert_allclose(port.energy(xa[3], ba[3])[0][2], e_a[3], rtol=1e-5)
+
+
+def test_martini_port_steps_match_the_langevin_oracle():
+    """Five BAOAB steps with unequal masses against oracle/martini_langevin_oracle.py on the same Philox stream, with a
+    list rebuild in the middle; the result does not depend on the thread count."""
+    from oracle.martini_langevin_oracle import MartiniLangevinOracle
+    from tests import martini_helpers as MH
+
+    rng = np.random.default_rng(5)
+    mass = rng.uniform(40.0, 90.0, size=1280)
+    port, s = _martini_port(0, mass)
+    x, box, _ = MH.frames("lj")
+    x0, b0 = x[3].copy(), box[3].copy()
+    v0 = 0.3 * rng.standard_normal(x0.shape)
+    kT = 0.0083144626 * 273.0
+    outs = []
+    all_threads = cpu_port.threads()
+    for threads in (all_threads, 1):
+        cpu_port.set_threads(threads)
+        xp, vp = x0.copy(), v0.copy()
+        builds, e4 = port.run(xp, vp, b0, 5, dt=0.01, kT=kT, gamma=2.0, seed=0xABCDEF012345, skin=0.25, rebuild_every=2)
+        assert builds == 3
+        outs.append((xp, vp, e4))
+    cpu_port.set_threads(all_threads)
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    orc = MartiniLangevinOracle(s["types"], s["sigma"], s["eps"], s["top"].bonded_neighbors, s["bond_k"], s["bond_r0"], s["top"].angles,
+                                s["angle_k"], s["angle_t0"], True, b0, 0.01, kT, 2.0, mass, seed=0xABCDEF012345)
+    xo, vo = x0.copy(), v0.copy()
+    e_ref = orc.run(xo, vo, 5)
+    np.testing.assert_allclose(outs[0][0], xo, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(outs[0][1], vo, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(outs[0][2], e_ref[-1], rtol=1e-9, atol=1e-7)

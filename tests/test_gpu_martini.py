@@ -172,6 +172,33 @@ def test_lj_parameter_gradients_match_oracle_autograd(dtype):
     assert checked >= 20  # DMPC + water use 4 bead types: 10 unordered pairs x 2 parameters see a gradient
 
 
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_lj_parameter_gradients_are_reproducible_bit_for_bit(dtype):
+    """dU/dsigma, dU/deps come from per-wavefront LDS tables added in a fixed order and a fixed-order sum over the
+    workgroups' partial tables (no global atomics since round 4): five calls, on the fixture and on the 20 480-bead
+    tiling (720 workgroups per frame), give the same bits."""
+    from mythos_amd.hip_system import MartiniSystem
+
+    s = MH.system()
+    x, box, _ = MH.frames("lj")
+    for reps in (1, 4):
+        top = s["top"].tile(reps * reps) if reps > 1 else s["top"]
+        tile = lambda a: np.tile(a, reps * reps)  # noqa: E731
+        sysm = MartiniSystem(tile(s["types"]), s["sigma"], s["eps"], top.bonded_neighbors, tile(s["bond_k"]), tile(s["bond_r0"]),
+                             top.angles, tile(s["angle_k"]), tile(s["angle_t0"]), dtype=dtype)
+        frames = [0, 4, 9] if reps == 1 else [3]
+        xs = np.stack([np.concatenate([x[f] + np.array([i * box[f][0], j * box[f][1], 0.0]) for i in range(reps) for j in range(reps)])
+                       for f in frames])
+        bs = np.stack([box[f] * np.array([reps, reps, 1.0]) for f in frames])
+        pos = torch.as_tensor(xs, dtype=dtype, device=sysm.device)
+        bx = torch.as_tensor(bs, dtype=dtype, device=sysm.device)
+        first = sysm.param_grads(pos, bx, bonds=False, angles=False)
+        assert first["sigma"].abs().max() > 0 and torch.isfinite(first["eps"]).all()
+        for _ in range(4):
+            again = sysm.param_grads(pos, bx, bonds=False, angles=False)
+            assert torch.equal(first["sigma"], again["sigma"]) and torch.equal(first["eps"], again["eps"])
+
+
 @pytest.mark.parametrize("angle_cls", [M.Angle, M.Angle3])
 def test_bond_and_angle_parameter_gradients_match_oracle_autograd(angle_cls):
     s = MH.system()

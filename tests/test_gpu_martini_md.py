@@ -215,3 +215,94 @@ def test_rows_longer_than_the_default_stride_grow_at_the_first_build():
         mx, _ = integ.neighbor_stats()
         assert (mx > 256) == (skin == 1.0), mx
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_resident_advances_equal_one_run_bitwise(dtype):
+    """mythos_martini_langevin_load / advance / store: the list and its rebuild schedule carry over,
+    advance(n) is n launches and leaves the frame open, and whatever the sequence of calls the state handed back is the
+    one mythos_martini_langevin_run(total) hands back, bit for bit."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(dtype)
+
+    def fresh():
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=17)
+        integ.set_neighbor_policy(0.3, 7)
+        integ.set_timing(1)
+        pos = torch.as_tensor(x0, dtype=dtype, device=sysm.device).contiguous()
+        return integ, pos, integ.init_velocities()
+
+    integ, pos, vel = fresh()
+    integ.run(pos, vel, b0, 60)
+    assert integ.last_kernel_ms()["launches"] == 61 and integ.step == 60
+    want = (pos.clone(), vel.clone())
+
+    integ, pos, vel = fresh()
+    with pytest.raises(Exception, match="resident"):
+        integ.advance(1)
+    integ.load(pos, vel, b0)
+    integ.advance(17)
+    assert integ.last_kernel_ms()["launches"] == 17
+    integ.advance(0)
+    out = (torch.empty_like(pos), torch.empty_like(vel))
+    integ.store(*out)  # closes the open frame with one launch
+    assert integ.last_kernel_ms()["launches"] == 1 and integ.step == 17
+    again = (torch.empty_like(pos), torch.empty_like(vel))
+    integ.store(*again)  # already closed: a copy
+    assert torch.equal(out[0], again[0]) and torch.equal(out[1], again[1])
+    integ.advance(20)  # from a closed frame
+    _, et = integ.advance(23, save_every=23)  # from an open one; the last step saves an energy row: closed while there
+    assert integ.last_kernel_ms()["launches"] == 24 and et.shape == (1, 4)
+    integ.store(pos, vel)
+    assert integ.step == 60
+    assert torch.equal(pos, want[0]) and torch.equal(vel, want[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_positions_only_rows_equal_single_step_stores_and_the_energy_trace_route(dtype):
+    """e_trace == NULL: the launch that produces a saved state writes its row (no energy-trace instantiation, no closing
+    launch); the rows are the states store hands out after single-step advances and the rows of the energy-trace route,
+    bit for bit - through out-of-turn rebuilds as well (a thin skin, segments of five launches)."""
+    from mythos_amd import _lib
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(dtype)
+
+    def fresh(skin=0.3, every=6):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=23)
+        integ.set_neighbor_policy(skin, every)
+        integ.set_timing(1)
+        pos = torch.as_tensor(x0, dtype=dtype, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        integ.load(pos, vel, b0)
+        return integ, pos, vel
+
+    n = 20
+    integ, pos, vel = fresh()
+    traj, et = integ.advance(n, save_every=1, want_energy=False)
+    assert et is None and traj.shape == (n, sysm.n, 3) and integ.last_kernel_ms()["launches"] == n
+    integ, pos, vel = fresh()
+    for k in range(n):
+        integ.advance(1)
+        integ.store(pos, vel)
+        assert torch.equal(traj[k], pos), k
+    integ, pos, vel = fresh()
+    traj2, et2 = integ.advance(n, save_every=1)
+    assert torch.equal(traj, traj2) and torch.isfinite(et2).all()
+    integ, pos, vel = fresh()
+    traj3, _ = integ.advance(n, save_every=7, want_energy=False)  # a cadence that does not divide the call
+    assert traj3.shape[0] == 2 and torch.equal(traj3[0], traj[6]) and torch.equal(traj3[1], traj[13])
+    # through halts: no scheduled rebuild, a skin of 0.08 nm
+    integ, pos, vel = fresh(0.08, 1000)
+    _lib.debug_set("md_segment", 5)
+    try:
+        traj4, _ = integ.advance(40, save_every=1, want_energy=False)
+    finally:
+        _lib.debug_set("md_segment", 0)
+    assert integ.last_recoveries() >= 2
+    integ, pos, vel = fresh(0.08, 1000)
+    for k in range(40):
+        integ.advance(1)
+        integ.store(pos, vel)
+        assert torch.equal(traj4[k], pos), k
