@@ -11,25 +11,35 @@ A "step" is one fused force + BAOAB kernel over the whole system (mythos_amd/csr
 The timed region is one ``mythos_langevin_advance`` call of exactly K steps with the state resident in HBM
 (loaded into the integrator before the clock starts), bracketed by barrier + synchronize, MAX over ranks.
 It is measured ``--repeats`` times back to back (the trajectory continues from sample to sample; default 5, or 21
-when K < 500: a 20-step sample lasts a third of a millisecond, and on a GPU that sat idle until the clock started the
-first few samples run at clocks still coming up - 0.345 ms against 0.325 ms a few milliseconds later, measured);
-value = N_gpus * K / the MEDIAN sample, all samples are in ``config.samples_ms`` and the number of scheduled
-list rebuilds that fell inside each in ``config.scheduled_rebuilds_per_sample``.  Nothing else is inside a
-sample: the per-dispatch HIP events behind ``roofline.kernel_ms`` are taken in a second, untimed pass.  For
-N > 1 every rank steps its own replica (weak scaling; the MD data path has no collective): barrier + synchronize, the
-rank's clock around its K steps, synchronize + barrier, MAX over ranks.  With ``--save-every`` the replicas' energy
-traces are all-gathered over RCCL inside the timed region (one collective).  The headline precision is fp32 (north_star: fp32 forces at 1e-3); the same measurement in the
-reference's fp64 is ``config.f64``, ``f64_steps_per_s`` and the tail of ``config.timed_region``.
+when K < 500).  **value = N_gpus * repeats * K / the SUM of the samples**: every scheduled list rebuild that falls into
+the repeats is paid for in it (round 3 reported the median sample, which for K = 20 never contains a rebuild: ADVICE r3);
+the median rate is ``steps_per_s_median``, all samples are in ``config.samples_ms`` and the scheduled rebuilds inside
+each in ``config.scheduled_rebuilds_per_sample``.  A GPU that sat idle until the clock starts runs its first
+milliseconds at clocks still coming up; the untimed warm-up is therefore at least W steps AND at least
+``--min-warmup-ms`` of stepping (``config.warmup_steps_done``).  Nothing else is inside a sample: the per-dispatch HIP
+events behind ``roofline.kernel_ms`` are taken in a second, untimed pass.  For N > 1 every rank steps its own replica
+(weak scaling; the MD data path has no collective): barrier + synchronize, the rank's clock around its K steps,
+synchronize + barrier, MAX over ranks.  ``--save-every S`` stores positions + quaternions every S steps inside the
+timed region (the reference's run stores every step, jaxmd.py:84-99); with ``--trace-energy`` also the energies, and
+for N > 1 those are all-gathered over RCCL (one collective).  The headline precision is fp32 (north_star: fp32 forces
+at 1e-3); the same measurement in the reference's fp64 is ``f64_steps_per_s`` / ``f64_frac`` / ``f64_kernel_ms`` and
+``config.f64``.
 
 Rank 0 prints ONE JSON line with the fields of the driver contract plus
   roofline      HBM roofline of the step kernel: algorithmic bytes per launch (2 x 14 state
                 words + 13 B topology + 4 B per neighbour entry, per nucleotide) / the kernel's mean duration,
-                measured with HIP events on the launch stream inside the timed region.  ``traffic`` is the
-                PMC-measured HBM-side byte count per launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)
-                of the SAME command, read from profiles/traffic.json when that file matches the workload.
-  cpu_baseline  the C++/OpenMP port of the same kernels (oracle/cpu_port, fp64, all host cores; median of 5 x 1 000
-                steps) and, under ``torch_restatement``, the vectorised torch-fp64 oracle that stands in for JAX-CPU,
-                both on a bounded sample of the same system (N=1, rank 0 only)
+                measured with HIP events on the launch stream.  ``traffic`` is the PMC-measured HBM-side byte count per
+                launch (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction) of the SAME command, read from
+                profiles/traffic.json when that file matches the workload.
+  cpu_baseline  the C++/OpenMP port of the same kernels (oracle/cpu_port, fp64, all cores the process may use; median of
+                5 x <= 1 000 steps) and, under ``torch_restatement``, the vectorised torch-fp64 oracle that stands in for
+                JAX-CPU, both on a bounded sample of the same system (N=1, rank 0 only)
+  config.save_every_1   the same K steps with every step's positions + quaternions stored (the reference's semantics of
+                run), both precisions: steps/s, its ratio to the no-output rate, bytes written per step
+  secondary     (N = 1) the other BASELINE configs, each with its own kernel time, algorithmic bytes and HBM fraction:
+                cfg1 oxDNA2 1 kbp (fp32 steps/s + the fp64 energy check), cfg2 MARTINI 20 480 beads (with its own
+                cpu_baseline), cfg4 DiffTRe: U and dU/dtheta frames/s at 6 400 x 64 nt in both precisions and ONE
+                end-to-end iteration (64 replicas x 2 000 steps -> map -> grad -> Adam) with its host-side share
 """
 
 from __future__ import annotations
@@ -83,6 +93,10 @@ def parse_args():
                     help="the timed region (exactly --steps steps) is run this many times back to back, each bracketed by barrier + "
                          "synchronize; value = steps / the MEDIAN sample, every sample is in config.samples_ms "
                          "(default 5; 21 for timed regions under 500 steps)")
+    ap.add_argument("--min-warmup-ms", type=float, default=150.0,
+                    help="the untimed warm-up lasts at least --warmup steps and at least this long (GPU clocks ramp for the "
+                         "first milliseconds after idling)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs (cfg1 / cfg2 / cfg4) and save_every_1")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
                          "between ranks); the printed line is then marked as a rehearsal, not a measurement")
@@ -112,7 +126,8 @@ def measured_traffic(args, n: int):
 
 def host_cores() -> int:
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a GPU box hands
-    a 1-GPU job a share of a much larger host; oversubscribing it makes the baseline meaningless)."""
+    a 1-GPU job a share of a much larger host; oversubscribing it makes the baseline meaningless).  ``nproc`` in the
+    output line is os.cpu_count(), the host's total."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
@@ -120,7 +135,8 @@ def host_cores() -> int:
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("MYTHOS_BENCH_CPU_CORES", "16"))))
+    cap = os.environ.get("MYTHOS_BENCH_CPU_CORES")  # (dev: a fixed thread count for A/B runs; default = all the process may use)
+    return max(1, min(n, int(cap))) if cap else max(1, n)
 
 
 def param_gradient_error(dev) -> dict:
@@ -240,63 +256,30 @@ def cpu_baseline_openmp(top, c0, q0, sim, flat, n_steps: int = 1000, repeats: in
 
 def martini_main(args):
     """BASELINE configs[2]: the reference's shipped DMPC bilayer (tests/golden/martini) tiled 4 x 4 = 20 480 beads,
-    Langevin dt 0.02 ps, 273 K, friction 1/ps; 1 GPU.  Not the headline metric: a secondary line."""
-    from mythos_amd.hip_system import MartiniLangevinIntegrator, MartiniSystem
-    from tests import martini_helpers as MH
-
+    Langevin dt 0.02 ps, 273 K, friction 1/ps; 1 GPU.  Not the headline metric: a secondary line (the headline's
+    ``secondary.cfg2_martini`` carries the same measurement)."""
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    word = 4 if args.dtype == "f32" else 8
-    s = MH.system()
-    x, box, _ = MH.frames("lj")
-    x0, b0 = x[3].copy(), box[3].copy()
-    for i, j in s["top"].bonded_neighbors:  # whole lipids before tiling (GROMACS wraps bead by bead)
-        d = x0[j] - x0[i]
-        x0[j] = x0[i] + d - b0 * np.round(d / b0)
-    reps = 4
-    xt = np.concatenate([x0 + np.array([i * b0[0], j * b0[1], 0.0]) for i in range(reps) for j in range(reps)])
-    bt = b0 * np.array([reps, reps, 1.0])
-    top = s["top"].tile(reps * reps)
-    tile = lambda a: np.tile(a, reps * reps)  # noqa: E731
-    system = MartiniSystem(tile(s["types"]), s["sigma"], s["eps"], top.bonded_neighbors, tile(s["bond_k"]), tile(s["bond_r0"]),
-                           top.angles, tile(s["angle_k"]), tile(s["angle_t0"]), dtype=dtype, device=dev)
-    kT = 0.0083144626 * 273.0
-    integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
     # skin 0.5 nm, rebuild every 12 steps: re-scanned in round 3 (0.4 / 8: 65.9 k steps/s; 0.4 / 9 68.6 k; 0.45 / 11 69.9 k;
     # 0.5 / 12 68.8 k, all without an out-of-turn rebuild in 40 000 steps; 0.4 / 10 and 0.5 / 14 have them, 0.6 and above
     # collapse under them).  0.5 / 12 for its margin.
     skin, every = (0.5 if args.skin is None else args.skin), (12 if args.rebuild_every is None else args.rebuild_every)
-    integ.set_neighbor_policy(skin, every)
-    pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
-    vel = integ.init_velocities()
-    integ.run(pos, vel, bt, args.warmup)
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    integ.run(pos, vel, bt, args.steps)
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    integ.set_timing(16)  # untimed second pass: HIP event pairs on 16 dispatches (roofline.kernel_ms)
-    integ.run(pos, vel, bt, max(args.steps, 64))
-    timing = integ.last_kernel_ms()
-    mx, nbar = integ.neighbor_stats()
-    n = system.n
-    alg = n * (2 * 6 * word + 4 + 4.0 * nbar)
-    kms = timing["kernel_ms"]
-    assert torch.isfinite(pos).all()
+    m = measure_martini(dev, args.dtype, args.steps, args.warmup, skin, every, repeats=max(1, args.repeats if args.repeats else 3))
+    kms = m["timing"]["kernel_ms"]
+    fr = _frac(m["alg"], kms)
+    cpu = None if args.cpu_steps == 0 else martini_cpu_baseline(m["port_args"], m["xt"], m["bt"], m["kT"], 0.3, 10)
     print(json.dumps({
-        "metric": "MD steps/sec per GPU, MARTINI-2 DMPC bilayer 20 480 beads", "value": args.steps / elapsed, "unit": "steps/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "metric": "MD steps/sec per GPU, MARTINI-2 DMPC bilayer 20 480 beads", "value": m["steps_per_s"], "unit": "steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 / m["steps_per_s"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"MARTINI-2 DMPC bilayer (fixture tiled 4x4, {n} beads), LJ r_c 1.1 nm + bonds + G96 angles, dt 0.02 ps, 273 K",
-                   "thermostat": "Langevin, gamma 1/ps", "ns_per_day": args.steps / elapsed * 0.02e-3 * 86400.0,
-                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": nbar, "max_row": mx,
-                                     "out_of_turn_rebuilds": integ.last_recoveries()}},
-        "roofline": {"bound": "hbm", "achieved": alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "martini_md_step_kernel", "kernel_ms": kms, "loop_ms_per_launch": timing["loop_ms_per_launch"],
-                     "algorithmic_bytes_per_launch": alg},
-        "cpu_baseline": None,
+        "config": {"workload": f"MARTINI-2 DMPC bilayer (fixture tiled 4x4, {m['n']} beads), LJ r_c 1.1 nm + bonds + G96 angles, dt 0.02 ps, 273 K",
+                   "thermostat": "Langevin, gamma 1/ps", "ns_per_day": m["steps_per_s"] * 0.02e-3 * 86400.0, "samples_ms": m["samples_ms"],
+                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": m["mean_row"], "max_row": m["max_row"],
+                                     "out_of_turn_rebuilds": m["recoveries"]}},
+        "roofline": {"bound": "hbm", "achieved": fr["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["frac"], "traffic": None,
+                     "kernel": "martini_md_step_kernel", "kernel_ms": kms, "loop_ms_per_launch": m["timing"]["loop_ms_per_launch"],
+                     "algorithmic_bytes_per_launch": m["alg"]},
+        "cpu_baseline": cpu,
     }))
 
 
@@ -317,10 +300,12 @@ def spawn_ranks(args) -> int:
     return subprocess.run(cmd, env=env, check=False).returncode
 
 
-def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=None, md=None) -> dict:
+def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=None, md=None, positions_too: bool = False) -> dict:
     """Warm up, time ``args.steps`` steps of the resident state (barrier + synchronize on both sides, MAX over
-    ranks), then - outside the timed region - the same number of steps with 16 dispatches bracketed by HIP events
-    on the launch stream (a bracketed dispatch costs ~8 us of queue time, so it is not part of the timed run)."""
+    ranks) ``args.repeats`` times, then - outside the timed region - the same number of steps with 16 dispatches
+    bracketed by HIP events on the launch stream (a bracketed dispatch costs ~8 us of queue time, so it is not part of
+    the timed run).  ``positions_too``: afterwards the same samples once more with every step's positions + quaternions
+    stored (config.save_every_1)."""
     dtype = torch.float32 if dtype_name == "f32" else torch.float64
     kT = sim["kT"]
     system = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype, device=dev)
@@ -335,40 +320,59 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     p, L = integ.init_momenta()
     integ.load(c, q, p, L)  # inputs resident in HBM, in the integrator's layout, before the clock starts
 
-    # ---- warm-up (untimed): also thermalises the ideal helix
+    # ---- warm-up (untimed): W steps, and on until --min-warmup-ms of stepping have passed (clock ramp); it also
+    #      thermalises the ideal helix
+    t_w = time.perf_counter()
     integ.advance(args.warmup)
     torch.cuda.synchronize(dev)
+    warm_done = args.warmup
+    while (time.perf_counter() - t_w) * 1e3 < args.min_warmup_ms:
+        integ.advance(max(args.warmup, 100))
+        torch.cuda.synchronize(dev)
+        warm_done += max(args.warmup, 100)
 
-    # ---- timed region: exactly args.steps steps, measured args.repeats times back to back (the trajectory simply
-    #      continues); every sample has its own barrier + synchronize on both sides and its own MAX over ranks
     world = 1 if dist is None else dist.get_world_size()
-    samples, rebuilds, recoveries = [], [], 0
-    for _ in range(max(1, args.repeats)):
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        _, _, et = integ.advance(args.steps, save_every=args.save_every, want_energy=args.trace_energy)
-        if dist is not None and et is not None:
-            # a run that saves observables (--save-every) gathers them inside the timed region: per-replica energy trace,
-            # replica id = rank, ONE all-gather over RCCL / xGMI and no host read-back.  Without --save-every a replica
-            # produces nothing to exchange: the MD data path has no collective, and none is invented for the clock.
-            obs = et.reshape(1, -1)
-            gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs, n_total=world)
-            assert gathered.shape[0] == world
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's
-        if dist is not None:
-            dist.barrier()  # (the closing bracket; its own latency is not part of anybody's K steps)
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        samples.append(elapsed)
-        rebuilds.append(integ.last_rebuilds())
-        recoveries += integ.last_recoveries()
+
+    def timed(save_every: int, want_energy: bool):
+        """args.repeats samples of exactly args.steps steps -> (samples [s], scheduled rebuilds per sample, recoveries)"""
+        samples, rebuilds, recoveries = [], [], 0
+        for _ in range(max(1, args.repeats)):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            _, _, et = integ.advance(args.steps, save_every=save_every, want_energy=want_energy)
+            if dist is not None and et is not None:
+                # a run that saves energies (--save-every + --trace-energy) gathers them inside the timed region: per-replica
+                # trace, replica id = rank, ONE all-gather over RCCL / xGMI and no host read-back.  Otherwise a replica
+                # produces nothing to exchange: the MD data path has no collective, and none is invented for the clock.
+                obs = et.reshape(1, -1)
+                gathered = md.all_gather_observables(obs.cpu() if args.rehearse_on_one_gpu else obs, n_total=world)
+                assert gathered.shape[0] == world
+            torch.cuda.synchronize(dev)
+            elapsed = time.perf_counter() - t0  # this rank's K steps; the MAX over ranks below is the job's
+            if dist is not None:
+                dist.barrier()  # (the closing bracket; its own latency is not part of anybody's K steps)
+                t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            samples.append(elapsed)
+            rebuilds.append(integ.last_rebuilds())
+            recoveries += integ.last_recoveries()
+        return samples, rebuilds, recoveries
+
+    # ---- timed region
+    samples, rebuilds, recoveries = timed(args.save_every, args.trace_energy)
+    total = sum(samples)
     order = sorted(range(len(samples)), key=lambda k: samples[k])
-    mid = order[len(order) // 2]  # the median sample (the upper one of an even count): value, ms_per_step and its rebuild count
-    elapsed = samples[mid]
+    mid = order[len(order) // 2]  # the median sample (the upper one of an even count)
+
+    out_pos = None
+    if positions_too and world == 1:
+        ps, _, _ = timed(1, False)
+        word = 4 if dtype_name == "f32" else 8
+        out_pos = {"steps_per_s": len(ps) * args.steps / sum(ps), "vs_no_output": (len(ps) * args.steps / sum(ps)) / (len(samples) * args.steps / total),
+                   "bytes_written_per_step": 7 * word * top.n_nucleotides, "samples_ms": [1e3 * t for t in ps]}
 
     # ---- instrumented pass (untimed): duration of the step kernel from HIP events attached to sampled dispatches on
     #      the launch stream (rocprofv3's kernel trace of the same command, profiles/, is the cross-check)
@@ -382,26 +386,297 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     mx, nbar = system.neighbor_stats()
     n = top.n_nucleotides
     alg = algorithmic_bytes_per_step(n, nbar, 4 if dtype_name == "f32" else 8)
+    if args.save_every > 0:
+        alg += 7 * (4 if dtype_name == "f32" else 8) * n / args.save_every  # trajectory output adds 7 s N / save_every
     kms = timing["kernel_ms"]
     achieved = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-    return {"elapsed": elapsed, "steps_per_s": world * args.steps / elapsed, "kernel_ms": kms,
-            "loop_ms_per_launch": timing["loop_ms_per_launch"], "alg": alg, "achieved": achieved,
+    if out_pos is not None:
+        out_pos["algorithmic_bytes_per_step"] = algorithmic_bytes_per_step(n, nbar, 4 if dtype_name == "f32" else 8) + out_pos["bytes_written_per_step"]
+    return {"elapsed_mean": total / len(samples), "elapsed_median": samples[mid],
+            "steps_per_s": world * len(samples) * args.steps / total, "steps_per_s_median": world * args.steps / samples[mid],
+            "kernel_ms": kms, "loop_ms_per_launch": timing["loop_ms_per_launch"], "alg": alg, "achieved": achieved,
             "mean_row": nbar, "max_row": mx, "recoveries": recoveries, "samples_ms": [1e3 * t for t in samples],
-            "rebuilds": rebuilds, "rebuilds_in_median": rebuilds[mid]}
+            "rebuilds": rebuilds, "rebuilds_total": sum(rebuilds), "warmup_steps_done": warm_done, "save_every_1": out_pos}
 
 
 def _timed_region(args, m, m2) -> str:
-    """What the timed region held, in under 120 characters: steps, launches, list rebuilds inside the median sample,
-    and the rate at the other precision."""
+    """What the timed region held, in under 120 characters: steps, launches and list rebuilds over all repeats, and the
+    rate at the other precision."""
     # (an advance call is one force evaluation per step: the closing half kick of its last step rides on the next call's
     #  first launch - or on store's - see advance_typed in mythos_amd/csrc/langevin_core.inc)
     closes = args.trace_energy and args.save_every > 0 and args.steps % args.save_every == 0
-    txt = (f"{args.steps} steps = {args.steps + (1 if closes else 0)} launches + {m['rebuilds_in_median']} list rebuilds + 1 sync; "
-           f"median of {len(m['samples_ms'])}")
+    r = len(m["samples_ms"])
+    txt = (f"{r} x {args.steps} steps = {r * (args.steps + (1 if closes else 0))} launches + {m['rebuilds_total']} list rebuilds + {r} syncs; "
+           f"value = steps / total time")
     if m2 is not None:
         other = "f64" if args.dtype == "f32" else "f32"
-        txt += f"; {other} {m2['steps_per_s'] / 1e3:.1f}k steps/s"
+        txt += f"; {other} {m2['steps_per_s'] / 1e3:.1f}k"
     return txt
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# secondary configs (N = 1): every BASELINE config gets a driver-measured number in the same line
+# ------------------------------------------------------------------------------------------------------------------
+def _frac(alg_bytes: float, kernel_ms: float) -> dict:
+    gbs = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"kernel_ms": kernel_ms, "alg_bytes": alg_bytes, "GBs": gbs, "frac": gbs / HBM_PEAK_GBS}
+
+
+def secondary_1kbp(dev, sim, flat, steps: int = 2000) -> dict:
+    """BASELINE configs[1]: oxDNA2 1 kbp duplex with Debye-Hueckel, fp32 stepping + the fp64 energy check (energies and
+    forces of the fp32 energy kernel against the fp64 one on the thermalised state the fp32 run produced)."""
+    top, c0, q0 = generators.ideal_duplex(1000, model=2, seed=1234)
+    kT = sim["kT"]
+    n = top.n_nucleotides
+    out = {"workload": f"oxDNA2 1 kbp duplex ({n} nt), Debye-Hueckel, Langevin dt {sim['dt']}, free space, {steps} steps after 500"}
+    state = {}
+    for name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        system = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype, device=dev)
+        system.set_params(flat)
+        integ = LangevinIntegrator(system, dt=sim["dt"], kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"],
+                                   mass=sim["nucleotide_mass"], inertia=sim["moment_of_inertia"], seed=7)
+        integ.set_neighbor_policy(R_CUT, 0.9, 50)
+        c = torch.as_tensor(c0, dtype=dtype, device=dev).contiguous()
+        q = torch.as_tensor(q0, dtype=dtype, device=dev).contiguous()
+        p, L = integ.init_momenta()
+        integ.load(c, q, p, L)
+        integ.advance(500)
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            integ.advance(steps)
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        integ.set_timing(16)
+        integ.advance(512)
+        kms = integ.last_kernel_ms()["kernel_ms"]
+        integ.set_timing(0)
+        integ.store(c, q, p, L)
+        torch.cuda.synchronize(dev)
+        _, nbar = system.neighbor_stats()
+        out[name] = {"steps_per_s": 3 * steps / sum(ts), **_frac(algorithmic_bytes_per_step(n, nbar, 4 if name == "f32" else 8), kms)}
+        state[name] = (system, c, q)
+    # fp64 energy check of the fp32 path: the same (thermalised) state through both energy kernels, on the fp32 run's list
+    s32, c32, q32 = state["f32"]
+    s64 = state["f64"][0]
+    s64.build_neighbors(c32.double(), R_CUT, 0.0)
+    s32.build_neighbors(c32, R_CUT, 0.0)
+    e32, g32, _, _ = s32.energy(c32, q32, grads=True)
+    e64, g64, _, _ = s64.energy(c32.double(), q32.double(), grads=True)
+    out["f64_energy_check"] = {"rel_err_energy": float((e32.sum() - e64.sum()).abs() / e64.sum().abs()),
+                               "rel_err_force": float((g32.double() - g64).abs().max() / g64.abs().max())}
+    return out
+
+
+def martini_system(dev, dtype):
+    """The reference's shipped DMPC bilayer (tests/golden/martini) tiled 4 x 4 = 20 480 beads -> (MartiniSystem, the
+    arguments a CPU port takes, positions, box)."""
+    from mythos_amd.hip_system import MartiniSystem
+    from tests import martini_helpers as MH
+
+    s = MH.system()
+    x, box, _ = MH.frames("lj")
+    x0, b0 = x[3].copy(), box[3].copy()
+    for i, j in s["top"].bonded_neighbors:  # whole lipids before tiling (GROMACS wraps bead by bead)
+        d = x0[j] - x0[i]
+        x0[j] = x0[i] + d - b0 * np.round(d / b0)
+    reps = 4
+    xt = np.concatenate([x0 + np.array([i * b0[0], j * b0[1], 0.0]) for i in range(reps) for j in range(reps)])
+    bt = b0 * np.array([reps, reps, 1.0])
+    top = s["top"].tile(reps * reps)
+    tile = lambda a: np.tile(a, reps * reps)  # noqa: E731
+    port_args = (tile(s["types"]), s["sigma"], s["eps"], top.bonded_neighbors, tile(s["bond_k"]), tile(s["bond_r0"]), top.angles,
+                 tile(s["angle_k"]), tile(s["angle_t0"]))
+    system = MartiniSystem(*port_args, dtype=dtype, device=dev)
+    return system, port_args, xt, bt
+
+
+def martini_cpu_baseline(port_args, xt, bt, kT: float, skin: float, every: int, budget_s: float = 6.0) -> dict:
+    """The C++/OpenMP MARTINI port (oracle/cpu_port/martini_cpu.cpp, fp64) on the same 20 480 beads: a bounded sample."""
+    from oracle import cpu_port
+
+    cores = host_cores()
+    cpu_port.set_threads(cores)
+    port = cpu_port.MartiniCpuPort(*port_args)
+    x, v = xt.copy(), np.zeros_like(xt)
+    t0 = time.perf_counter()
+    port.run(x, v, bt, 10, dt=0.02, kT=kT, gamma=1.0, seed=0, skin=skin, rebuild_every=every)
+    est = (time.perf_counter() - t0) / 10
+    n_steps = int(max(20, min(500, budget_s / max(est, 1e-9))))
+    t0 = time.perf_counter()
+    port.run(x, v, bt, n_steps, dt=0.02, kT=kT, gamma=1.0, seed=0, step0=10, skin=skin, rebuild_every=every)
+    dt = time.perf_counter() - t0
+    assert np.isfinite(x).all()
+    return {"value": n_steps / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"C++/OpenMP MARTINI port (oracle/cpu_port) fp64, {n_steps} steps after 10, same {xt.shape[0]} beads, {dt:.1f} s"}
+
+
+def measure_martini(dev, dtype_name: str, steps: int, warmup: int, skin: float, every: int, repeats: int = 3):
+    """BASELINE configs[2] through the resident integrator: load, warm up, ``repeats`` x advance(steps), then an
+    instrumented pass."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    dtype = torch.float32 if dtype_name == "f32" else torch.float64
+    word = 4 if dtype_name == "f32" else 8
+    system, port_args, xt, bt = martini_system(dev, dtype)
+    kT = 0.0083144626 * 273.0
+    integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
+    integ.set_neighbor_policy(skin, every)
+    pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
+    vel = integ.init_velocities()
+    integ.load(pos, vel, bt)
+    integ.advance(warmup)
+    torch.cuda.synchronize(dev)
+    ts, rec = [], 0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        integ.advance(steps)
+        torch.cuda.synchronize(dev)
+        ts.append(time.perf_counter() - t0)
+        rec += integ.last_recoveries()
+    integ.set_timing(16)  # untimed pass: HIP event pairs on 16 dispatches
+    integ.advance(max(steps, 512))
+    timing = integ.last_kernel_ms()
+    integ.set_timing(0)
+    integ.store(pos, vel)
+    torch.cuda.synchronize(dev)
+    assert torch.isfinite(pos).all()
+    mx, nbar = integ.neighbor_stats()
+    n = system.n
+    alg = n * (2 * 6 * word + 4 + 4.0 * nbar)  # SURVEY 8d: 2 x (pos 3 + vel 3) words + type 4 B + 4 B per neighbour entry
+    return {"steps_per_s": repeats * steps / sum(ts), "samples_ms": [1e3 * t for t in ts], "n": n, "mean_row": nbar, "max_row": mx,
+            "recoveries": rec, "kT": kT, "timing": timing, "alg": alg, "port_args": port_args, "xt": xt, "bt": bt}
+
+
+def secondary_martini(dev, skin: float = 0.5, every: int = 12, steps: int = 2000) -> dict:
+    m = measure_martini(dev, "f32", steps, 300, skin, every)
+    out = {"workload": f"MARTINI-2 DMPC bilayer (fixture tiled 4x4, {m['n']} beads), LJ + bonds + G96 angles, dt 0.02 ps, 273 K, fp32",
+           "steps_per_s": m["steps_per_s"], "ns_per_day": m["steps_per_s"] * 0.02e-3 * 86400.0, "mean_row": m["mean_row"],
+           "out_of_turn_rebuilds": m["recoveries"], **_frac(m["alg"], m["timing"]["kernel_ms"]),
+           "loop_ms_per_launch": m["timing"]["loop_ms_per_launch"]}
+    out["cpu_baseline"] = martini_cpu_baseline(m["port_args"], m["xt"], m["bt"], m["kT"], 0.3, 10)
+    return out
+
+
+def secondary_difftre(dev, sim_cfg, n_frames: int = 6400) -> dict:
+    """BASELINE configs[4]: (i) U and dU/dtheta of 6 400 frames x 64 nt (32 bp, all-pairs list: 64 replicas x 100
+    snapshots) per call of the energy kernel, both precisions, kernel time from events on the call's stream;
+    (ii) ONE end-to-end DiffTRe iteration in the reference's fp64: 64 replicas x 2 000 steps in one launch per step, 100
+    stored states each -> map -> loss + gradient of a reweighted propeller twist -> Adam, with the simulator's
+    per-call host cost (run of 0 steps on the cached handles) and the host share of the whole iteration."""
+    from mythos_amd.energy import dna2
+    from mythos_amd.energy.base import Quaternion, RigidBody, space
+    from mythos_amd.observables import PropellerTwist
+    from mythos_amd.optimization import objective as O
+    from mythos_amd.optimization.optimization import Adam, apply_updates
+    from mythos_amd.simulators.hip_md import HipMDSimulator, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList
+
+    kT = sim_cfg["kT"]
+    top, c0, q0 = generators.ideal_duplex(32, model=2, seed=21)
+    n = top.n_nucleotides
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    rng = np.random.default_rng(0)
+    C = np.repeat(c0[None], n_frames, 0) + 0.02 * rng.standard_normal((n_frames, *c0.shape))
+    Q = np.repeat(q0[None], n_frames, 0) + 0.01 * rng.standard_normal((n_frames, *q0.shape))
+    Q /= np.linalg.norm(Q, axis=-1, keepdims=True)
+    out = {"workload": f"oxDNA2 32 bp ({n} nt), all-pairs list; energy calls on {n_frames} frames; iteration: 64 replicas x 2000 steps, fp64"}
+    n_params = len(_lib.param_names())
+    for name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype, device=dev)
+        s.set_params(flat)
+        s.set_neighbors(top.unbonded_neighbors)
+        _, nbar = s.neighbor_stats()
+        word = 4 if name == "f32" else 8
+        cd, qd = torch.as_tensor(C, dtype=dtype, device=dev), torch.as_tensor(Q, dtype=dtype, device=dev)
+        rec = {}
+        for key, kw, written in (("U", {}, 64.0), ("dU_dtheta", {"grads": True, "param_grads": True}, 64.0 + 7 * word * n + 8.0 * n_params)):
+            s.energy(cd, qd, **kw)
+            torch.cuda.synchronize(dev)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            t0 = time.perf_counter()
+            for a, b in ev:  # (the energy call runs on torch's current stream: these events bracket its launches)
+                a.record()
+                s.energy(cd, qd, **kw)
+                b.record()
+            torch.cuda.synchronize(dev)
+            wall = (time.perf_counter() - t0) / len(ev)
+            kms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+            alg = n_frames * ((7 * word + 13 + 4.0 * nbar) * n + written)  # SURVEY 8d: per frame, read + written
+            rec[key] = {"frames_per_s": n_frames / wall, "ms_per_call": 1e3 * wall, **_frac(alg, kms)}
+        out[name] = rec
+
+    # ---- one end-to-end iteration (fp64: the reference's precision on this path)
+    disp, shift = space.free()
+    ef = dna2.create_default_energy_fn(topology=top, displacement_fn=disp)
+    init = RigidBody(center=torch.as_tensor(c0, device=dev), orientation=Quaternion(vec=torch.as_tensor(q0, device=dev)))
+    sp = StaticSimulatorParams(seq=top.seq, mass=(1.0, (1.0, 1.0, 1.0)), gamma=(kT / 2.5, kT / 7.5), bonded_neighbors=top.bonded_neighbors,
+                               checkpoint_every=0, dt=0.005, kT=kT)
+    n_rep, steps, save_every = 64, 2000, 20
+    simr = HipMDSimulator(energy_fn=ef, simulator_params=sp, space=(disp, shift), simulator_init=nvt_langevin,
+                          neighbors=NoNeighborList(unbonded_nbrs=top.unbonded_neighbors), save_every=save_every, dtype=torch.float64,
+                          n_replicas=n_rep)
+    half = n // 2
+    ptwist = PropellerTwist(np.stack([np.arange(half), n - 1 - np.arange(half)], axis=1)[1:-1])
+    target = 21.7
+    opt = {"eps_stack_base": 1.3523, "eps_hb": 1.0678, "theta0_hb_4": float(np.pi)}
+    adam = Adam(learning_rate=1e-3)
+    adam_state = adam.init(opt)
+
+    def loss_fn(ref_states, weights, energy_fn, opt_params, observables):  # noqa: ARG001
+        mval = (weights * ptwist(ref_states).to(weights.dtype)).sum()
+        return (mval - target) ** 2, (("propeller_twist", mval.detach()), {})
+
+    def iteration(opt, adam_state, state, key):
+        t = {}
+        t0 = time.perf_counter()
+        o = simr.run(opt, state, steps, key=key)
+        torch.cuda.synchronize(dev)
+        t["md_ms"] = 1e3 * (time.perf_counter() - t0)
+        traj = o.observables[0]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref_e = ef.with_params(opt).map(traj).detach()
+        torch.cuda.synchronize(dev)
+        t["map_ms"] = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        (loss, (neff, _, _)), grads = O.compute_loss_and_grad(opt, ef, 1.0 / kT, loss_fn, traj, ref_e, [traj])
+        torch.cuda.synchronize(dev)
+        t["grad_ms"] = 1e3 * (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        upd, adam_state = adam.update({k: torch.as_tensor(v) for k, v in grads.items()}, adam_state, opt)
+        opt = {k: float(v) for k, v in apply_updates(opt, upd).items()}
+        t["adam_ms"] = 1e3 * (time.perf_counter() - t0)
+        t["total_ms"] = sum(t.values())
+        t["frames"] = int(traj.center.shape[0])
+        t["loss"], t["neff"] = float(loss), float(neff)
+        return opt, adam_state, o.state["init_state"], t
+
+    opt, adam_state, state, _ = iteration(opt, adam_state, init, 1)  # first call: handles, lists, allocator
+    opt, adam_state, state, t2 = iteration(opt, adam_state, state, 2)
+    # what a run() costs on the host once the handles exist: 0 steps
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(5):
+        simr.run(opt, state, 0, key=10 + k)
+    torch.cuda.synchronize(dev)
+    call_ms = 1e3 * (time.perf_counter() - t0) / 5
+    # GPU time of the iteration's step launches: 2 000 launches at the kernel's own duration (events on sampled dispatches)
+    system, integ, _ = next(iter(simr._resident.values()))
+    integ.set_timing(16)
+    simr.run(opt, state, 512, key=99)
+    kms = integ.last_kernel_ms()["kernel_ms"]
+    integ.set_timing(0)
+    md_gpu_ms = steps * kms
+    t2.update({"run_call_host_ms": call_ms, "md_kernel_ms": kms, "md_gpu_ms": md_gpu_ms,
+               "host_share": max(0.0, 1.0 - (md_gpu_ms + out["f64"]["U"]["kernel_ms"] * t2["frames"] / n_frames +
+                                            out["f64"]["dU_dtheta"]["kernel_ms"] * t2["frames"] / n_frames) / t2["total_ms"]),
+               "replicas": n_rep, "steps": steps, "save_every": save_every, "n_params": len(opt)})
+    out["iteration"] = t2
+    simr.release()
+    return out
 
 
 def main():
@@ -441,10 +716,12 @@ def main():
     n = top.n_nucleotides
     flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=kT, salt_conc=sim["salt_conc"], half_charged_ends=True), _lib.param_names())
 
-    m = measure(args, args.dtype, top, c0, q0, sim, flat, dev, rank, dist, md)
+    extras = world == 1 and not args.no_secondary
+    m = measure(args, args.dtype, top, c0, q0, sim, flat, dev, rank, dist, md, positions_too=extras and args.save_every == 0)
     # the reference computes in fp64 (jax_enable_x64): the same measurement at that precision goes into the same line
     other = "f64" if args.dtype == "f32" else "f32"
-    m2 = measure(args, other, top, c0, q0, sim, flat, dev, rank, dist, md) if not args.no_second_dtype else None
+    m2 = (measure(args, other, top, c0, q0, sim, flat, dev, rank, dist, md, positions_too=extras and args.save_every == 0)
+          if not args.no_second_dtype else None)
 
     if rank == 0:
         out = {
@@ -454,7 +731,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * m["elapsed"] / args.steps,
+            "ms_per_step": 1e3 * m["elapsed_mean"] / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -474,8 +751,14 @@ def main():
                 "repeats": len(m["samples_ms"]),
                 "samples_ms": m["samples_ms"],
                 "scheduled_rebuilds_per_sample": m["rebuilds"],
+                "warmup_steps_done": m["warmup_steps_done"],
+                "ms_per_step_median": 1e3 * m["elapsed_median"] / args.steps,
                 "precision": f"headline {args.dtype} (north_star: fp32 at 1e-3); the reference's fp64 is config.{other} and f64_steps_per_s",
             },
+            # value = steps_per_s_mean: all repeats over their total time, list rebuilds included; the median sample beside it
+            "steps_per_s_mean": m["steps_per_s"],
+            "steps_per_s_median": m["steps_per_s_median"],
+            "nproc": os.cpu_count(),
             "roofline": {
                 "bound": "hbm",
                 "achieved": m["achieved"],
@@ -492,11 +775,29 @@ def main():
         }
         if m2 is not None:
             out[f"{other}_steps_per_s"] = m2["steps_per_s"]  # top level too: nested objects do not survive every parser
-            out["config"][other] = {"steps_per_s": m2["steps_per_s"], "ms_per_step": 1e3 * m2["elapsed"] / args.steps,
+            out[f"{other}_frac"] = m2["achieved"] / HBM_PEAK_GBS
+            out[f"{other}_kernel_ms"] = m2["kernel_ms"]
+            out["config"][other] = {"steps_per_s": m2["steps_per_s"], "steps_per_s_median": m2["steps_per_s_median"],
+                                    "ms_per_step": 1e3 * m2["elapsed_mean"] / args.steps,
                                     "samples_ms": m2["samples_ms"], "scheduled_rebuilds_per_sample": m2["rebuilds"],
                                     "kernel_ms": m2["kernel_ms"], "loop_ms_per_launch": m2["loop_ms_per_launch"],
                                     "achieved_GBs": m2["achieved"], "frac": m2["achieved"] / HBM_PEAK_GBS,
                                     "algorithmic_bytes_per_launch": m2["alg"]}
+        if m["save_every_1"] is not None:
+            out["config"]["save_every_1"] = {args.dtype: m["save_every_1"], **({other: m2["save_every_1"]} if m2 is not None else {}),
+                                             "what": "the same K steps, every step's positions + quaternions stored (jaxmd.py:84-99)"}
+        if extras:
+            sec = {}
+            for key, fn in (("cfg1_1kbp", lambda: secondary_1kbp(dev, sim, flat)), ("cfg2_martini", lambda: secondary_martini(dev)),
+                            ("cfg4_difftre", lambda: secondary_difftre(dev, sim))):
+                t0 = time.perf_counter()
+                try:
+                    sec[key] = fn()
+                except Exception as exc:  # noqa: BLE001 - a secondary config must not take the headline line down
+                    sec[key] = {"error": f"{type(exc).__name__}: {exc}"[:118]}
+                sec[key]["wall_s"] = time.perf_counter() - t0
+                print(f"[bench] secondary {key}: {sec[key].get('wall_s', 0):.1f} s", file=sys.stderr, flush=True)
+            out["secondary"] = sec
         cpu_steps = args.cpu_steps
         if cpu_steps < 0:
             cpu_steps = 60 if n > 8000 else 400  # capped at about 20 s of host work

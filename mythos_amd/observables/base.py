@@ -100,8 +100,10 @@ def _frames(trajectory):
 # of the same shape, so "same address, same shape, same version counters" does identify the frames (an entry keyed on
 # data_ptr alone would serve the rows of a freed trajectory to the next one allocated in its place).  The library
 # writes into caller tensors through raw pointers in two places only - LangevinIntegrator.run / store - and those bump
-# the version counters (hip_system._touched).  At most four entries, i.e. at most four trajectories kept alive here;
-# clear_fused() drops them.
+# the version counters (hip_system._touched).  At most four entries, i.e. at most four trajectories kept alive here - and
+# only until the optimisation step that produced them ends: SimpleOptimizer.step and DiffTReObjective.calculate call
+# clear_fused() when they are done with the trajectory (nothing did, and a DiffTRe loop over large
+# trajectories kept four stale ones on the GPU).
 _FUSED: list = []
 _FUSED_MAX = 4
 

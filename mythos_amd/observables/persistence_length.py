@@ -23,8 +23,10 @@ def persistence_length_fit(correlations: torch.Tensor, l0_av):
     # sums over y are the only device work (differentiable with respect to the DiffTRe weights behind ``correlations``).
     # Through round 3 this was torch.linalg.lstsq on the (n_lags, 2) system: a QR solver launch chain of ~0.5 ms for a
     # two-parameter fit, on the path of every DiffTRe iteration that reweights the persistence length.
+    n = int(correlations.shape[0])
+    if n < 2:
+        raise ValueError(f"persistence_length_fit needs at least 2 lags of the axis autocorrelation to fit a line, got {n}")
     y = torch.log(correlations)
-    n = int(y.shape[0])
     d = torch.arange(n, dtype=y.dtype, device=y.device)
     sd, sdd = n * (n - 1) / 2.0, (n - 1) * n * (2 * n - 1) / 6.0
     sy, sdy = y.sum(), (d * y).sum()

@@ -279,6 +279,9 @@ class DiffTReObjective(Objective):
                                    state={"opt_steps": 0})
         (loss, (_, measured, _)), grads = compute_loss_and_grad(
             opt_params, self.energy_fn, beta.to(ref_energies.device), self.grad_or_loss_fn, ref_states, ref_energies, ordered)
+        from mythos_amd.observables.base import clear_fused
+
+        clear_fused()  # (observable rows computed beside the energy launches above: the loss has used them)
         return ObjectiveOutput(
             is_ready=True, grads=grads, observables={"loss": loss, "neff": neff, measured[0]: measured[1]},
             state={"opt_steps": opt_steps + 1, "reference_opt_params": reference_opt_params})

@@ -105,6 +105,9 @@ class SimpleOptimizer(Optimizer):
                 raise ValueError("Objective readiness check failed after simulation run.")
         opt_state = state.optimizer_state or self.optimizer.init(params)
         updates, opt_state = self.optimizer.update(out.grads, opt_state, params)
+        from mythos_amd.observables.base import clear_fused
+
+        clear_fused()  # rows remembered beside this iteration's energy launches (and the trajectories they pin) are done with
         new_state = dc.replace(state, optimizer_state=opt_state, component_state={
             **state.component_state, self.objective.name: obj_state, self.simulator.name: sim_state})
         return OptimizerOutput(grads=out.grads, opt_params=apply_updates(params, updates), state=new_state,

@@ -240,8 +240,8 @@ def test_bench_strings_fit_the_drivers_parsed_record():
     spec.loader.exec_module(bench)
     for steps, save_every, n in ((20, 0, 21), (2000, 0, 5), (100000, 1000, 5)):
         args = argparse.Namespace(steps=steps, save_every=save_every, dtype="f32", trace_energy=save_every > 0)
-        m = {"rebuilds_in_median": steps // 50, "samples_ms": [0.3] * n}
+        m = {"rebuilds_total": n * (steps // 50), "samples_ms": [0.3] * n}
         txt = bench._timed_region(args, m, {"steps_per_s": 40714.2})
-        assert len(txt) <= 120 and f"{steps} steps" in txt and "f64 40.7k" in txt and f"median of {n}" in txt
-        launches = steps + (1 if save_every and steps % save_every == 0 else 0)
-        assert f"= {launches} launches" in txt
+        assert len(txt) <= 120 and f"{n} x {steps} steps" in txt and "f64 40.7k" in txt and "steps / total time" in txt
+        launches = n * (steps + (1 if save_every and steps % save_every == 0 else 0))
+        assert f"= {launches} launches" in txt and f"+ {n * (steps // 50)} list rebuilds" in txt

@@ -169,8 +169,19 @@ def test_gradient_with_respect_to_the_distribution(model):
         assert (a.cpu().double() - b).abs().max().item() <= 2e-3 * b.abs().max().item()
 
 
+@pytest.fixture(params=["short", "wide"])
+def work_lists(request):
+    """The PSEQ step kernels exist with both work-list widths since round 4 (ITEMS = 16, and 32 / 22 after an aborted
+    launch); "wide" starts a run on the wide ones through mythos_debug_set."""
+    from mythos_amd import _lib
+
+    _lib.debug_set("md_items_big", 1 if request.param == "wide" else 0)
+    yield request.param
+    _lib.debug_set("md_items_big", 0)
+
+
 @pytest.mark.parametrize(("model", "save_every"), [(1, 1), (2, 1), (2, 0)])
-def test_langevin_steps_with_a_soft_distribution_match_the_oracle(model, save_every):
+def test_langevin_steps_with_a_soft_distribution_match_the_oracle(model, save_every, work_lists):
     """A probabilistic sequence inside the dynamics (the reference's stacking / hydrogen-bonding configurations
     carry pseq into whatever energy function a simulator steps with, dna1/stacking.py:261-285, hydrogen_bonding.py:310-331):
     md_step_kernel's PSEQ instantiation, six fp64 steps on dna1/helix-4bp with a soft distribution - three constrained

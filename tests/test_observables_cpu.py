@@ -7,6 +7,7 @@ import dataclasses as dc
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from mythos_amd.energy.base import Quaternion, space
@@ -169,3 +170,15 @@ def test_oracle_reproduces_the_references_own_known_answers():
     pt = PropellerTwist(torch.as_tensor(H.PROPELLER_CALL["pairs"]))(
         _known_answer_traj([[0.0, 0, 0]] * 4, H.PROPELLER_CALL["quats"], H.PROPELLER_CALL["frames"]))
     np.testing.assert_allclose(pt.numpy(), [H.PROPELLER_CALL["expected"]] * H.PROPELLER_CALL["frames"], rtol=1e-7)
+
+
+def test_persistence_length_fit_needs_two_lags():
+    """(the closed-form line fit divides by n sum d^2 - (sum d)^2, zero for fewer than two lags)"""
+    import torch
+
+    from mythos_amd.observables.persistence_length import persistence_length_fit
+
+    with pytest.raises(ValueError, match="at least 2 lags"):
+        persistence_length_fit(torch.tensor([0.9]), 0.4)
+    lp, off = persistence_length_fit(torch.exp(-0.4 * torch.arange(6, dtype=torch.float64) / 120.0), 0.4)
+    assert abs(float(lp) - 120.0) < 1e-9 and abs(float(off)) < 1e-12
