@@ -96,6 +96,8 @@ def parse_args():
     ap.add_argument("--min-warmup-ms", type=float, default=150.0,
                     help="the untimed warm-up lasts at least --warmup steps and at least this long (GPU clocks ramp for the "
                          "first milliseconds after idling)")
+    ap.add_argument("--debug-set", action="append", default=[], metavar="KEY=VALUE",
+                    help="dev A/B: mythos_debug_set switches (mythos_amd._lib.DEBUG_KEYS), e.g. mm_subcells=1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs (cfg1 / cfg2 / cfg4) and save_every_1")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development aid: all ranks share cuda:0 and meet over gloo (a 1-GPU box cannot run RCCL "
@@ -112,14 +114,15 @@ def algorithmic_bytes_per_step(n: int, nbar: float, word: int) -> float:
     return n * (2 * 14 * word + 13 + 4.0 * nbar)
 
 
-def measured_traffic(args, n: int):
+def measured_traffic(dtype_name: str, n: int):
     """HBM-side bytes per md_step_kernel launch from the committed PMC passes of this command
-    (profiles/traffic.json, written by scripts/collect_traffic.py), or None if it is for another workload."""
-    f = ROOT / "profiles" / "traffic.json"
+    (profiles/traffic.json for fp32, profiles/traffic_f64.json for fp64, written by scripts/collect_traffic.py), or None
+    if there is none for this workload."""
+    f = ROOT / "profiles" / ("traffic.json" if dtype_name == "f32" else "traffic_f64.json")
     if not f.exists():
         return None
     t = json.loads(f.read_text())
-    if t.get("n_nucleotides") != n or t.get("dtype") != args.dtype:
+    if t.get("n_nucleotides") != n or t.get("dtype") != dtype_name:
         return None
     return t["hbm_bytes_per_launch"]
 
@@ -681,6 +684,9 @@ def secondary_difftre(dev, sim_cfg, n_frames: int = 6400) -> dict:
 
 def main():
     args = parse_args()
+    for kv in args.debug_set:
+        key, _, val = kv.partition("=")
+        _lib.debug_set(key, int(val))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(args))  # no GPU call has been made in this process
@@ -765,7 +771,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": m["achieved"] / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args, n),
+                "traffic": measured_traffic(args.dtype, n) if args.save_every == 0 else None,
                 "traffic_source": "profiles/traffic.json: PMC passes of this command (rocprofv3), not measured inside this run",
                 "kernel": "md_step_kernel",
                 "kernel_ms": m["kernel_ms"],
@@ -782,7 +788,8 @@ def main():
                                     "samples_ms": m2["samples_ms"], "scheduled_rebuilds_per_sample": m2["rebuilds"],
                                     "kernel_ms": m2["kernel_ms"], "loop_ms_per_launch": m2["loop_ms_per_launch"],
                                     "achieved_GBs": m2["achieved"], "frac": m2["achieved"] / HBM_PEAK_GBS,
-                                    "algorithmic_bytes_per_launch": m2["alg"]}
+                                    "algorithmic_bytes_per_launch": m2["alg"],
+                                    "traffic": measured_traffic(other, n) if args.save_every == 0 else None}
         if m["save_every_1"] is not None:
             out["config"]["save_every_1"] = {args.dtype: m["save_every_1"], **({other: m2["save_every_1"]} if m2 is not None else {}),
                                              "what": "the same K steps, every step's positions + quaternions stored (jaxmd.py:84-99)"}

@@ -307,11 +307,9 @@ enum mythos_debug_key {
                                        overflow although its rows fit (one shot: cleared when it fires) */
   MYTHOS_DEBUG_MD_DENSE = 4,        /* 1: every fp32 oxDNA1/2 stepping launch takes the DENSE instantiation (normally
                                        grids of more than four workgroups per CU), 2: none does */
-  MYTHOS_DEBUG_MM_SUBCELLS = 5,     /* 1: the MARTINI row builder uses the classic 27-cell grid (normally cells of half the list
-                                       range, 125 around a bead, wherever the box holds five per edge) */
-  MYTHOS_DEBUG_MD_ITEMS_BIG = 6,    /* 1: oxDNA step launches start on the wide work lists (ITEMS = 32) instead of reaching them
+  MYTHOS_DEBUG_MD_ITEMS_BIG = 5,    /* 1: oxDNA step launches start on the wide work lists (ITEMS = 32) instead of reaching them
                                        through an aborted launch */
-  MYTHOS_DEBUG_KEYS = 7
+  MYTHOS_DEBUG_KEYS = 6
 };
 int mythos_debug_set(int key, int64_t value);
 int64_t mythos_debug_get(int key);

@@ -394,13 +394,13 @@ __device__ __forceinline__ bool mm_excluded(const int* __restrict__ ex, int j) {
 #endif
 constexpr int kMmRowG = MYTHOS_MM_ROW_G;
 
-// SUB: cells per list range along an edge.  SUB = 1 is the classic grid - cells of the full range, 27 of them around a
-// bead: their volume is 27 rl^3 against the 4.2 rl^3 of the sphere, so 85 % of the candidates are swept for nothing, and
-// the kernel is bound by the instructions of its sweeps.  SUB = 2 (round 4): cells of half the range, the 5 x 5 x 5 block
-// around a bead, and every cell whose nearest point is farther than the range is dropped before the sweep (its count is
-// set to zero): ~84 cells = 10.5 rl^3 survive on average, 2.6 times fewer candidates.  The price is 125 table look-ups per
-// bead instead of 27 (eight per lane) and a cross-lane scan of their counts.
-template <typename R, int G, int SUB>
+// (Round 4 tried cells of HALF the list range again - 125 around a bead, those whose nearest point lies beyond the range
+// dropped before the sweep: 2.6 times fewer candidates, and 41.9 us against 36.1 us for this kernel at 20 480 beads
+// (rocprofv3, scripts/exp_martini_r04.sh; the loop 66.0 k against 68.6 k steps/s).  A sweep of 16 candidates then spans
+// four or five cells and every lane walks the prefix table through them - five dependent LDS reads per sweep where the
+// 27-cell grid needs one every other sweep - and 125 table look-ups per bead replace 27.  The kernel is not bound by its
+// candidate count alone; the variant is not in the source.)
+template <typename R, int G>
 __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int n, const typename Real4<R>::type* __restrict__ pos, const MmConst<R> K, const CellGrid<R> g, R rl2,
     const int* __restrict__ excl, const int* __restrict__ cell_cnt,
@@ -408,9 +408,7 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     int* __restrict__ rows, int* __restrict__ row_len, int row_stride, int* __restrict__ overflow,
     typename Real4<R>::type* __restrict__ ref_pos) {
   constexpr int NG = 256 / G;  // beads per workgroup
-  constexpr int W = 2 * SUB + 1, NC = W * W * W;  // cells around a bead; entry NC is the spill list
-  constexpr int PER = (NC + 1 + G - 1) / G;       // table entries per lane
-  __shared__ int s_pre[NG][NC + 2], s_st[NG][NC + 1];
+  __shared__ int s_pre[NG][29], s_st[NG][28], s_c[NG][28][3];
   const int grp = threadIdx.x / G, l = threadIdx.x % G;
   const int gshift = (threadIdx.x & 63) & ~(G - 1);  // first lane of this group inside its wavefront
   const int i = blockIdx.x * NG + grp;
@@ -418,64 +416,34 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
   const auto pi = pos[i];
   int cx, cy, cz;
   cell_of(g, pi.x, pi.y, pi.z, cx, cy, cz);
-  // position of the bead inside its cell, in cell units, and the cell edges: what the distance to a neighbouring cell needs
-  R u[3], cs[3];
-  {
-    const R p3[3] = {pi.x, pi.y, pi.z};
-    const int c3[3] = {cx, cy, cz};
+  for (int k = l; k < 28; k += G) {
+    int cnt;
+    if (k < 27) {
+      int c[3] = {cx + k % 3 - 1, cy + (k / 3) % 3 - 1, cz + k / 9 - 1};
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      R f = p3[a] * g.ibox[a];
-      f -= floor(f);
-      u[a] = fmin(fmax(f * R(g.nc[a]) - R(c3[a]), R(0)), R(1));
-      cs[a] = R(1) / (g.ibox[a] * R(g.nc[a]));
-    }
-  }
-  // lane l looks up the entries [l * PER, (l + 1) * PER): consecutive, so their running sum is a lane-local prefix plus
-  // one scan over the group
-  int cnt_l[PER];
-  int run = 0;
-#pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int k = l * PER + t;
-    int cnt = 0;
-    if (k < NC) {
-      const int d[3] = {k % W - SUB, (k / W) % W - SUB, k / (W * W) - SUB};
-      int c[3] = {cx + d[0], cy + d[1], cz + d[2]};
-      R gap2 = R(0);
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        c[a] = (c[a] + g.nc[a]) % g.nc[a];
-        // nearest point of the cell along this axis: |d| - 1 whole cells plus what is left of the bead's own cell
-        const R gap = d[a] > 0 ? (R(d[a]) - u[a]) * cs[a] : (d[a] < 0 ? (u[a] + R(-d[a] - 1)) * cs[a] : R(0));
-        gap2 += gap * gap;
-      }
+      for (int a = 0; a < 3; ++a) c[a] = (c[a] + g.nc[a]) % g.nc[a];
       const int h = cell_slot(g, c[0], c[1], c[2]);
+      cnt = min(cell_cnt[h], cell_cap);
       s_st[grp][k] = h * cell_cap;
-      cnt = gap2 < rl2 ? min(cell_cnt[h], cell_cap) : 0;
-    } else if (k == NC) {  // the spill list: particles whose bucket was full, candidates for every row
+      s_c[grp][k][0] = c[0], s_c[grp][k][1] = c[1], s_c[grp][k][2] = c[2];
+    } else {  // the spill list: particles whose bucket was full, candidates for every row
       cnt = min(cell_cnt[cell_H], kCellSpill);
     }
-    cnt_l[t] = cnt;
-    run += cnt;
-  }
-  int incl = run;  // inclusive scan of the lanes' sums over the group
-#pragma unroll
-  for (int o = 1; o < G; o <<= 1) {
-    const int v = __shfl_up(incl, o, G);
-    if (l >= o) incl += v;
-  }
-  int at = incl - run;
-#pragma unroll
-  for (int t = 0; t < PER; ++t) {
-    const int k = l * PER + t;
-    if (k <= NC) s_pre[grp][k] = at;
-    at += cnt_l[t];
-    if (k == NC) s_pre[grp][NC + 1] = at;
+    s_pre[grp][k + 1] = cnt;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  const int total = s_pre[grp][NC + 1];
+  if (l == 0) {
+    int run = 0;
+    s_pre[grp][0] = 0;
+    for (int k = 1; k <= 28; ++k) {
+      run += s_pre[grp][k];
+      s_pre[grp][k] = run;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  const int total = s_pre[grp][28];
   int ex[kMaxExcl];
 #pragma unroll
   for (int q = 0; q < kMaxExcl; ++q) ex[q] = excl[(size_t)i * kMaxExcl + q];
@@ -491,10 +459,12 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
   int out = 0;
   int lo = 0;  // cell of this lane's candidate: only ever advances, t grows by G per sweep
   // The sweep body is written without nested branches (clamped reads, predicates folded into `hit`): as nested ifs it
-  // compiled to a dozen exec-mask branches per sweep, and the kernel is bound by the instructions of its wave-sweeps, not
-  // by their memory traffic.
-  const int n_direct = s_pre[grp][NC];  // candidates that come from buckets; the rest is the spill list
-  // kSweeps sweeps per iteration: their (clamped, unconditional) reads are issued together and waited for once.
+  // compiled to a dozen exec-mask branches per sweep, and the kernel is bound by the instructions of its ~164 k
+  // wave-sweeps (10.5 M candidates / 64), not by their memory traffic.
+  const int n_direct = s_pre[grp][27];  // candidates that come from buckets; the rest is the spill list
+  // kSweeps sweeps per iteration: their (clamped, unconditional) reads are issued together and waited for once.  With
+  // four beads per wavefront a dense cell is ~47 sweeps of 16 for its group, and a group's chain of sweeps - each a
+  // table look-up and a read away from its test - is what the kernel's duration follows.
 #ifndef MYTHOS_MM_SWEEPS
 #define MYTHOS_MM_SWEEPS 4
 #endif
@@ -503,37 +473,35 @@ __global__ __launch_bounds__(256) void mm_build_rows_cells_kernel(
     typename CellPlace<R>::type pj[kSweeps];
     int cell[kSweeps], tcs[kSweeps];
 #pragma unroll
-    for (int q = 0; q < kSweeps; ++q) {
-      const int t = t0 + q * G + l;
+    for (int u = 0; u < kSweeps; ++u) {
+      const int t = t0 + u * G + l;
       const int tc = t < total ? t : total - 1;
       while (s_pre[grp][lo + 1] <= tc) ++lo;
-      cell[q] = lo;
-      tcs[q] = tc;
+      cell[u] = lo;
+      tcs[u] = tc;
       // position and index of the candidate arrive together, a contiguous stream per cell
-      pj[q] = place[tc < n_direct ? s_st[grp][lo] + (tc - s_pre[grp][lo]) : 0];
+      pj[u] = place[tc < n_direct ? s_st[grp][lo] + (tc - s_pre[grp][lo]) : 0];
     }
 #pragma unroll
-    for (int q = 0; q < kSweeps; ++q) {
-      const int t = t0 + q * G + l;
+    for (int u = 0; u < kSweeps; ++u) {
+      const int t = t0 + u * G + l;
       const bool live = t < total;
-      const bool from_bucket = tcs[q] < n_direct;
-      int j = cell_index_of(pj[q].w);
+      const bool from_bucket = tcs[u] < n_direct;
+      int j = cell_index_of(pj[u].w);
       if (!from_bucket) {  // spill list (rare): index, then a gather
-        j = spill[tcs[q] - n_direct];
-        const auto qq = pos[j];
-        pj[q].x = qq.x, pj[q].y = qq.y, pj[q].z = qq.z;
+        j = spill[tcs[u] - n_direct];
+        const auto q = pos[j];
+        pj[u].x = q.x, pj[u].y = q.y, pj[u].z = q.z;
       }
       bool keep = live & (j != i);
       if (j >= ex_lo && j <= ex_hi) keep = keep & !mm_excluded<R>(ex, j);  // one or two sweeps of a row
       if (!g.direct) {  // hashed table: a bucket may mix cells that collide, a candidate counts only for the cell it lies in
         int jx, jy, jz;
-        cell_of(g, pj[q].x, pj[q].y, pj[q].z, jx, jy, jz);
-        const int k = cell[q];
-        const int wx = (cx + k % W - SUB + g.nc[0]) % g.nc[0], wy = (cy + (k / W) % W - SUB + g.nc[1]) % g.nc[1],
-                  wz = (cz + k / (W * W) - SUB + g.nc[2]) % g.nc[2];
-        keep = keep & (!from_bucket | (jx == wx & jy == wy & jz == wz));
+        cell_of(g, pj[u].x, pj[u].y, pj[u].z, jx, jy, jz);
+        const int c = cell[u];
+        keep = keep & (!from_bucket | (jx == s_c[grp][c][0] & jy == s_c[grp][c][1] & jz == s_c[grp][c][2]));
       }
-      const R dx = wrap(pj[q].x - pi.x, K.lx, K.ilx), dy = wrap(pj[q].y - pi.y, K.ly, K.ily), dz = wrap(pj[q].z - pi.z, K.lz, K.ilz);
+      const R dx = wrap(pj[u].x - pi.x, K.lx, K.ilx), dy = wrap(pj[u].y - pi.y, K.ly, K.ily), dz = wrap(pj[u].z - pi.z, K.lz, K.ilz);
       const bool hit = keep & (dx * dx + dy * dy + dz * dz < rl2);
       const unsigned int m = (unsigned int)(__ballot(hit) >> gshift) & kGroupMask;
       const int slot = out + __popc(m & below);
@@ -605,7 +573,7 @@ struct mythos_martini_sim {
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
-  int cell_H = 0, cell_alloc_bucket_cap = 0, cell_bucket_cap = 64, cell_phase = 0, cell_sub = 1;
+  int cell_H = 0, cell_alloc_bucket_cap = 0, cell_bucket_cap = 64, cell_phase = 0;
   int row_stride = 256;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -645,14 +613,9 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
   const double rl = m->r_cut + sim->skin;
   CellGrid<R> g;
   bool cells_ok = n >= 512;
-  // cells of half the list range where every box edge holds at least five of them (see mm_build_rows_cells_kernel)
-  const long long dbg_sub = debug_value(MYTHOS_DEBUG_MM_SUBCELLS);  // (tests: 1 forces the classic 27-cell grid)
-  int sub = dbg_sub == 1 ? 1 : 2;
-  for (int k = 0; k < 3; ++k)
-    if ((int)std::floor(box[k] / (rl / 2)) < 5) sub = 1;
   for (int k = 0; k < 3; ++k) {
-    const int nc = (int)std::floor(box[k] / (rl / sub));
-    if (nc < 2 * sub + 1) cells_ok = false;
+    const int nc = (int)std::floor(box[k] / rl);
+    if (nc < 3) cells_ok = false;
     g.nc[k] = std::max(nc, 1);
     g.ibox[k] = R(1.0 / box[k]);
     g.inv[k] = R(g.nc[k] / box[k]);
@@ -667,8 +630,6 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
     g.direct = n_cells <= 8LL * n ? 1 : 0;
     const int H = g.direct ? (int)n_cells : next_pow2(2 * n);
     if (cell_cap_override()) sim->cell_bucket_cap = cell_cap_override();
-    // (sub-cells hold an eighth of the beads: start their buckets at 16 places; growth is by demand, build_until_fit)
-    if (sub != sim->cell_sub) sim->cell_bucket_cap = cell_cap_override() ? cell_cap_override() : (sub == 2 ? 16 : 64), sim->cell_sub = sub;
     const int cap = sim->cell_bucket_cap;
     const size_t need = CellBins::ints(H, cap, sizeof(R));
     if (need > sim->cell_cap || H != sim->cell_H || cap != sim->cell_alloc_bucket_cap) {
@@ -687,15 +648,8 @@ static int mm_rebuild(mythos_martini_sim* sim, const typename Real4<R>::type* po
     // buckets sorted by bead index: the row builder copies candidates in bucket order, and rows must not depend on
     // the order in which the binning atomics landed
     cell_bins_build<R, true>(n, reinterpret_cast<const R*>(pos), g, bins, sim->d_overflow, true, st);
-#define MM_BUILD_ARGS                                                                                                          \
-  dim3((n + 256 / kMmRowG - 1) / (256 / kMmRowG)), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl, bins.cnt_cur,           \
-      (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sim->d_rows, sim->d_row_len, sim->row_stride, \
-      sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos
-    if (sub == 2)
-      hipLaunchKernelGGL((mm_build_rows_cells_kernel<R, kMmRowG, 2>), MM_BUILD_ARGS);
-    else
-      hipLaunchKernelGGL((mm_build_rows_cells_kernel<R, kMmRowG, 1>), MM_BUILD_ARGS);
-#undef MM_BUILD_ARGS
+hipLaunchKernelGGL((mm_build_rows_cells_kernel<R, kMmRowG>), dim3((n + 256 / kMmRowG - 1) / (256 / kMmRowG)), dim3(256), 0, st, n, pos, K, g, R(rl * rl), m->d_excl,
+                       bins.cnt_cur, (const typename CellPlace<R>::type*)bins.place, bins.cap, bins.spill, bins.H, sim->d_rows, sim->d_row_len, sim->row_stride, sim->d_overflow, (typename Real4<R>::type*)sim->ref_pos);
   }
   return 0;
 }

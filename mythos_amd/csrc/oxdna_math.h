@@ -172,9 +172,6 @@ struct NoPG {
 // acos(clamp(c)) with d(theta)/dc; the clamp has zero slope where it clips (math.py:78-81)
 template <typename R>
 __device__ __forceinline__ FD<R> acos_clamped(R c) {
-#ifdef MYTHOS_MD_EXP_MESH_BOUND  // (round 4 bound, WRONG PHYSICS: what a perfect f4(acos(c)) mesh could leave - two multiply-adds)
-  if constexpr (kLeanMath<R>) return FD<R>{R(1.5707963) - c * (R(1) + R(0.17) * c * c), R(-1) - R(0.5) * c * c};
-#endif
   const bool clipped = (c >= R(1)) || (c <= R(-1));
   const R cc = c >= R(1) ? R(1) : (c <= R(-1) ? R(-1) : c);
   FD<R> o;

@@ -57,10 +57,28 @@ class BaseConfiguration:
     def _field_order(cls) -> tuple:
         return (*cls.required_params, *cls.optional_params, *cls.dependent_params, *cls.hidden_dependent_params)
 
+    # ---- dependent parameters on demand -----------------------------------------------------------
+    # ``init_params`` marks the record; the derivation runs when a dependent value is first read (``cfg["b_low_stack"]``,
+    # ``to_dictionary(include_dependent=True)``, ``items()``, pickling, printing).  The kernels never read them - the flat
+    # parameter vector is derived from the required values in one pass (energy/flat_params.py) - and eagerly deriving
+    # them cost a composed function's ``with_params`` eight full derivations, 7.8 ms per call: more than the 6 400-frame
+    # energy launch it precedes in a DiffTRe iteration (round 4, scripts/prof_host_r04.py).
+    def _materialise(self) -> None:
+        d = object.__getattribute__(self, "__dict__")
+        if d.get("_lazy"):
+            d["_lazy"] = False
+            d["_values"].update(type(self)._derive(self))
+
+    def _is_dependent(self, name: str) -> bool:
+        cls = type(self)
+        return name in cls.dependent_params or name in cls.hidden_dependent_params
+
     # ---- mapping-ish access ---------------------------------------------------------------------
     def __getattr__(self, name: str):
         vals = object.__getattribute__(self, "_values")
         if name in vals:
+            if self._is_dependent(name):
+                self._materialise()
             return vals[name]
         raise AttributeError(name)
 
@@ -71,22 +89,29 @@ class BaseConfiguration:
         return name in self._values or name in _META
 
     def __getitem__(self, name: str):
-        return self._values[name] if name in self._values else getattr(self, name)
+        if name in self._values:
+            if self._is_dependent(name):
+                self._materialise()
+            return self._values[name]
+        return getattr(self, name)
 
     def keys(self):
         return list(self._values.keys())
 
     def items(self):
+        self._materialise()
         return list(self._values.items())
 
     def __iter__(self):
         return iter(self._values)
 
     def __repr__(self) -> str:
+        self._materialise()
         body = ", ".join(f"{k}={v!r}" for k, v in self._values.items() if v is not None)
         return f"{type(self).__name__}({body})"
 
     def __getstate__(self):
+        self._materialise()
         return {
             "values": self._values,
             "opt": self.params_to_optimize,
@@ -103,11 +128,14 @@ class BaseConfiguration:
         meta = {k: changes.pop(k) for k in list(changes) if k in ("params_to_optimize", "non_optimizable_required_params")}
         vals = dict(self._values)
         vals.update(changes)
-        return type(self)(
+        new = type(self)(
             params_to_optimize=meta.get("params_to_optimize", self.params_to_optimize),
             non_optimizable_required_params=meta.get("non_optimizable_required_params", self.non_optimizable_required_params),
             **vals,
         )
+        if self.__dict__.get("_lazy"):  # dependents still owed: the copy derives them (from ITS values) when asked
+            object.__setattr__(new, "_lazy", True)
+        return new
 
     @property
     def opt_params(self) -> dict:
@@ -127,7 +155,9 @@ class BaseConfiguration:
             if type(self).dependent_params:
                 warnings.warn(WARN_INIT_PARAMS_NOT_IMPLEMENTED, stacklevel=1)
             return self
-        return self.replace(**derive(self))
+        new = self.replace()
+        object.__setattr__(new, "_lazy", True)  # derived at the first read of a dependent value (_materialise)
+        return new
 
     @classmethod
     def from_dict(cls, params: dict, params_to_optimize: tuple = ()) -> "BaseConfiguration":
@@ -136,6 +166,7 @@ class BaseConfiguration:
     def to_dictionary(self, *, include_dependent: bool, exclude_non_optimizable: bool) -> dict:
         params = {k: self._values[k] for k in self.required_params}
         if include_dependent:
+            self._materialise()
             for k in self.dependent_params:
                 if self._values.get(k) is not None:
                     params[k] = self._values[k]

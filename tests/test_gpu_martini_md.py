@@ -306,28 +306,3 @@ def test_positions_only_rows_equal_single_step_stores_and_the_energy_trace_route
         integ.advance(1)
         integ.store(pos, vel)
         assert torch.equal(traj4[k], pos), k
-
-
-@pytest.mark.parametrize("reps", [1, 4])
-def test_subcell_rows_hold_the_same_neighbours_as_the_classic_grid(reps):
-    """The row builder sweeps cells of half the list range (125 around a bead, those beyond the range dropped) wherever
-    the box holds five per edge; mythos_debug_set forces the classic 27 cells of the full range.  Same neighbours (row
-    lengths bead by bead are what the statistics see; the trajectory, fp64, agrees to summation order)."""
-    from mythos_amd import _lib
-    from mythos_amd.hip_system import MartiniLangevinIntegrator
-
-    sysm, *_rest, x0, b0 = _make(torch.float64, reps=reps)
-    outs = []
-    try:
-        for mode in (1, 0):
-            _lib.debug_set("mm_subcells", mode)
-            integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=31)
-            integ.set_neighbor_policy(0.5, 6)
-            pos = torch.as_tensor(x0, dtype=torch.float64, device=sysm.device).contiguous()
-            vel = integ.init_velocities()
-            integ.run(pos, vel, b0, 20)
-            outs.append((pos.clone(), integ.neighbor_stats(), integ.last_recoveries()))
-    finally:
-        _lib.debug_set("mm_subcells", 0)
-    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2] == 0, (outs[0][1], outs[1][1])
-    torch.testing.assert_close(outs[0][0], outs[1][0], rtol=1e-9, atol=1e-9)
