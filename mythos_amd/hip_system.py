@@ -303,18 +303,27 @@ class LangevinIntegrator:
         """Copy a state into the integrator (mythos_langevin_load); ``advance`` then steps it in place."""
         _lib.check(self._lib.mythos_langevin_load(self._h, *self._state_ptrs(center, quat, p_lin, p_ang), _stream(self.system.device)), "langevin_load")
 
-    def advance(self, n_steps: int, save_every: int = 0, want_energy: bool = True):
+    def advance(self, n_steps: int, save_every: int = 0, want_energy: bool = True, out=None):
         """``n_steps`` on the resident state; the neighbour list and its rebuild schedule carry over between calls.
-        Returns (traj_center, traj_quat, e_trace) or Nones when save_every == 0."""
+        Returns (traj_center, traj_quat, e_trace) or Nones when save_every == 0.  ``out = (traj_center, traj_quat)``:
+        rows written into the caller's tensors ((n_steps // save_every, n, 3 | 4), contiguous) instead of new ones."""
         s = self.system
         n_save = n_steps // save_every if save_every > 0 else 0
-        tc = torch.empty((n_save, s.n, 3), dtype=s.dtype, device=s.device) if n_save else None
-        tq = torch.empty((n_save, s.n, 4), dtype=s.dtype, device=s.device) if n_save else None
+        if out is not None and n_save:
+            tc, tq = out
+            for t, w in ((tc, 3), (tq, 4)):
+                if t.device != s.device or t.dtype != s.dtype or tuple(t.shape) != (n_save, s.n, w) or not t.is_contiguous():
+                    raise ValueError(f"out tensors must be contiguous {s.dtype} of shape ({n_save}, {s.n}, 3) and ({n_save}, {s.n}, 4) on {s.device}")
+        else:
+            tc = torch.empty((n_save, s.n, 3), dtype=s.dtype, device=s.device) if n_save else None
+            tq = torch.empty((n_save, s.n, 4), dtype=s.dtype, device=s.device) if n_save else None
         et = torch.zeros((n_save, TRACE_WIDTH), dtype=torch.float64, device=s.device) if (n_save and want_energy) else None
         _lib.check(
             self._lib.mythos_langevin_advance(self._h, int(n_steps), int(save_every), _lib.ptr(tc), _lib.ptr(tq), _lib.ptr(et), _stream(s.device)),
             "langevin_advance",
         )
+        if out is not None and n_save:
+            _touched(tc, tq)
         return tc, tq, et
 
     def store(self, center, quat, p_lin, p_ang) -> None:

@@ -205,3 +205,38 @@ def test_cfg4_12kbp_md_is_reproducible_and_splittable():
     # 1/gamma is 5 000 steps): kinetic temperature a little below kT, never above
     ke = a[3][-1, 8:].sum().item()
     assert 0.8 < ke / (3.0 * top.n_nucleotides * kT) < 1.02
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+@pytest.mark.parametrize("bp", [32, 1000])
+def test_the_three_modes_of_the_energy_kernel_agree_on_the_energies(bp, dtype):
+    """MODE 0 (energies), 1 (+ forces), 2 (+ dU/dtheta) are three instantiations with three register allocations; their
+    term energies must agree (fp64: to the rounding of differently ordered sums; since round 4 the gradient modes of the
+    fp64 kernel park their radial sums in LDS) and a repeated call must return the same bits.  Round 4 shipped, for an
+    hour, a forces-mode configuration whose energies were wrong and changed from run to run while every other test was
+    green: this is the test that catches it."""
+    from mythos_amd.hip_system import OxdnaSystem
+
+    top, c0, q0 = generators.ideal_duplex(bp, model=2, seed=1234)
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=None, dtype=dtype)
+    s.set_params(flat)
+    c = torch.as_tensor(c0, dtype=dtype, device=s.device)
+    q = torch.as_tensor(q0, dtype=dtype, device=s.device)
+    for how in ("build", "pairs"):
+        if how == "build":
+            s.build_neighbors(c, 3.25, 0.1)
+        elif bp <= 100:
+            s.set_neighbors(top.unbonded_neighbors)
+        else:
+            continue
+        e0 = s.energy(c, q)[0].cpu().numpy()
+        e1 = s.energy(c, q, grads=True)[0].cpu().numpy()
+        e2 = s.energy(c, q, grads=True, param_grads=True)[0].cpu().numpy()
+        scale = np.abs(e0).max()
+        tol = 1e-12 if dtype == torch.float64 else 2e-6
+        assert np.abs(e1 - e0).max() <= tol * scale and np.abs(e2 - e0).max() <= tol * scale, (how, e0, e1, e2)
+        for kw in ({}, {"grads": True}, {"grads": True, "param_grads": True}):
+            a, b = s.energy(c, q, **kw), s.energy(c, q, **kw)
+            assert all(torch.equal(x, y) for x, y in zip(a, b) if x is not None), (how, kw)
