@@ -638,13 +638,18 @@ def secondary_difftre(dev, sim_cfg, n_frames: int = 6400) -> dict:
         mval = (weights * ptwist(ref_states).to(weights.dtype)).sum()
         return (mval - target) ** 2, (("propeller_twist", mval.detach()), {})
 
-    def iteration(opt, adam_state, state, key):
+    def iteration(opt, adam_state, state, key, sim_obj=None):
         t = {}
         t0 = time.perf_counter()
-        o = simr.run(opt, state, steps, key=key)
+        o = (sim_obj or simr).run(opt, state, steps, key=key)
         torch.cuda.synchronize(dev)
         t["md_ms"] = 1e3 * (time.perf_counter() - t0)
         traj = o.observables[0]
+        if traj.center.dtype != torch.float64:  # fp32 sampling, fp64 reweighting (north_star: fp32 forces + fp64 energy check)
+            from mythos_amd.simulators.io import SimulatorTrajectory
+
+            traj = SimulatorTrajectory(center=traj.center.double(), orientation=Quaternion(vec=traj.orientation.vec.double()),
+                                       temperature=traj.temperature, metadata=None)
         t0 = time.perf_counter()
         with torch.no_grad():
             ref_e = ef.with_params(opt).map(traj).detach()
@@ -685,6 +690,14 @@ def secondary_difftre(dev, sim_cfg, n_frames: int = 6400) -> dict:
                "replicas": n_rep, "steps": steps, "save_every": save_every, "n_params": len(opt)})
     out["iteration"] = t2
     simr.release()
+    # the same iteration with the MD in fp32 (hi + lo centres) and the reweighting in fp64
+    import dataclasses as _dc
+
+    sim32 = _dc.replace(simr, dtype=torch.float32)
+    o3, a3, st3, _ = iteration(opt, adam_state, init, 3, sim32)
+    _, _, _, t3 = iteration(o3, a3, st3, 4, sim32)
+    out["iteration_md_f32"] = {k: t3[k] for k in ("md_ms", "map_ms", "grad_ms", "adam_ms", "total_ms", "frames", "neff")}
+    sim32.release()
     return out
 
 
