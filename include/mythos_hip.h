@@ -309,7 +309,9 @@ enum mythos_debug_key {
                                        grids of more than four workgroups per CU), 2: none does */
   MYTHOS_DEBUG_MD_ITEMS_BIG = 5,    /* 1: oxDNA step launches start on the wide work lists (ITEMS = 32) instead of reaching them
                                        through an aborted launch */
-  MYTHOS_DEBUG_KEYS = 6
+  MYTHOS_DEBUG_MD_LANES = 6,        /* 8 | 16: lanes per nucleotide of the oxDNA step launches, fixed when a state is loaded
+                                       (normally 16 where n / 16 workgroups are at most two per CU, 8 otherwise) */
+  MYTHOS_DEBUG_KEYS = 7
 };
 int mythos_debug_set(int key, int64_t value);
 int64_t mythos_debug_get(int key);

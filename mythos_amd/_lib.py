@@ -193,7 +193,7 @@ def check(rc: int, what: str = "") -> None:
 
 
 # keys of mythos_debug_set (include/mythos_hip.h: enum mythos_debug_key) - test and diagnostic switches
-DEBUG_KEYS = {"cell_bucket_cap": 0, "energy_list_cap": 1, "md_segment": 2, "md_overflow_at": 3, "md_dense": 4, "md_items_big": 5}
+DEBUG_KEYS = {"cell_bucket_cap": 0, "energy_list_cap": 1, "md_segment": 2, "md_overflow_at": 3, "md_dense": 4, "md_items_big": 5, "md_lanes": 6}
 
 
 def debug_set(key: str, value: int) -> None:

@@ -107,7 +107,7 @@ def test_zero_steps_and_one_nucleotide_system():
     assert torch.isfinite(c1).all() and abs(float(q1.norm()) - 1.0) < 1e-12 and float(c1.abs().max()) > 0
 
 
-def test_md_kernel_with_circular_strands_matches_the_oracle_step_by_step():
+def test_md_kernel_with_circular_strands_matches_the_oracle_step_by_step(md_lanes):
     """The MD kernel's bonded wave makes a second sweep for the ring-closing bonds (slots 2 / 3)."""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle
@@ -177,7 +177,7 @@ def test_md_rows_that_overflow_in_the_middle_of_a_run_grow_and_the_run_continues
     assert integ.last_recoveries() >= 1
 
 
-def test_md_partially_filled_workgroup_matches_the_oracle():
+def test_md_partially_filled_workgroup_matches_the_oracle(md_lanes):
     """50 nucleotides = one full 32-nucleotide workgroup and one with 18 of 32 groups idle (and a padded grid)."""
     from mythos_amd.hip_system import LangevinIntegrator
     from mythos_amd.utils import generators
@@ -275,7 +275,7 @@ def test_reference_all_pairs_list_of_a_1000_nt_system_goes_through_the_energy_ke
             assert float((a.double() - b.double()).abs().max()) <= tol * scale
 
 
-def test_a_crowded_nucleotide_makes_the_step_rerun_with_wider_work_lists():
+def test_a_crowded_nucleotide_makes_the_step_rerun_with_wider_work_lists(md_lanes):
     """More than 16 neighbours of one nucleotide inside the range of an angular term: the launch that finds out aborts
     (nothing it wrote counts: frames and momenta ping-pong), the run switches to the 32-row instantiation, repeats
     the step and carries on.  A blob of unbonded nucleotides, tiny time step, fp64: the trajectory equals the
@@ -389,7 +389,11 @@ def test_a_crowded_workgroup_exhausts_the_row_pool_and_the_step_reruns():
     q = torch.as_tensor(q0, device=s.device).contiguous()
     p, L = integ.init_momenta()
     x, qq, pp, LL = (t.cpu().numpy().copy() for t in (c, q, p, L))
-    tc, tq, et = integ.run(c, q, p, L, 3, save_every=1)
+    _lib.debug_set("md_lanes", 8)  # the premise is about ONE workgroup of 32 nucleotides (a system this small would take 16 lanes per nucleotide, two workgroups)
+    try:
+        tc, tq, et = integ.run(c, q, p, L, 3, save_every=1)
+    finally:
+        _lib.debug_set("md_lanes", 0)
     assert integ.last_recoveries() == 1 and integ.step == 3
     lo = LangevinOracle(2, H.oracle_params(2), H.topo_tensors(top), None, dt, kT, kT / 2.5, kT / 7.5, 1.0, (1.0, 1.0, 1.0), seed=3)
     for k in range(3):

@@ -37,7 +37,7 @@ def _state(c, q, dtype, dev):
 
 @pytest.mark.parametrize(("model", "name", "salt"), [(2, "simple-helix", 0.5), (1, "simple-helix", 0.5), (3, "simple-helix-12bp", 1.0),
                                                      (3, "simple-coax", 1.0)])
-def test_step_by_step_parity_with_oracle_fp64(model, name, salt):
+def test_step_by_step_parity_with_oracle_fp64(model, name, salt, md_lanes):
     """(oxRNA2, model 3: the integrator keeps the backbone site on a1 and a3 - the offsets the frames carry)"""
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle

@@ -52,7 +52,7 @@ def _top_tensors(top, pairs):
             torch.as_tensor(top.bonded_neighbors, dtype=torch.long), torch.as_tensor(pairs, dtype=torch.long))
 
 
-def test_1kbp_fp64_device_list_steps_match_oracle():
+def test_1kbp_fp64_device_list_steps_match_oracle(md_lanes):
     from mythos_amd.hip_system import LangevinIntegrator
     from oracle.langevin_oracle import LangevinOracle
 
@@ -508,7 +508,7 @@ def test_resident_advances_equal_one_run_bitwise():
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
-def test_advance_leaves_the_frame_open_and_store_closes_it(dtype):
+def test_advance_leaves_the_frame_open_and_store_closes_it(dtype, md_lanes):
     """mythos_langevin_advance(n) is n launches: the closing half kick of step n comes with the next force evaluation -
     the next advance's first launch, or one launch inside mythos_langevin_store.  Whatever the sequence of calls, the
     state handed back is the one mythos_langevin_run(total) hands back, bit for bit; a second store changes nothing."""

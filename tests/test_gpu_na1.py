@@ -142,7 +142,7 @@ def test_random_dimers(bonded):
 
 @pytest.mark.parametrize("unfused", [False, True])
 @pytest.mark.parametrize("name", ["simple-helix-dna-rna", "simple-coax-dna-dna-rna", "simple-helix-rna-rna"])
-def test_langevin_steps_match_the_oracle(name, unfused):
+def test_langevin_steps_match_the_oracle(name, unfused, md_lanes):
     """The fused step kernel's oxNA instantiation (per row entry: the parameter set of the pair's kind; sites by the type of
     each nucleotide), and the two-launch path behind LangevinIntegrator.set_unfused (the energy kernel's forces + an integrator
     kernel): six fp64 steps against LangevinOracle on the same Philox stream - positions, quaternions, potential and kinetic

@@ -181,7 +181,7 @@ def work_lists(request):
 
 
 @pytest.mark.parametrize(("model", "save_every"), [(1, 1), (2, 1), (2, 0)])
-def test_langevin_steps_with_a_soft_distribution_match_the_oracle(model, save_every, work_lists):
+def test_langevin_steps_with_a_soft_distribution_match_the_oracle(model, save_every, work_lists, md_lanes):
     """A probabilistic sequence inside the dynamics (the reference's stacking / hydrogen-bonding configurations
     carry pseq into whatever energy function a simulator steps with, dna1/stacking.py:261-285, hydrogen_bonding.py:310-331):
     md_step_kernel's PSEQ instantiation, six fp64 steps on dna1/helix-4bp with a soft distribution - three constrained

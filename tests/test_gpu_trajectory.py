@@ -70,7 +70,7 @@ def _dev(a, dtype, s):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("model", [1, 2, 3, 4])
-def test_frames_at_cadence_one_equal_single_step_stores_and_the_energy_trace_route(model, dtype):
+def test_frames_at_cadence_one_equal_single_step_stores_and_the_energy_trace_route(model, dtype, md_lanes):
     s, c0, q0, dynamic = _case(model, dtype)
     n_steps = 12
 
