@@ -81,7 +81,8 @@ const char* mythos_oxdna_param_name(int index); /* NULL if out of range */
  *             hybrid vectors one after the other; dU_dparams rows have the same layout).  No structural observables for it;
  *             a probabilistic sequence for hydrogen bonding only (mythos_oxdna_set_pseq terms = 2), with dU/d(distribution)
  *             through mythos_oxdna_energy_dpseq like the other models.  The Langevin integrator has an oxNA instantiation of its fused step kernel
- *             (about half the oxDNA2 rate: a parameter set is chosen per row entry).
+ *             (two thirds of the oxDNA2 rate: a parameter set is chosen per row entry).  A probabilistic sequence and its gradient reach
+ *             an oxNA system through the hydrogen-bonding term (mythos_oxdna_set_pseq, mythos_oxdna_energy_dpseq).
  *   seq       host int32[n]  bases A,C,G,T -> 0..3 (mythos/utils/constants.py:5-11)
  *   is_end    host uint8[n]  1 for strand-terminal nucleotides (Debye half charges), may be NULL
  *   bonded    host int32[n_bonded][2] rows (nn_i, nn_j) as mythos/input/topology.py:166-183

@@ -222,7 +222,7 @@ def na1_flat_and_types(energy_fns, weights, geom, kt_default=None):
     if kt is None:
         kt = _terms.default_kt() if kt_default is None else kt_default
     named = fp.derive_flat_na1(sets["dna"], sets["rna"], sets["drh"], kt=kt, salt_conc=0.5 if salt is None else salt,
-                               half_charged_ends=False if hce is None else hce, term_weights=term_w)
+                               half_charged_ends=False if hce is None else hce, term_weights=term_w, numbers_ok=True)
     flat = fp.pack_flat_na1(named, _lib.param_names())
     if nt_type.shape != (int(_np(energy_fns[0].seq).shape[0]),):
         raise ValueError("nt_type must have one entry per nucleotide")
@@ -610,7 +610,7 @@ class ComposedEnergyFunction(EnergyFunction):
         if kt is None:
             kt = _terms.default_kt()
         flat_named = fp.derive_flat(model, sections, kt=kt, salt_conc=0.5 if salt is None else salt,
-                                    half_charged_ends=True if hce is None else hce, term_weights=term_w)
+                                    half_charged_ends=True if hce is None else hce, term_weights=term_w, numbers_ok=True)
         flat = fp.pack_flat(flat_named, _lib.param_names())
         center, quat = body.center, body.orientation.vec
         box = getattr(first.displacement_fn, "box", None)

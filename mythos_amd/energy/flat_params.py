@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 F64 = torch.float64
@@ -27,17 +28,61 @@ def _t(x) -> torch.Tensor:
     return x if isinstance(x, torch.Tensor) else torch.as_tensor(x, dtype=F64)
 
 
+class _Torch:
+    """The arithmetic of ``derive_flat`` on 0-d torch tensors: differentiable (the chain rule of dU/dtheta runs through it)."""
+
+    exp, sqrt, log = torch.exp, torch.sqrt, torch.log
+    t = staticmethod(_t)
+
+    @staticmethod
+    def ones(n):
+        return torch.ones(n, dtype=F64)
+
+
+class _Numpy:
+    """The same arithmetic on numpy float64 scalars, for callers that need numbers, not a graph (a simulator run, ``map``
+    without gradients): ~300 scalar operations cost 0.85 ms as torch tensors and 0.06 ms as numpy scalars, and the packed
+    vector another 0.3 ms of ``torch.stack`` (round 4: what was left of HipMDSimulator.run's host time)."""
+
+    exp, sqrt, log = np.exp, np.sqrt, np.log
+
+    @staticmethod
+    def t(x):
+        if isinstance(x, torch.Tensor):
+            x = x.detach().cpu().numpy()
+        a = np.asarray(x, dtype=np.float64)
+        return np.float64(a) if a.ndim == 0 else a
+
+    @staticmethod
+    def ones(n):
+        return np.ones(n, dtype=np.float64)
+
+
+def _wants_graph(*values) -> bool:
+    for v in values:
+        if isinstance(v, torch.Tensor):
+            if v.requires_grad:
+                return True
+        elif isinstance(v, dict):
+            if _wants_graph(*v.values()):
+                return True
+        elif isinstance(v, (tuple, list)):
+            if _wants_graph(*v):
+                return True
+    return False
+
+
 def c1_match(x, v, dv):
     """(b, x_c) of the parabola b (x_c - x)^2 matching value v and slope dv at x."""
     return dv * dv / (4.0 * v), x - 2.0 * v / dv
 
 
-def _f1_block(prefix, r_low, r_high, a, r0, r_c, out):
+def _f1_block(prefix, r_low, r_high, a, r0, r_c, out, xp=_Torch):
     """f1 = Morse(r) - Morse(r_c), eps = 1 (dna1/base_functions.py:13-37)."""
-    shift = (1.0 - torch.exp(-a * (r_c - r0))) ** 2
+    shift = (1.0 - xp.exp(-a * (r_c - r0))) ** 2
 
     def v(x):
-        e = torch.exp(-a * (x - r0))
+        e = xp.exp(-a * (x - r0))
         return (1.0 - e) ** 2 - shift, 2.0 * a * e * (1.0 - e)
 
     b_low, rc_low = c1_match(r_low, *v(r_low))
@@ -116,7 +161,7 @@ TERM_WEIGHT_NAMES = ("TW_FENE", "TW_BEXC", "TW_STCK", "TW_NEXC", "TW_HB", "TW_CR
 
 
 def derive_flat(
-    model: int, sections: dict, *, kt, salt_conc=0.5, half_charged_ends=True, term_weights=None
+    model: int, sections: dict, *, kt, salt_conc=0.5, half_charged_ends=True, term_weights=None, numbers_ok: bool = False
 ) -> dict[str, torch.Tensor]:
     """Name -> fp64 tensor for every entry of the kernels' flat parameter vector.
 
@@ -124,11 +169,15 @@ def derive_flat(
     parameter names; values may be floats or (requires_grad) tensors.  ``stacking`` may hold
     ``ss_stack_weights`` (4,4) and ``hydrogen_bonding`` ``ss_hb_weights`` (4,4).  ``term_weights`` (8,)
     scale the gradients of the eight terms (ComposedEnergyFunction.weights); energies stay unweighted.
+    ``numbers_ok``: the caller only packs the result (``pack_flat``); when no input requires a gradient the derivation then
+    runs on numpy scalars and the values come back as numpy float64 (same formulas, same rounding to the last digits).
     """
+    xp = _Numpy if (numbers_ok and not _wants_graph(sections, kt, salt_conc, term_weights)) else _Torch
+    _t = xp.t  # noqa: F811 - the conversion of this backend
     S = {sec: {k: (_t(v) if v is not None else None) for k, v in d.items()} for sec, d in sections.items()}
     kt = _t(kt)
     out: dict[str, torch.Tensor] = {}
-    zero = torch.zeros((), dtype=F64)
+    zero = _t(0.0)
 
     g = S["geometry"]
     rna_only = ("GEO_STACK3_A1", "GEO_STACK3_A2", "GEO_STACK5_A1", "GEO_STACK5_A2", "GEO_P3_X", "GEO_P3_Y", "GEO_P3_Z",
@@ -162,9 +211,9 @@ def derive_flat(
     # FENE (dna1/interactions.py:16-41)
     f = S["fene"]
     eps, r0, delta, fmax, finf = f["eps_backbone"], f["r0_backbone"], f["delta_backbone"], f["fmax"], f["finf"]
-    xmax = (-eps + torch.sqrt(eps**2 + 4 * fmax**2 * delta**2)) / (2 * fmax)
-    fene_xmax = -(eps / 2.0) * torch.log(1.0 - xmax**2 / delta**2)
-    long_xmax = (fmax - finf) * xmax * torch.log(xmax) + finf * xmax
+    xmax = (-eps + xp.sqrt(eps**2 + 4 * fmax**2 * delta**2)) / (2 * fmax)
+    fene_xmax = -(eps / 2.0) * xp.log(1.0 - xmax**2 / delta**2)
+    long_xmax = (fmax - finf) * xmax * xp.log(xmax) + finf * xmax
     out.update(
         FENE_EPS=eps, FENE_R0=r0, FENE_DELTA=delta, FENE_FMAX=fmax, FENE_FINF=finf, FENE_XMAX=xmax,
         FENE_CONST=fene_xmax - long_xmax,
@@ -187,7 +236,7 @@ def derive_flat(
     st = S["stacking"]
     st_kt = st.get("kt", kt)
     st_kt = kt if st_kt is None else st_kt
-    _f1_block("STCK", st["dr_low_stack"], st["dr_high_stack"], st["a_stack"], st["dr0_stack"], st["dr_c_stack"], out)
+    _f1_block("STCK", st["dr_low_stack"], st["dr_high_stack"], st["a_stack"], st["dr0_stack"], st["dr_c_stack"], out, xp)
     # oxDNA: theta 4, 5, 6; oxRNA2: theta 5, 6, 9, 10 (rna2/stacking.py:60-176).  The blocks a model does not have are
     # filled with a well-formed unused modulation (the kernels never read them).
     for k in (4, 5, 6, 9, 10):
@@ -198,16 +247,16 @@ def derive_flat(
     for k in (1, 2):
         _f5_block(f"STCK_PHI{k}", st[f"neg_cos_phi{k}_star_stack"], st[f"a_stack_{k}"], out)
     if st.get("ss_stack_weights") is None:
-        eps_stack = (st["eps_stack_base"] + st["eps_stack_kt_coeff"] * st_kt) * STACK_WEIGHTS_SA
+        eps_stack = (st["eps_stack_base"] + st["eps_stack_kt_coeff"] * st_kt) * _t(STACK_WEIGHTS_SA)
     else:
         eps_stack = st["ss_stack_weights"] * (1.0 - st["eps_stack_kt_coeff"] + (st_kt * 9.0 * st["eps_stack_kt_coeff"]))
 
     # hydrogen bonding (dna1/hydrogen_bonding.py:148-223)
     hb = S["hydrogen_bonding"]
-    _f1_block("HYDR", hb["dr_low_hb"], hb["dr_high_hb"], hb["a_hb"], hb["dr0_hb"], hb["dr_c_hb"], out)
+    _f1_block("HYDR", hb["dr_low_hb"], hb["dr_high_hb"], hb["a_hb"], hb["dr0_hb"], hb["dr_c_hb"], out, xp)
     for k in (1, 2, 3, 4, 7, 8):
         _f4_block(f"HYDR_TH{k}", hb[f"theta0_hb_{k}"], hb[f"delta_theta_star_hb_{k}"], hb[f"a_hb_{k}"], out)
-    eps_hb = HB_WEIGHTS_SA * hb["eps_hb"] if hb.get("ss_hb_weights") is None else hb["ss_hb_weights"]
+    eps_hb = _t(HB_WEIGHTS_SA) * hb["eps_hb"] if hb.get("ss_hb_weights") is None else hb["ss_hb_weights"]
 
     # cross stacking (dna1/cross_stacking.py:110-183)
     cr = S["cross_stacking"]
@@ -243,10 +292,10 @@ def derive_flat(
         d_salt = _t(salt_conc) if d_salt is None else d_salt
         hce = d.get("half_charged_ends")
         hce = half_charged_ends if hce is None else bool(hce)
-        lam = d["lambda_factor"] * torch.sqrt(d_kt / 0.1) / torch.sqrt(d_salt)
+        lam = d["lambda_factor"] * xp.sqrt(d_kt / 0.1) / xp.sqrt(d_salt)
         r_high = 3.0 * lam
         pref = d["prefactor_coeff"] * d["q_eff"] ** 2
-        v = pref * torch.exp(-r_high / lam) / r_high
+        v = pref * xp.exp(-r_high / lam) / r_high
         dv = -v * (1.0 / lam + 1.0 / r_high)
         bsm, r_cut = c1_match(r_high, v, dv)
         out.update(
@@ -263,7 +312,7 @@ def derive_flat(
         for j in range(4):
             out[f"STCK_EPS_{i}{j}"] = eps_stack[i, j]
             out[f"HYDR_EPS_{i}{j}"] = eps_hb[i, j]
-    tw = torch.ones(8, dtype=F64) if term_weights is None else _t(term_weights).to(F64)
+    tw = xp.ones(8) if term_weights is None else _t(term_weights)
     for k, name in enumerate(TERM_WEIGHT_NAMES):
         out[name] = tw[k]
     return out
@@ -274,13 +323,13 @@ NA1_UNBONDED_SECTIONS = ("unbonded_excluded_volume", "hydrogen_bonding", "cross_
 
 
 def derive_flat_na1(sections_dna: dict, sections_rna: dict, sections_drh: dict, *, kt, salt_conc=0.5, half_charged_ends=False,
-                    term_weights=None) -> dict[str, dict[str, torch.Tensor]]:
+                    term_weights=None, numbers_ok: bool = False) -> dict[str, dict[str, torch.Tensor]]:
     """The three flat vectors of a hybrid DNA / RNA system (mythos/energy/na1/*.py): ``dna`` - DNA-DNA pairs, the oxDNA2
     sections in the oxDNA2 forms; ``rna`` - RNA-RNA pairs, oxRNA2; ``drh`` - DNA-RNA pairs: the five unbonded sections of
     mythos/input/na1/default_energy.toml in their oxDNA1 forms (cross-stacking with theta4, coaxial stacking with f5 of
     cos phi3 / phi4, Debye-Hueckel).  The hybrid kernels read the bonded entries and the geometry of neither: those
     places of the ``drh`` vector are filled from the oxRNA2 sections, which have the same form."""
-    kw = dict(kt=kt, salt_conc=salt_conc, half_charged_ends=half_charged_ends, term_weights=term_weights)
+    kw = dict(kt=kt, salt_conc=salt_conc, half_charged_ends=half_charged_ends, term_weights=term_weights, numbers_ok=numbers_ok)
     drh = {**{k: v for k, v in sections_rna.items() if k not in NA1_UNBONDED_SECTIONS}, **{k: sections_drh[k] for k in NA1_UNBONDED_SECTIONS}}
     return {"dna": derive_flat(2, sections_dna, **kw), "rna": derive_flat(3, sections_rna, **kw), "drh": derive_flat(3, drh, **kw)}
 
@@ -294,7 +343,9 @@ def pack_flat(named: dict[str, torch.Tensor], names: list[str]) -> torch.Tensor:
     missing = [n for n in names if n not in named]
     if missing:
         raise KeyError(f"flat parameters not derived: {missing}")
-    return torch.stack([named[n].reshape(()).to(F64) for n in names])
+    if not any(isinstance(named[n], torch.Tensor) for n in names):  # the numpy derivation (derive_flat, numbers_ok)
+        return torch.from_numpy(np.array([float(named[n]) for n in names], dtype=np.float64))
+    return torch.stack([_t(named[n]).reshape(()).to(F64) for n in names])
 
 
 PI = math.pi

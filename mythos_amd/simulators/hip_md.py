@@ -164,7 +164,7 @@ class HipMDSimulator(Simulator):
             _terms.fill_missing_sections(model, sections)
         flat = flat if model == 4 else fp.pack_flat(
             fp.derive_flat(model, sections, kt=sp.kT if kt_e is None else kt_e, salt_conc=0.5 if salt is None else salt,
-                           half_charged_ends=True if hce is None else hce, term_weights=tw),
+                           half_charged_ends=True if hce is None else hce, term_weights=tw, numbers_ok=True),
             _lib.param_names(),
         )
         dev = torch.device(self.device) if self.device is not None else init_state.center.device
