@@ -34,6 +34,42 @@ def test_library_exports_every_declared_symbol():
     assert lib.mythos_oxdna_param_name(-1) is None
 
 
+def test_no_kernel_holds_vector_work_in_a_block_entered_only_with_exec_zero():
+    """A compiler fault met in round 4 (oxdna_energy_core.inc, MYTHOS_EN_PARK_FROM): spill reloads placed where no lane
+    is enabled.  The scan runs over the disassembly of every gfx950 code object of the library that ships."""
+    sys.path.insert(0, str(ROOT / "scripts"))
+    try:
+        import check_exec0_reloads as scan
+    finally:
+        sys.path.pop(0)
+    if not Path(scan.OBJDUMP).exists():
+        pytest.skip("llvm-objdump of the ROCm toolchain is not here")
+    objects = list(scan.code_objects(_lib.lib_path()))
+    assert len(objects) >= 8, "the library's offload bundles were not found"
+    hits = scan.scan_library(_lib.lib_path())
+    assert not hits, hits[:6]
+    # the rule itself, on a listing in the shape the fault had
+    listing = """_Zkernel:
+\ts_and_saveexec_b64 s[2:3], vcc
+\ts_cbranch_execz .LBB0_3
+.LBB0_1:
+\tv_add_u32_e32 v1, 8, v1
+\ts_andn2_b64 exec, exec, s[4:5]
+\ts_cbranch_execz .LBB0_3
+\ts_branch .LBB0_1
+.LBB0_3:
+\tscratch_load_dword v130, off, off offset:44
+.LBB0_4:
+\ts_or_b64 exec, exec, s[2:3]
+\ts_endpgm
+"""
+    tmp = ROOT / "build" / "exec0_listing.s"
+    tmp.parent.mkdir(exist_ok=True)
+    tmp.write_text(listing)
+    found = scan.scan(str(tmp))
+    assert len(found) == 1 and "scratch_load_dword v130" in found[0][3]
+
+
 def test_no_gpu_means_loud_failure():
     if torch.cuda.is_available():
         pytest.skip("a GPU is present")
