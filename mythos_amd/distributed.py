@@ -36,14 +36,15 @@ def shard_replicas(n_replicas: int, rank: int, world: int) -> list[int]:
     return list(range(rank, n_replicas, world))
 
 
-def all_gather_observables(local: torch.Tensor, group=None, n_total: int | None = None) -> torch.Tensor:
+def all_gather_observables(local: torch.Tensor, group=None, n_total: int | None = None, force: bool = False) -> torch.Tensor:
     """(R_local, ...) per rank -> (R_total, ...) ordered by replica id (replica r lives on rank r mod world).
 
     ``n_total`` given (the caller knows how many replicas the job has - always true for ``shard_replicas``): every rank's
     count follows from it, so the gather is ONE collective (``all_gather_into_tensor`` of rows padded to ceil(n_total /
     world)) and nothing crosses to the host.  Without it the counts are gathered first (a second collective and a host
-    read-back), which is fine off the timed path."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    read-back), which is fine off the timed path.  ``force``: issue the collective in a group of one as well (the
+    single-GPU test of the RCCL path, tests/test_gpu_difftre.py)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     if n_total is not None:
@@ -72,7 +73,7 @@ def all_gather_observables(local: torch.Tensor, group=None, n_total: int | None 
     return out
 
 
-def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def all_reduce_sum(t: torch.Tensor, group=None, force: bool = False) -> torch.Tensor:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t

@@ -190,3 +190,43 @@ def test_bench_with_two_ranks_prints_one_line_of_the_contract():
     assert "rehearsal" in d["config"] and d["f64_steps_per_s"] > 0 and "f64" in d["config"]["timed_region"]
     for text in (d["config"]["workload"], d["config"]["timed_region"], d["metric"]):
         assert len(text) <= 120, text
+
+
+def test_the_collectives_run_through_rccl_on_this_gpu():
+    """The N > 1 path of bench.py and the DiffTRe driver is `torch.distributed` backend "nccl" = RCCL; the tests above
+    share ONE GPU between two ranks and therefore use gloo (RCCL refuses two ranks on one device).  Here the same
+    functions of mythos_amd/distributed.py issue their collectives through RCCL in a group of one on this GPU:
+    library load, communicator set-up, all_gather_into_tensor, all_reduce and barrier execute on the device."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    code = """
+import json, torch, torch.distributed as dist
+from mythos_amd import distributed as md
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rows = torch.arange(12, dtype=torch.float64, device="cuda").reshape(4, 3)
+g = md.all_gather_observables(rows, n_total=4, force=True)
+g2 = md.all_gather_observables(rows, force=True)
+t = md.all_reduce_sum(torch.tensor([1.5, -2.0], dtype=torch.float64, device="cuda"), force=True)
+dist.barrier(device_ids=[0])
+torch.cuda.synchronize()
+print(json.dumps({"backend": dist.get_backend(), "gather": bool(torch.equal(g, rows)), "gather_counts": bool(torch.equal(g2, rows)),
+                  "reduce": t.tolist(), "own_storage": g.data_ptr() != rows.data_ptr()}))
+dist.destroy_process_group()
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root, check=False)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    import json
+
+    d = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")][0]
+    assert d == {"backend": "nccl", "gather": True, "gather_counts": True, "reduce": [1.5, -2.0], "own_storage": True}
