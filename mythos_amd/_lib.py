@@ -205,9 +205,15 @@ def debug_get(key: str) -> int:
     return int(load().mythos_debug_get(DEBUG_KEYS[key]))
 
 
+_PARAM_NAMES: list[str] = []
+
+
 def param_names() -> list[str]:
-    lib = load()
-    return [lib.mythos_oxdna_param_name(i).decode() for i in range(lib.mythos_oxdna_param_count())]
+    """Names of the flat parameter vector, in its order (a property of the library: read once)."""
+    if not _PARAM_NAMES:
+        lib = load()
+        _PARAM_NAMES.extend(lib.mythos_oxdna_param_name(i).decode() for i in range(lib.mythos_oxdna_param_count()))
+    return list(_PARAM_NAMES)
 
 
 def device_count() -> int:

@@ -88,10 +88,11 @@ def fill_missing_sections_na1(sets: dict) -> None:
 
 def fill_missing_sections(model: int, sections: dict) -> None:
     """Terms absent from a composed function still need well-formed (unused, weight 0) parameters."""
-    _, cfg = defaults.default_configs_for(MODEL_NAMES[model])
-    for sec, vals in cfg.items():
-        if sec not in sections:
-            sections[sec] = vals
+    missing = [sec for sec in defaults.energy_section_names(MODEL_NAMES[model]) if sec not in sections]
+    if missing:  # (a copy of the defaults only when one is needed: a composed function of all terms has none missing)
+        _, cfg = defaults.default_configs_for(MODEL_NAMES[model])
+        for sec in missing:
+            sections[sec] = cfg[sec]
     if model == 2 and "debye" in sections:
         sections["debye"] = dict(sections["debye"])
     if model == 1 and "com_to_backbone" not in sections["geometry"]:

@@ -254,6 +254,11 @@ def default_configs_for(base: str) -> tuple[dict, dict]:
     raise ValueError(f"unknown model '{base}' (expected 'dna1', 'dna2', 'rna2' or 'na1')")
 
 
+def energy_section_names(base: str) -> tuple:
+    """Section names of the default energy configuration of "dna1" / "dna2" / "rna2" (no copy made)."""
+    return tuple({"dna1": DNA1_ENERGY, "dna2": DNA2_ENERGY, "rna2": RNA2_ENERGY}[base])
+
+
 # ---------------------------------------------------------------------------------------------
 # TOML with arithmetic strings (reference: mythos/input/toml.py:21-57, which uses sympy)
 # ---------------------------------------------------------------------------------------------

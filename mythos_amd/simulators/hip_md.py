@@ -69,10 +69,105 @@ def _pair(x):
     return x
 
 
-def nvt_langevin(energy_or_force_fn, shift_fn, dt, kT, gamma, **_):  # noqa: N803, ARG001
-    """Marker with the signature of ``jax_md.simulate.nvt_langevin``: HipMDSimulator recognises it and
-    runs the fused kernel instead of returning (init_fn, step_fn) closures."""
-    return {"integrator": "nvt_langevin", "dt": dt, "kT": kT, "gamma": gamma}
+@dc.dataclass
+class NVTLangevinState:
+    """What ``init_fn`` / ``step_fn`` hand back: the fields the reference reads off jax_md's state (``.position``, ``.mass``:
+    mythos/simulators/jax_md/utils.py:19-28, jaxmd.py:84-92) plus the momenta and the step counter.  Self-contained: the
+    tensors are copies of the integrator's resident frames, so an older state stays valid and can be stepped again."""
+
+    position: RigidBody
+    momentum: RigidBody  # center: linear momenta (N, 3); orientation: body-frame angular momenta (N, 3)
+    mass: RigidBody
+    step: int
+    _version: int = dc.field(default=-1, repr=False)
+
+
+class NVTLangevin:
+    """``init_fn, step_fn = nvt_langevin(energy_fn, shift_fn, dt=, kT=, gamma=)`` - the integrator plug of the reference
+    (``simulator_init``, mythos/simulators/jax_md/utils.py:19-28; call sites jaxmd.py:73-92) on the fused HIP kernel.
+
+    ``init_fn(key, R, mass=..., **kw) -> state`` draws the momenta at kT from ``key`` and loads the state into the
+    integrator; ``step_fn(state, **kw) -> state`` advances ONE step (one launch) and reads the frames back, so that every
+    state is a value as it is in JAX: stepping the newest state continues the resident frames, stepping an older one
+    reloads it first and reproduces what it produced before to rounding (the noise of a step is a function of key, step and
+    nucleotide; a reloaded state's closing half kick and the next opening one are two additions where the resident frames
+    have one).  This is the reference's calling shape, at one C-ABI call and four small copies per step; the loop the
+    reference builds from it (``run_fn``) is ``HipMDSimulator.run`` - one call for all steps - and that is the fast path.
+
+    ``energy_or_force_fn`` must be one of this package's energy functions (it names the topology, the model and the
+    parameters the kernel steps with); an arbitrary Python callable cannot be run by the HIP kernel and is refused.
+    ``dtype`` defaults to the reference's fp64; ``neighbors`` as for HipMDSimulator (default: the energy function's pairs).
+    """
+
+    def __init__(self, energy_or_force_fn, shift_fn, dt, kT, gamma, dtype=torch.float64, device=None, neighbors=None):  # noqa: N803
+        if not isinstance(energy_or_force_fn, EnergyFunction):
+            raise NotImplementedError("nvt_langevin steps an energy function of this package (dna1 / dna2 / rna2 / na1); "
+                                      f"got {type(energy_or_force_fn).__name__}")
+        self.energy_fn, self.shift_fn = energy_or_force_fn, shift_fn
+        self.dt, self.kT, self.gamma = float(dt), float(kT), gamma
+        self.dtype, self.device, self.neighbors = dtype, device, neighbors
+        self._sim = self._integ = None
+        self._version = 0
+
+    def __iter__(self):  # init_fn, step_fn = nvt_langevin(...)
+        yield self.init_fn
+        yield self.step_fn
+
+    def __getitem__(self, k):  # (the marker this function used to return)
+        return {"integrator": "nvt_langevin", "dt": self.dt, "kT": self.kT, "gamma": self.gamma}[k]
+
+    def _read(self, mass, step):
+        s = self._integ.system
+        c, p, ang = (torch.empty((s.n, 3), dtype=s.dtype, device=s.device) for _ in range(3))
+        q = torch.empty((s.n, 4), dtype=s.dtype, device=s.device)
+        self._integ.store(c, q, p, ang)
+        self._version += 1
+        return NVTLangevinState(position=RigidBody(center=c, orientation=Quaternion(vec=q)), momentum=RigidBody(center=p, orientation=ang),
+                                mass=mass, step=step, _version=self._version)
+
+    def init_fn(self, key, R, mass=None, **_):  # noqa: N803
+        if mass is None:
+            mass = RigidBody(center=1.0, orientation=(1.0, 1.0, 1.0))
+        elif not isinstance(mass, RigidBody):
+            m, inertia = mass if isinstance(mass, (tuple, list)) else (mass, (1.0, 1.0, 1.0))
+            mass = RigidBody(center=m, orientation=inertia)
+        first = self.energy_fn.energy_fns[0] if isinstance(self.energy_fn, ComposedEnergyFunction) else self.energy_fn
+        sp = StaticSimulatorParams(seq=first.seq, mass=mass, gamma=self.gamma, bonded_neighbors=first.bonded_neighbors, checkpoint_every=0,
+                                   dt=self.dt, kT=self.kT)
+        if self._sim is not None:
+            self._sim.release()
+        self._sim = HipMDSimulator(energy_fn=self.energy_fn, simulator_params=sp, space=(None, self.shift_fn), neighbors=self.neighbors,
+                                   save_every=0, dtype=self.dtype, device=self.device)
+        system, integ, dev, _, _ = self._sim._prepare(None, int(key), R.center.device)
+        self._integ = integ
+        c = R.center.to(device=dev, dtype=self.dtype).contiguous().clone()
+        q = R.orientation.vec.to(device=dev, dtype=self.dtype).contiguous().clone()
+        p, ang = integ.init_momenta()
+        integ.load(c, q, p, ang)
+        return self._read(mass, 0)
+
+    def step_fn(self, state: NVTLangevinState, **_):
+        if self._integ is None:
+            raise ValueError("step_fn: call init_fn first")
+        integ = self._integ
+        if state._version != self._version:  # not the resident frames: make it so
+            integ.load(state.position.center.contiguous(), state.position.orientation.vec.contiguous(), state.momentum.center.contiguous(),
+                       state.momentum.orientation.contiguous())
+            integ.step = int(state.step)
+        integ.advance(1)
+        return self._read(state.mass, int(state.step) + 1)
+
+    def close(self) -> None:
+        if self._sim is not None:
+            self._sim.release()
+        self._sim = self._integ = None
+
+
+def nvt_langevin(energy_or_force_fn, shift_fn, dt, kT, gamma, **kw):  # noqa: N803
+    """Signature of ``jax_md.simulate.nvt_langevin``.  Called, it returns the (init_fn, step_fn) pair (NVTLangevin);
+    passed uncalled as ``simulator_init`` - what the reference's simulators are given - HipMDSimulator recognises it and
+    runs the whole loop in one call."""
+    return NVTLangevin(energy_or_force_fn, shift_fn, dt, kT, gamma, **kw)
 
 
 @dc.dataclass(frozen=True, kw_only=True)
@@ -117,15 +212,9 @@ class HipMDSimulator(Simulator):
             system.close()
         self._resident.clear()
 
-    def run(self, opt_params: dict, init_state: RigidBody | None = None, n_steps: int | None = None, key: int | None = None,
-            **_) -> SimulatorOutput:
-        init_state = self.init_state if init_state is None else init_state
-        n_steps = self.n_steps if n_steps is None else n_steps
-        key = self.key if key is None else key
-        if init_state is None or n_steps is None:
-            raise ValueError("HipMDSimulator.run needs init_state and n_steps (as arguments or as fields)")
-        if self.simulator_init is not nvt_langevin:
-            raise NotImplementedError("HipMDSimulator implements nvt_langevin (the integrator every reference example uses)")
+    def _prepare(self, opt_params, key, state_device):
+        """The device-side objects of this simulator at ``opt_params``: (system, integrator, device, replicas, nucleotides
+        per replica) - built on first use, afterwards the kept ones with the new parameter vector, key and step 0."""
         ef = self.energy_fn.with_params(opt_params) if opt_params else self.energy_fn
         if not isinstance(ef, ComposedEnergyFunction):
             ef = ComposedEnergyFunction(energy_fns=[ef])
@@ -167,7 +256,7 @@ class HipMDSimulator(Simulator):
                            half_charged_ends=True if hce is None else hce, term_weights=tw, numbers_ok=True),
             _lib.param_names(),
         )
-        dev = torch.device(self.device) if self.device is not None else init_state.center.device
+        dev = torch.device(self.device) if self.device is not None else state_device
         if dev.type != "cuda":
             dev = torch.device("cuda", torch.cuda.current_device())
         box = getattr(first.displacement_fn, "box", None)
@@ -234,6 +323,19 @@ class HipMDSimulator(Simulator):
             system.set_pseq(marg, unit, bp, terms)
         elif had_pseq:
             system.set_pseq()
+        return system, integ, dev, n_rep, n_one
+
+    def run(self, opt_params: dict, init_state: RigidBody | None = None, n_steps: int | None = None, key: int | None = None,
+            **_) -> SimulatorOutput:
+        init_state = self.init_state if init_state is None else init_state
+        n_steps = self.n_steps if n_steps is None else n_steps
+        key = self.key if key is None else key
+        if init_state is None or n_steps is None:
+            raise ValueError("HipMDSimulator.run needs init_state and n_steps (as arguments or as fields)")
+        if self.simulator_init is not nvt_langevin:
+            raise NotImplementedError("HipMDSimulator implements nvt_langevin (the integrator every reference example uses)")
+        system, integ, dev, n_rep, n_one = self._prepare(opt_params, key, init_state.center.device)
+        sp, nb = self.simulator_params, self.neighbors
         c = init_state.center.to(device=dev, dtype=self.dtype).contiguous().clone()
         q = init_state.orientation.vec.to(device=dev, dtype=self.dtype).contiguous().clone()
         offsets = None

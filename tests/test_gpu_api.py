@@ -194,6 +194,54 @@ def test_simulator_run_surface():
         torch.testing.assert_close(e_traj.cpu(), tr.metadata["energy_terms"].sum(1).cpu(), rtol=2e-4, atol=1e-3)
 
 
+def test_integrator_plug_has_the_reference_shape_and_equals_the_one_call_loop():
+    """`init_fn, step_fn = simulator_init(energy_fn, shift_fn, dt=, kT=, gamma=)`; `state = init_fn(key, R, mass=)`;
+    `state = step_fn(state)`; the loop reads `state.position` (mythos/simulators/jax_md/jaxmd.py:73-92, utils.py:19-28).
+    Stepped that way, the states equal the rows of HipMDSimulator.run - the same loop in one call - bit for bit; a state is a
+    value: stepping an older one again reproduces its successor."""
+    from mythos_amd.simulators.hip_md import HipMDSimulator, NVTLangevinState, StaticSimulatorParams, nvt_langevin
+    from mythos_amd.simulators.neighbors import NoNeighborList
+
+    top, traj, _, _, mod, _, _, _ = _setup(2, "simple-helix")
+    disp, shift = space.free()
+    ef = mod.create_default_energy_fn(top, disp)
+    gamma = RigidBody(center=KT / 2.5, orientation=KT / 7.5)
+    mass = RigidBody(center=1.0, orientation=(1.0, 1.0, 1.0))
+    init = _states(traj, torch.float64)[0]
+    for dtype in (torch.float64, torch.float32):
+        plug = nvt_langevin(ef, shift, dt=5e-3, kT=KT, gamma=gamma, dtype=dtype)
+        init_fn, step_fn = plug
+        state = init_fn(11, init, mass=mass)
+        assert isinstance(state, NVTLangevinState) and state.step == 0 and state.mass is mass
+        torch.testing.assert_close(state.position.center.double().cpu(), init.center.cpu().double(), rtol=0, atol=1e-6 if dtype == torch.float32 else 0)
+        states = [state]
+        for _ in range(6):
+            states.append(step_fn(states[-1]))
+        assert [s.step for s in states] == list(range(7))
+        sim = HipMDSimulator(energy_fn=ef, simulator_params=StaticSimulatorParams(seq=top.seq, mass=mass, gamma=gamma, bonded_neighbors=top.bonded_neighbors,
+                                                                                  checkpoint_every=0, dt=5e-3, kT=KT),
+                             space=(disp, shift), simulator_init=nvt_langevin, neighbors=NoNeighborList(unbonded_nbrs=top.unbonded_neighbors),
+                             save_every=1, dtype=dtype)
+        rows = sim.run({}, init, 6, key=11).observables[0]
+        for k in range(6):
+            assert torch.equal(states[k + 1].position.center, rows.center[k]), (dtype, k)
+            assert torch.equal(states[k + 1].position.orientation.vec, rows.orientation.vec[k]), (dtype, k)
+        # a state is a value: an older one can be stepped again (reloaded, its closing half kick and the next step's opening one
+        # are then two roundings where the resident frames have one: equal to rounding, not to the bit)
+        tol = dict(rtol=0, atol=1e-12) if dtype == torch.float64 else dict(rtol=0, atol=2e-5)
+        again = step_fn(states[2])
+        assert again.step == 3
+        torch.testing.assert_close(again.position.center, states[3].position.center, **tol)
+        torch.testing.assert_close(again.position.orientation.vec, states[3].position.orientation.vec, **tol)
+        torch.testing.assert_close(again.momentum.center, states[3].momentum.center, **tol)
+        torch.testing.assert_close(again.momentum.orientation, states[3].momentum.orientation, **tol)
+        onward = step_fn(again)
+        torch.testing.assert_close(onward.position.center, states[4].position.center, **tol)
+        plug.close()
+    with pytest.raises(NotImplementedError, match="energy function of this package"):
+        nvt_langevin(lambda R, **kw: 0.0, shift, dt=5e-3, kT=KT, gamma=gamma)
+
+
 def test_simulator_batches_independent_replicas_in_one_launch():
     """n_replicas copies of the system advance as one launch per step, far apart in free space.  Cold and frictionless
     (kT -> 0, gamma = 0) the copies follow the same deterministic trajectory as a single run; thermal, they stay where
