@@ -34,6 +34,8 @@ one md_rna2 "" python scripts/bench_rna2.py 500
 one md_na1 "" python scripts/bench_na1.py
 fi
 [ "$part" = md ] && exit 0
+# configs[1], 1 kbp: the 16-lanes-per-nucleotide instantiation of the step kernel (2 000 nt <= 6 144)
+one md_1kbp_f32 "" python bench.py --bp 1000 $short
 one martini_md "" python bench.py --workload martini-bilayer --steps 500 --warmup 100 --cpu-steps 0 --repeats 1
 one energy_difftre "" python scripts/bench_energy.py --difftre
 one energy_difftre_obs "" python scripts/bench_energy.py --obs
