@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--skin", type=float, default=None, help="Verlet skin (default: 0.9 oxDNA length units / 0.5 nm MARTINI)")
     ap.add_argument("--rebuild-every", type=int, default=None, help="steps between list rebuilds (default: 50 oxDNA / 12 MARTINI)")
+    ap.add_argument("--inner-list", type=str, default=None,
+                    help="MARTINI workload: MARGIN,EVERY of the pruned rows (default 0.2,4; 0,0 switches them off)")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--save-every", type=int, default=0, help="observable cadence inside the timed region (N>1: all-gathered)")
     ap.add_argument("--trace-energy", action="store_true",
@@ -268,7 +270,8 @@ def martini_main(args):
     # 0.5 / 12 68.8 k, all without an out-of-turn rebuild in 40 000 steps; 0.4 / 10 and 0.5 / 14 have them, 0.6 and above
     # collapse under them).  0.5 / 12 for its margin.
     skin, every = (0.5 if args.skin is None else args.skin), (12 if args.rebuild_every is None else args.rebuild_every)
-    m = measure_martini(dev, args.dtype, args.steps, args.warmup, skin, every, repeats=max(1, args.repeats if args.repeats else 3))
+    inner = None if args.inner_list is None else tuple(float(v) for v in args.inner_list.split(","))
+    m = measure_martini(dev, args.dtype, args.steps, args.warmup, skin, every, repeats=max(1, args.repeats if args.repeats else 3), inner=inner)
     kms = m["timing"]["kernel_ms"]
     fr = _frac(m["alg"], kms)
     cpu = None if args.cpu_steps == 0 else martini_cpu_baseline(m["port_args"], m["xt"], m["bt"], m["kT"], 0.3, 10)
@@ -278,7 +281,7 @@ def martini_main(args):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"MARTINI-2 DMPC bilayer (fixture tiled 4x4, {m['n']} beads), LJ r_c 1.1 nm + bonds + G96 angles, dt 0.02 ps, 273 K",
                    "thermostat": "Langevin, gamma 1/ps", "ns_per_day": m["steps_per_s"] * 0.02e-3 * 86400.0, "samples_ms": m["samples_ms"],
-                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": m["mean_row"], "max_row": m["max_row"],
+                   "neighbor_list": {"skin": skin, "rebuild_every": every, "mean_row": m["mean_row"], "max_row": m["max_row"], "pruned_rows": m["pruned_rows"],
                                      "out_of_turn_rebuilds": m["recoveries"]}},
         "roofline": {"bound": "hbm", "achieved": fr["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr["frac"], "traffic": None,
                      "kernel": "martini_md_step_kernel", "kernel_ms": kms, "loop_ms_per_launch": m["timing"]["loop_ms_per_launch"],
@@ -521,7 +524,7 @@ def martini_cpu_baseline(port_args, xt, bt, kT: float, skin: float, every: int, 
             "sample": f"C++/OpenMP MARTINI port (oracle/cpu_port) fp64, {n_steps} steps after 10, same {xt.shape[0]} beads, {dt:.1f} s"}
 
 
-def measure_martini(dev, dtype_name: str, steps: int, warmup: int, skin: float, every: int, repeats: int = 3):
+def measure_martini(dev, dtype_name: str, steps: int, warmup: int, skin: float, every: int, repeats: int = 3, inner=None):
     """BASELINE configs[2] through the resident integrator: load, warm up, ``repeats`` x advance(steps), then an
     instrumented pass."""
     from mythos_amd.hip_system import MartiniLangevinIntegrator
@@ -532,6 +535,8 @@ def measure_martini(dev, dtype_name: str, steps: int, warmup: int, skin: float, 
     kT = 0.0083144626 * 273.0
     integ = MartiniLangevinIntegrator(system, dt=0.02, kT=kT, gamma=1.0, seed=0)
     integ.set_neighbor_policy(skin, every)
+    inner = (0.2, 4) if inner is None else inner  # pruned rows: 75.5 k -> 77.6 k steps/s at 0.5 / 12 (profiles/r04_experiments.md)
+    integ.set_inner_list(float(inner[0]), int(inner[1]))
     pos = torch.as_tensor(xt, dtype=dtype, device=dev).contiguous()
     vel = integ.init_velocities()
     integ.load(pos, vel, bt)
@@ -552,9 +557,10 @@ def measure_martini(dev, dtype_name: str, steps: int, warmup: int, skin: float, 
     torch.cuda.synchronize(dev)
     assert torch.isfinite(pos).all()
     mx, nbar = integ.neighbor_stats()
+    pruned = {"margin": float(inner[0]), "every": int(inner[1]), "mean_row": float(integ.rows(True)[1].mean())} if inner[0] > 0 and inner[1] >= 2 else None
     n = system.n
     alg = n * (2 * 6 * word + 4 + 4.0 * nbar)  # 2 x (pos 3 + vel 3) words + type 4 B + 4 B per neighbour entry
-    return {"steps_per_s": repeats * steps / sum(ts), "samples_ms": [1e3 * t for t in ts], "n": n, "mean_row": nbar, "max_row": mx,
+    return {"steps_per_s": repeats * steps / sum(ts), "samples_ms": [1e3 * t for t in ts], "n": n, "mean_row": nbar, "max_row": mx, "pruned_rows": pruned,
             "recoveries": rec, "kT": kT, "timing": timing, "alg": alg, "port_args": port_args, "xt": xt, "bt": bt}
 
 
@@ -562,7 +568,7 @@ def secondary_martini(dev, skin: float = 0.5, every: int = 12, steps: int = 2000
     m = measure_martini(dev, "f32", steps, 300, skin, every)
     out = {"workload": f"MARTINI-2 DMPC bilayer (fixture tiled 4x4, {m['n']} beads), LJ + bonds + G96 angles, dt 0.02 ps, 273 K, fp32",
            "steps_per_s": m["steps_per_s"], "ns_per_day": m["steps_per_s"] * 0.02e-3 * 86400.0, "mean_row": m["mean_row"],
-           "out_of_turn_rebuilds": m["recoveries"], **_frac(m["alg"], m["timing"]["kernel_ms"]),
+           "pruned_rows": m["pruned_rows"], "out_of_turn_rebuilds": m["recoveries"], **_frac(m["alg"], m["timing"]["kernel_ms"]),
            "loop_ms_per_launch": m["timing"]["loop_ms_per_launch"]}
     out["cpu_baseline"] = martini_cpu_baseline(m["port_args"], m["xt"], m["bt"], m["kT"], 0.3, 10)
     return out

@@ -362,6 +362,14 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
                                                      const double* mass, uint64_t seed);
 void mythos_martini_langevin_destroy(mythos_martini_sim_t* sim);
 int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* sim, double skin, int rebuild_every);
+/* Pruned rows (round 4; no counterpart in the reference - GROMACS, which runs its MARTINI dynamics, prunes its pair list
+ * between searches in the same way): every `every` steps the step launch writes, as a by-product of the distances it
+ * computes, the entries of each Verlet row inside r_cut + margin to a second set of rows, and the launches in between walk
+ * those.  Safe while no bead moves more than margin / 2 between two prunings: checked per step (a step longer than
+ * margin / (2 (every - 1)) halts and rebuilds like a bead that leaves its skin).  Off by default; bench.py runs the
+ * bilayer with margin 0.2 nm, every 4.  margin <= 0, margin >= skin or every < 2 switches the pruned rows off.  The forces are those of the Verlet rows up to the
+ * order of the sums. */
+int mythos_martini_langevin_set_inner_list(mythos_martini_sim_t* sim, double margin, int every);
 int mythos_martini_langevin_init_velocities(mythos_martini_sim_t* sim, void* vel, mythos_stream_t stream);
 int mythos_martini_langevin_run(mythos_martini_sim_t* sim, void* pos, void* vel, const double* box, int n_steps,
                                 int save_every, void* traj_pos, double* e_trace, mythos_stream_t stream);
@@ -384,6 +392,10 @@ int mythos_martini_langevin_set_timing(mythos_martini_sim_t* sim, int samples); 
 /* out-of-turn rebuilds of the last run (same protocol as mythos_langevin_last_recoveries) */
 int mythos_martini_langevin_last_recoveries(const mythos_martini_sim_t* sim, int* recoveries);
 int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* sim, int* max_row, double* mean_row);
+/* Diagnostics / tests: the neighbour rows as the device holds them, which = 0 the Verlet rows, 1 the pruned rows
+ * (mythos_martini_langevin_set_inner_list).  rows host int32[n][*stride], row_len host int32[n]; with both NULL only
+ * *stride is set.  Synchronises the device. */
+int mythos_martini_langevin_get_rows(const mythos_martini_sim_t* sim, int which, int32_t* rows, int32_t* row_len, int* stride);
 
 #ifdef __cplusplus
 }

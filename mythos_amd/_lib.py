@@ -95,6 +95,7 @@ def load() -> C.CDLL:
         "mythos_martini_langevin_create": (V, [V, C.c_double, C.c_double, C.c_double, c_double_p, C.c_uint64]),
         "mythos_martini_langevin_destroy": (None, [V]),
         "mythos_martini_langevin_set_neighbor_policy": (C.c_int, [V, C.c_double, C.c_int]),
+        "mythos_martini_langevin_set_inner_list": (C.c_int, [V, C.c_double, C.c_int]),
         "mythos_martini_langevin_init_velocities": (C.c_int, [V, V, V]),
         "mythos_martini_langevin_run": (C.c_int, [V, V, V, c_double_p, C.c_int, C.c_int, V, V, V]),
         "mythos_martini_langevin_load": (C.c_int, [V, V, V, c_double_p, V]),
@@ -105,6 +106,7 @@ def load() -> C.CDLL:
         "mythos_martini_langevin_last_kernel_ms": (C.c_int, [V, c_double_p, c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "mythos_martini_langevin_last_recoveries": (C.c_int, [V, C.POINTER(C.c_int)]),
         "mythos_martini_langevin_neighbor_stats": (C.c_int, [V, C.POINTER(C.c_int), c_double_p]),
+        "mythos_martini_langevin_get_rows": (C.c_int, [V, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = header / library mismatch: fail loudly
@@ -163,6 +165,7 @@ DECLARED_SYMBOLS = (
     "mythos_martini_langevin_create",
     "mythos_martini_langevin_destroy",
     "mythos_martini_langevin_set_neighbor_policy",
+    "mythos_martini_langevin_set_inner_list",
     "mythos_martini_langevin_init_velocities",
     "mythos_martini_langevin_run",
     "mythos_martini_langevin_load",
@@ -172,6 +175,7 @@ DECLARED_SYMBOLS = (
     "mythos_martini_langevin_last_rebuilds",
     "mythos_martini_langevin_last_kernel_ms",
     "mythos_martini_langevin_neighbor_stats",
+    "mythos_martini_langevin_get_rows",
     "mythos_martini_langevin_last_recoveries",
 )
 

@@ -61,8 +61,21 @@ struct MmConst {
   R rc2;
   R dt, half_dt, c1, kT;
   R skin_half_sq;  // (skin/2)^2, <= 0 disables the displacement check
+  R rin2;          // (r_c + inner margin)^2: range of the pruned rows (EMIT); <= 0: no pruned rows
+  R step_max_sq;   // a bead may move (margin / 2) / (inner_every - 1) per step while pruned rows are in use; <= 0: no check
   int n_types, angle_kind;
 };
+
+// Fused multiply-add spelled out.  The squared distance of the row walk decides which entries the pruned rows keep: every
+// instantiation of the step kernel has to round it the same way, whatever contraction the compiler would choose for it
+// (the energy-trace and the plain instantiation disagreed in the last bit of r^2 in fp64, kept different entries at
+// the edge of the pruned range, and the sums behind that entry fell into other lanes).
+__device__ __forceinline__ float mm_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double mm_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename R>
+__device__ __forceinline__ R mm_wrap(R d, R l, R il) {
+  return mm_fma(-l, m_rint(d * il), d);
+}
 
 // optimisation barrier on a register value: whatever produced it stays before this point, its uses after
 template <typename T>
@@ -87,7 +100,13 @@ constexpr int mm_prio_digit(int phase) {
 #define MM_PRIO(phase) do { } while (0)
 #endif
 
-template <typename R, bool SAVE>
+// EMIT (pruned rows, round 4): the launch walks the Verlet rows (range r_c + skin) and, as a by-product of the distances it
+// computes anyway, writes for every bead the entries inside r_c + margin to a second set of rows, in row order.  The next
+// inner_every - 1 launches walk those instead - 78 entries for 135 at the bilayer's policy - while no bead moves more
+// than margin / 2 in total (checked per step, conservatively; a violation halts like a bead that leaves its skin, and
+// the recovery rebuilds both lists).  GROMACS prunes its pair list the same way between searches ("dynamic pruning").
+// Which list a launch walks is a function of the steps since the Verlet rows were built, so split calls stay bitwise equal.
+template <typename R, bool SAVE, bool EMIT = false>
 __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     int n, const MmConst<R> K, const typename Real4<R>::type* __restrict__ in, typename Real4<R>::type* __restrict__ out,
     typename Real4<R>::type* __restrict__ vel, const int* __restrict__ rows, const int* __restrict__ row_len,
@@ -96,7 +115,8 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     const R* __restrict__ bond_r0, const int* __restrict__ angles, const R* __restrict__ angle_k,
     const R* __restrict__ angle_t0, R kick_close, int do_step, uint64_t seed, uint64_t step,
     const typename Real4<R>::type* __restrict__ ref_pos, int* __restrict__ flags, R* __restrict__ traj,
-    double* __restrict__ e_part, const int* __restrict__ list_overflow, int k_index) {
+    double* __restrict__ e_part, const int* __restrict__ list_overflow, int k_index, int* __restrict__ emit_rows,
+    int* __restrict__ emit_len) {
   using V4 = typename Real4<R>::type;
   constexpr int G = kMmG, PPB = kMmPPB;
   extern __shared__ unsigned char smem_raw[];
@@ -146,6 +166,11 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   {
     constexpr int kLjBatch = MYTHOS_MM_BATCH;
     int jn[kLjBatch];
+    int n_in = 0;  // (EMIT) entries of the pruned row so far: the same number in every lane of the group
+    int* __restrict__ emit_row = EMIT ? emit_rows + (size_t)ii * row_stride : nullptr;
+    const int gshift = (int)(threadIdx.x & 63) & ~(G - 1);
+    constexpr unsigned int kGroupMask = (G >= 32) ? 0xffffffffu : ((1u << (G & 31)) - 1u);
+    (void)n_in, (void)emit_row, (void)gshift;
 #pragma unroll
     for (int u = 0; u < kLjBatch; ++u) jn[u] = (u * G + lane < len) ? row[u * G + lane] : -1;
 #pragma unroll 1
@@ -164,10 +189,16 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       }
 #pragma unroll
       for (int u = 0; u < kLjBatch; ++u) {
-        if (j[u] < 0) continue;
-        const R dx = wrap(me.x - o[u].x, K.lx, K.ilx), dy = wrap(me.y - o[u].y, K.ly, K.ily), dz = wrap(me.z - o[u].z, K.lz, K.ilz);
-        const R r2 = dx * dx + dy * dy + dz * dz;
-        if (r2 < K.rc2) {
+        const bool have = j[u] >= 0;
+        const R dx = mm_wrap(me.x - o[u].x, K.lx, K.ilx), dy = mm_wrap(me.y - o[u].y, K.ly, K.ily), dz = mm_wrap(me.z - o[u].z, K.lz, K.ilz);
+        const R r2 = mm_fma(dz, dz, mm_fma(dy, dy, dx * dx));
+        if constexpr (EMIT) {
+          const bool keep = have && r2 < K.rin2;
+          const unsigned int gm = (unsigned int)(__ballot(keep) >> gshift) & kGroupMask;
+          if (keep) emit_row[n_in + __popc(gm & ((1u << lane) - 1u))] = j[u];
+          n_in += __popc(gm);
+        }
+        if (have && r2 < K.rc2) {
           const int tp = type_i + (int)o[u].w;
           const R ir2 = R(1) / r2;
           const R s2 = s_sig2[tp] * ir2, s6 = s2 * s2 * s2, s12 = s6 * s6;
@@ -181,6 +212,8 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
         }
       }
     }
+    if constexpr (EMIT)
+      if (valid && lane == 0) emit_len[i] = n_in;
   }
   // ---- bonds and angles of this bead (incidence lists, one entry per lane)
   MM_PRIO(1);
@@ -210,9 +243,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       const R c = uv * iu * iv;
       R dEdc, en;
       if (K.angle_kind == 0) {
-        R c0;
-        if constexpr (sizeof(R) == 4) c0 = cosf(angle_t0[a]); else c0 = cos(angle_t0[a]);
-        const R x = c - c0;
+        const R x = c - angle_t0[a];  // (G96: the array holds cos(theta0), mm_angle_ref)
         dEdc = angle_k[a] * x;
         en = R(0.5) * angle_k[a] * x * x;
       } else {
@@ -299,6 +330,10 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
       if (K.skin_half_sq > R(0)) {
         const R dx = x[0] - r0.x, dy = x[1] - r0.y, dz = x[2] - r0.z;
         if (dx * dx + dy * dy + dz * dz > K.skin_half_sq) atomicMax(flags + 1, k_index + 1);  // stale for the NEXT forces: launch k + 1 halts
+      }
+      if (K.step_max_sq > R(0)) {  // pruned rows in use: see EMIT
+        const R dx = x[0] - x0.x, dy = x[1] - x0.y, dz = x[2] - x0.z;
+        if (dx * dx + dy * dy + dz * dz > K.step_max_sq) atomicMax(flags + 1, k_index + 1);
       }
       if (!(x[0] == x[0]) || !(v[0] == v[0])) atomicOr(flags, 2);
     }
@@ -582,10 +617,17 @@ struct mythos_martini_sim {
   int rebuild_every = 10;
   void* frame[2] = {nullptr, nullptr};
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
+  void* d_angle_ref = nullptr;  // per angle: cos(theta0) for the G96 form (once, instead of a cosine per lane and step), theta0 for the harmonic one
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
   int cell_H = 0, cell_alloc_bucket_cap = 0, cell_bucket_cap = 64, cell_phase = 0;
   int row_stride = 256;
+  // pruned rows (martini_md_step_kernel, EMIT): entries of the Verlet rows inside r_c + inner_margin, rewritten every
+  // inner_every steps by the step launch itself; inner_margin <= 0 or inner_every < 2: not used
+  int *d_rows_in = nullptr, *d_row_len_in = nullptr;
+  int rows_in_stride = 0;
+  double inner_margin = 0.0;  // off until mythos_martini_langevin_set_inner_list asks for them
+  int inner_every = 4;
   double* d_epart = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   static constexpr int kMaxSamples = 16;
@@ -672,6 +714,11 @@ static __global__ void mm_publish_ctl_kernel(const int* __restrict__ flags, cons
   out[4] = overflow[0], out[5] = overflow[1], out[6] = overflow[2];
 }
 
+// pruned rows make sense inside the skin and when at least one launch walks them between two prunings
+static bool mm_inner_on(const mythos_martini_sim* sim) {
+  return sim->inner_margin > 0 && sim->inner_margin < sim->skin && sim->inner_every >= 2;
+}
+
 template <typename R>
 static MmConst<R> mm_const(const mythos_martini_sim* sim) {
   const mythos_martini* m = sim->sys;
@@ -682,6 +729,10 @@ static MmConst<R> mm_const(const mythos_martini_sim* sim) {
   K.rc2 = R(m->r_cut * m->r_cut);
   K.dt = R(sim->dt), K.half_dt = R(0.5 * sim->dt), K.c1 = R(std::exp(-sim->gamma * sim->dt)), K.kT = R(sim->kT);
   K.skin_half_sq = R(0.25 * sim->skin * sim->skin);
+  const bool inner = mm_inner_on(sim);
+  const double rin = m->r_cut + sim->inner_margin, smax = 0.5 * sim->inner_margin / std::max(1, sim->inner_every - 1);
+  K.rin2 = inner ? R(rin * rin) : R(0);
+  K.step_max_sq = inner ? R(smax * smax) : R(0);
   K.n_types = m->n_types, K.angle_kind = m->angle_kind;
   return K;
 }
@@ -777,6 +828,20 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
     built_at = -sim->since_build;
   }
   sim->list_valid = true;
+  const bool inner_on = mm_inner_on(sim);
+  // the pruned rows share the Verlet rows' stride (a pruned row is a subset of its row: it cannot overflow)
+  auto ensure_inner = [&]() -> int {
+    if (!inner_on) return 0;
+    if (!sim->d_row_len_in) MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_row_len_in, (size_t)n * sizeof(int)));
+    if (!sim->d_rows_in || sim->rows_in_stride != sim->row_stride) {
+      if (sim->d_rows_in) (void)hipFree(sim->d_rows_in);
+      sim->d_rows_in = nullptr;
+      MYTHOS_HIP_TRY(hipMalloc((void**)&sim->d_rows_in, (size_t)n * sim->row_stride * sizeof(int)));
+      sim->rows_in_stride = sim->row_stride;
+    }
+    return 0;
+  };
+  if (int rc = ensure_inner()) return rc;
   const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
   const bool timing = sim->timing_samples > 0;
   if (timing) MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
@@ -808,21 +873,35 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
       const int do_step = last ? 0 : 1;
       R* tp = ((save || save_next) && traj_pos) ? traj_pos + (size_t)sidx * n * 3 : nullptr;
       const bool sampled = !save && (k % sample_stride == sample_stride / 2) && samples < max_samples;
+      // pruned rows: the launch d steps after the Verlet rows were built prunes when d is a multiple of inner_every (so
+      // the first launch on new rows does) and walks the pruned rows otherwise
+      const bool emit = inner_on && ((k - built_at) % sim->inner_every == 0);
+      const int* walk_rows = (inner_on && !emit) ? sim->d_rows_in : sim->d_rows;
+      const int* walk_len = (inner_on && !emit) ? sim->d_row_len_in : sim->d_row_len;
+      int* emit_rows = emit ? sim->d_rows_in : nullptr;
+      int* emit_len = emit ? sim->d_row_len_in : nullptr;
 #define MM_ARGS                                                                                                    \
-  n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, sim->d_rows, sim->d_row_len, sim->row_stride, (const R*)m->d_sigma,    \
+  n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, walk_rows, walk_len, sim->row_stride, (const R*)m->d_sigma,           \
       (const R*)m->d_eps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
-      (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)m->d_angle_t0, kick_close, do_step,     \
-      sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k
+      (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)sim->d_angle_ref, kick_close, do_step,  \
+      sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k, \
+      emit_rows, emit_len
+      auto go = [&](auto save_tag, auto emit_tag) {
+        constexpr bool SV = decltype(save_tag)::value, EM = decltype(emit_tag)::value;
+        if (sampled) {
+          hipExtLaunchKernelGGL((martini_md_step_kernel<R, SV, EM>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
+                                sim->sb[samples], 0, MM_ARGS);
+        } else {
+          hipLaunchKernelGGL((martini_md_step_kernel<R, SV, EM>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+        }
+      };
       if (save) {
-        hipLaunchKernelGGL((martini_md_step_kernel<R, true>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+        if (emit) go(std::true_type{}, std::true_type{}); else go(std::true_type{}, std::false_type{});
         hipLaunchKernelGGL(mm_reduce_trace_kernel, dim3(1), dim3(256), 0, st, sim->d_epart, blocks,
                            e_trace + (size_t)sidx * kMmTrace);
-      } else if (sampled) {
-        hipExtLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, sim->sa[samples],
-                              sim->sb[samples], 0, MM_ARGS);
-        ++samples;
       } else {
-        hipLaunchKernelGGL((martini_md_step_kernel<R, false>), dim3(grid), dim3(kMmBlock), lds, st, MM_ARGS);
+        if (emit) go(std::false_type{}, std::true_type{}); else go(std::false_type{}, std::false_type{});
+        if (sampled) ++samples;
       }
 #undef MM_ARGS
       ++launches;
@@ -846,7 +925,10 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
       (void)hipMemsetAsync(sim->d_flags, 0, 4 * sizeof(int), st);
       set_error("mythos_martini_langevin_run: the neighbour list had to be rebuilt out of turn more than " +
                 std::to_string(kMaxRecoveries) + " times in one run: the skin (" + std::to_string(sim->skin) +
-                ") is too small for a rebuild every " + std::to_string(sim->rebuild_every) + " steps");
+                ") is too small for a rebuild every " + std::to_string(sim->rebuild_every) + " steps" +
+                (mm_inner_on(sim) ? ", or the margin of the pruned rows (" + std::to_string(sim->inner_margin) +
+                                        ") for one pruning in " + std::to_string(sim->inner_every) + " steps"
+                                  : std::string()));
       return MYTHOS_ERR_OVERFLOW;
     }
     k = ran;
@@ -854,6 +936,7 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
     seg_len = std::max(std::min(256, kSegment), seg_len / 4);
     MYTHOS_HIP_TRY(hipMemsetAsync(sim->d_flags + 1, 0, sizeof(int), st));
     if (int rc = build_until_fit(cur)) return rc;
+    if (int rc = ensure_inner()) return rc;  // (the rows may have grown)
     built_at = k;
     ovw[0] = ovw[1] = 0;
   }
@@ -916,7 +999,7 @@ void mythos_martini_langevin_destroy(mythos_martini_sim_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->sys->device);
   void* ptrs[] = {s->frame[0], s->frame[1], s->vel, s->ref_pos, s->d_inv_mass, s->d_rows, s->d_row_len,
-                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart};
+                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart, s->d_rows_in, s->d_row_len_in, s->d_angle_ref};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -962,6 +1045,21 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc((void**)&s->d_overflow, 3 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
+  {
+    std::vector<double> ref((size_t)std::max(sys->n_angles, 0));
+    if (ok && sys->n_angles > 0) {
+      if (sys->dtype == MYTHOS_F32) {
+        std::vector<float> t0(ref.size());
+        ok = hipMemcpy(t0.data(), sys->d_angle_t0, t0.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+        for (size_t a = 0; a < ref.size(); ++a) ref[a] = sys->angle_kind == 0 ? std::cos(double(t0[a])) : double(t0[a]);
+      } else {
+        ok = hipMemcpy(ref.data(), sys->d_angle_t0, ref.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        if (sys->angle_kind == 0)
+          for (double& v : ref) v = std::cos(v);
+      }
+    }
+    ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_angle_ref, ref) : upload_real_vec<double>(&s->d_angle_ref, ref));
+  }
   ok = ok && hipEventCreate(&s->ev0) == hipSuccess && hipEventCreate(&s->ev1) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&s->h_ctl, 8 * sizeof(int), hipHostMallocDefault) == hipSuccess &&
        hipHostGetDevicePointer((void**)&s->d_ctl, s->h_ctl, 0) == hipSuccess && hipMemset(s->d_overflow, 0, 3 * sizeof(int)) == hipSuccess;
@@ -985,6 +1083,17 @@ int mythos_martini_langevin_set_neighbor_policy(mythos_martini_sim_t* s, double 
   s->rebuild_every = rebuild_every;
   s->list_fitted = false;  // another list range: size rows and buckets again at the next run
   s->list_valid = false;
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_set_inner_list(mythos_martini_sim_t* s, double margin, int every) {
+  if (!s || every < 0) {
+    set_error("mythos_martini_langevin_set_inner_list: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  s->inner_margin = margin;
+  s->inner_every = every;
+  s->list_valid = false;  // the schedule of pruning starts again with the next build
   return MYTHOS_OK;
 }
 
@@ -1127,6 +1236,27 @@ int mythos_martini_langevin_neighbor_stats(const mythos_martini_sim_t* s, int* m
   for (int v : len) tot += v, mx = std::max(mx, v);
   if (max_row) *max_row = mx;
   if (mean_row) *mean_row = double(tot) / std::max<size_t>(1, len.size());
+  return MYTHOS_OK;
+}
+
+int mythos_martini_langevin_get_rows(const mythos_martini_sim_t* s, int which, int32_t* rows, int32_t* row_len, int* stride) {
+  if (!s || (which != 0 && which != 1)) {
+    set_error("mythos_martini_langevin_get_rows: invalid argument");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  const int* d_rows = which == 0 ? s->d_rows : s->d_rows_in;
+  const int* d_len = which == 0 ? s->d_row_len : s->d_row_len_in;
+  if (stride) *stride = s->row_stride;
+  if (!rows && !row_len) return MYTHOS_OK;
+  if (!d_rows || !d_len || !s->list_valid) {
+    set_error(which == 0 ? "mythos_martini_langevin_get_rows: no list has been built"
+                         : "mythos_martini_langevin_get_rows: no pruned rows (switched off, or no step taken yet)");
+    return MYTHOS_ERR_INVALID_ARGUMENT;
+  }
+  MYTHOS_HIP_TRY(hipSetDevice(s->sys->device));
+  MYTHOS_HIP_TRY(hipDeviceSynchronize());
+  if (rows) MYTHOS_HIP_TRY(hipMemcpy(rows, d_rows, (size_t)s->sys->n * s->row_stride * sizeof(int), hipMemcpyDeviceToHost));
+  if (row_len) MYTHOS_HIP_TRY(hipMemcpy(row_len, d_len, (size_t)s->sys->n * sizeof(int), hipMemcpyDeviceToHost));
   return MYTHOS_OK;
 }
 

@@ -498,6 +498,11 @@ class MartiniLangevinIntegrator:
     def set_neighbor_policy(self, skin: float, every: int) -> None:
         _lib.check(self._lib.mythos_martini_langevin_set_neighbor_policy(self._h, float(skin), int(every)), "set_neighbor_policy")
 
+    def set_inner_list(self, margin: float, every: int) -> None:
+        """Pruned rows inside r_cut + ``margin``, rewritten every ``every`` steps by the step launch (off by default;
+        margin <= 0 switches them off again) - include/mythos_hip.h."""
+        _lib.check(self._lib.mythos_martini_langevin_set_inner_list(self._h, float(margin), int(every)), "set_inner_list")
+
     def init_velocities(self) -> torch.Tensor:
         v = torch.empty((self.system.n, 3), dtype=self.system.dtype, device=self.system.device)
         _lib.check(self._lib.mythos_martini_langevin_init_velocities(self._h, _lib.ptr(v), _stream(self.system.device)), "init_velocities")
@@ -574,6 +579,18 @@ class MartiniLangevinIntegrator:
         _lib.check(self._lib.mythos_martini_langevin_last_kernel_ms(self._h, C.byref(k), C.byref(loop), C.byref(n), C.byref(ns)),
                    "last_kernel_ms")
         return {"kernel_ms": k.value, "loop_ms_per_launch": loop.value, "launches": n.value, "samples": ns.value}
+
+    def rows(self, pruned: bool = False):
+        """(rows (n, stride) int32, lengths (n,) int32) of the Verlet rows, or of the pruned rows, as numpy arrays
+        (diagnostics / tests; synchronises)."""
+        stride = C.c_int(0)
+        which = 1 if pruned else 0
+        _lib.check(self._lib.mythos_martini_langevin_get_rows(self._h, which, None, None, C.byref(stride)), "get_rows")
+        rows = np.empty((self.system.n, stride.value), dtype=np.int32)
+        lens = np.empty(self.system.n, dtype=np.int32)
+        _lib.check(self._lib.mythos_martini_langevin_get_rows(self._h, which, rows.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                              lens.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(stride)), "get_rows")
+        return rows, lens
 
     def neighbor_stats(self) -> tuple[int, float]:
         mx, mean = C.c_int(0), C.c_double(0.0)

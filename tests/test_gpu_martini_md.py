@@ -306,3 +306,86 @@ def test_positions_only_rows_equal_single_step_stores_and_the_energy_trace_route
         integ.advance(1)
         integ.store(pos, vel)
         assert torch.equal(traj4[k], pos), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_pruned_rows_are_the_verlet_rows_inside_the_margin_and_change_no_physics(dtype):
+    """mythos_martini_langevin_set_inner_list: every fourth launch writes, from the distances it computes anyway, the
+    entries of each Verlet row inside r_c + margin to a second set of rows, the launches in between walk those.
+    (i) the pruned rows ARE that subsequence, entry for entry, for the state they were written from; (ii) the trajectory
+    equals the one without pruning up to the order of the sums; (iii) split calls, single-step stores and the
+    energy-trace route stay bitwise equal with pruning on (which list a launch walks depends only on the steps since the
+    Verlet rows were built); (iv) a margin the beads outrun halts and recovers like a thin skin - still the same physics."""
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, *_rest, x0, b0 = _make(dtype)
+    r_c, skin, margin = 1.1, 0.4, 0.2
+
+    def fresh(inner=(margin, 4), every=8):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=31)
+        integ.set_neighbor_policy(skin, every)
+        integ.set_inner_list(*inner)
+        pos = torch.as_tensor(x0, dtype=dtype, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        integ.load(pos, vel, b0)
+        return integ, pos, vel
+
+    # (i) launch 0 prunes the rows it was given, at the loaded positions
+    integ, pos, vel = fresh()
+    integ.advance(1)
+    rows, lens = integ.rows(False)
+    rows_in, lens_in = integ.rows(True)
+    xw = torch.as_tensor(x0, dtype=dtype).numpy().astype(np.float64)  # the positions as the kernel saw them
+    b = np.asarray(b0, dtype=np.float64)
+    n_checked = 0
+    for i in range(0, sysm.n, 7):
+        j = rows[i, : lens[i]]
+        d = xw[i] - xw[j]
+        d -= b * np.round(d / b)
+        r2 = (d * d).sum(1)
+        edge = np.abs(np.sqrt(r2) - (r_c + margin)) < (1e-5 if dtype == torch.float32 else 1e-12)  # (rounding at the very edge)
+        keep = r2 < (r_c + margin) ** 2
+        got = rows_in[i, : lens_in[i]]
+        want = j[keep | edge] if edge.any() and len(got) != keep.sum() else j[keep]
+        if edge.any():
+            assert set(j[keep & ~edge]) <= set(got) <= set(j[keep | edge])
+        else:
+            assert np.array_equal(got, want), i
+        n_checked += 1
+    assert n_checked > 100 and lens_in.mean() < 0.85 * lens.mean()
+    # (ii) same physics
+    n = 24
+    integ, pos, vel = fresh()
+    tr_on, _ = integ.advance(n, save_every=1, want_energy=False)
+    integ, pos, vel = fresh(inner=(0.0, 0))
+    tr_off, _ = integ.advance(n, save_every=1, want_energy=False)
+    tol = 2e-4 if dtype == torch.float32 else 1e-10
+    assert (tr_on - tr_off).abs().max().item() < tol and not torch.equal(tr_on, tr_off)
+    # (iii) bitwise: split calls, single-step stores, the energy-trace route
+    integ, pos, vel = fresh()
+    for k in range(n):
+        integ.advance(1)
+        integ.store(pos, vel)
+        assert torch.equal(tr_on[k], pos), k
+    integ, pos, vel = fresh()
+    integ.advance(5)
+    integ.advance(7)
+    integ.advance(n - 12)
+    integ.store(pos, vel)
+    assert torch.equal(tr_on[-1], pos)
+    integ, pos, vel = fresh()
+    tr_e, et = integ.advance(n, save_every=1)
+    assert torch.equal(tr_e, tr_on) and torch.isfinite(et).all()
+    integ, pos, vel = fresh()
+    p2 = torch.as_tensor(x0, dtype=dtype, device=sysm.device).contiguous()
+    v2 = integ.init_velocities()
+    integ.run(p2, v2, b0, n)
+    assert torch.equal(p2, tr_on[-1])
+    # (iv) a margin that does not hold: 0.02 nm / 4 allows 0.0033 nm per step, a thermal bead makes 0.006
+    integ, pos, vel = fresh(inner=(0.02, 4))
+    tr_h, _ = integ.advance(n, save_every=1, want_energy=False)
+    assert integ.last_recoveries() >= 5
+    assert (tr_h - tr_off).abs().max().item() < tol
+    integ, pos, vel = fresh(inner=(0.02, 4))
+    with pytest.raises(Exception, match="margin of the pruned rows"):
+        integ.advance(400)
