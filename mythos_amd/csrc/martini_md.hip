@@ -144,9 +144,8 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   }
 
   const int tt = K.n_types * K.n_types;
-  for (int k = threadIdx.x; k < tt; k += kMmBlock) {
-    const R sg = sigma[k];
-    s_sig2[k] = sg * sg;
+  for (int k = threadIdx.x; k < tt; k += kMmBlock) {  // (sigma: squared already, mm compact tables)
+    s_sig2[k] = sigma[k];
     s_eps[k] = eps[k];
   }
   const V4 me = in[ii];
@@ -617,6 +616,12 @@ struct mythos_martini_sim {
   int rebuild_every = 10;
   void* frame[2] = {nullptr, nullptr};
   void *vel = nullptr, *ref_pos = nullptr, *d_inv_mass = nullptr;
+  // Type tables of the step kernel: only the types that occur, renumbered 0 .. n_ctypes - 1 (the DMPC bilayer uses 4 of
+  // the force field's 37: every workgroup filled 2 x 37^2 LDS entries per launch, 0.9 us of a 10.6 us kernel), sigma
+  // already squared.  d_ctypes: the compact type of every bead (what the frames carry in .w).
+  int n_ctypes = 0;
+  int* d_ctypes = nullptr;
+  void *d_csig2 = nullptr, *d_ceps = nullptr;
   void* d_angle_ref = nullptr;  // per angle: cos(theta0) for the G96 form (once, instead of a cosine per lane and step), theta0 for the harmonic one
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
@@ -733,7 +738,7 @@ static MmConst<R> mm_const(const mythos_martini_sim* sim) {
   const double rin = m->r_cut + sim->inner_margin, smax = 0.5 * sim->inner_margin / std::max(1, sim->inner_every - 1);
   K.rin2 = inner ? R(rin * rin) : R(0);
   K.step_max_sq = inner ? R(smax * smax) : R(0);
-  K.n_types = m->n_types, K.angle_kind = m->angle_kind;
+  K.n_types = sim->n_ctypes, K.angle_kind = m->angle_kind;
   return K;
 }
 
@@ -744,7 +749,7 @@ static int mm_load_typed(mythos_martini_sim* sim, const R* pos, const R* v, cons
   mythos_martini* m = sim->sys;
   const int n = m->n, tb = (n + 255) / 256;
   for (int k = 0; k < 3; ++k) sim->box[k] = box[k];
-  hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, m->d_types, (const R*)sim->d_inv_mass,
+  hipLaunchKernelGGL(mm_pack_kernel<R>, dim3(tb), dim3(256), 0, st, n, pos, v, sim->d_ctypes, (const R*)sim->d_inv_mass,
                      (V4*)sim->frame[0], (V4*)sim->vel);
   MYTHOS_HIP_TRY(hipGetLastError());
   sim->cur = 0;
@@ -842,7 +847,7 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
     return 0;
   };
   if (int rc = ensure_inner()) return rc;
-  const size_t lds = (size_t)2 * m->n_types * m->n_types * sizeof(R);
+  const size_t lds = (size_t)2 * sim->n_ctypes * sim->n_ctypes * sizeof(R);
   const bool timing = sim->timing_samples > 0;
   if (timing) MYTHOS_HIP_TRY(hipEventRecord(sim->ev0, st));
   int launches = 0, samples = 0, recoveries = 0, scheduled = 0;
@@ -881,8 +886,8 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
       int* emit_rows = emit ? sim->d_rows_in : nullptr;
       int* emit_len = emit ? sim->d_row_len_in : nullptr;
 #define MM_ARGS                                                                                                    \
-  n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, walk_rows, walk_len, sim->row_stride, (const R*)m->d_sigma,           \
-      (const R*)m->d_eps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
+  n, K, (const V4*)fr[cur], fr[cur ^ 1], vel, walk_rows, walk_len, sim->row_stride, (const R*)sim->d_csig2,          \
+      (const R*)sim->d_ceps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
       (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)sim->d_angle_ref, kick_close, do_step,  \
       sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k, \
       emit_rows, emit_len
@@ -999,7 +1004,7 @@ void mythos_martini_langevin_destroy(mythos_martini_sim_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->sys->device);
   void* ptrs[] = {s->frame[0], s->frame[1], s->vel, s->ref_pos, s->d_inv_mass, s->d_rows, s->d_row_len,
-                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart, s->d_rows_in, s->d_row_len_in, s->d_angle_ref};
+                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart, s->d_rows_in, s->d_row_len_in, s->d_angle_ref, s->d_ctypes, s->d_csig2, s->d_ceps};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -1045,6 +1050,42 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc((void**)&s->d_overflow, 3 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
+  if (ok) {  // the compact type tables
+    const int T = sys->n_types;
+    std::vector<int> types(n), cmap(T, -1), used;
+    ok = hipMemcpy(types.data(), sys->d_types, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    std::vector<double> sig((size_t)T * T), ep((size_t)T * T);
+    if (sys->dtype == MYTHOS_F32) {
+      std::vector<float> a((size_t)T * T), b((size_t)T * T);
+      ok = ok && hipMemcpy(a.data(), sys->d_sigma, a.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(b.data(), sys->d_eps, b.size() * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+      for (size_t k = 0; k < a.size(); ++k) sig[k] = a[k], ep[k] = b[k];
+    } else {
+      ok = ok && hipMemcpy(sig.data(), sys->d_sigma, sig.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(ep.data(), sys->d_eps, ep.size() * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (ok) {
+      for (int t : types)
+        if (t >= 0 && t < T && cmap[t] < 0) cmap[t] = 0;
+      for (int t = 0; t < T; ++t)
+        if (cmap[t] == 0) cmap[t] = (int)used.size(), used.push_back(t);
+      const int C = std::max<int>(1, (int)used.size());
+      std::vector<double> cs((size_t)C * C, 0.0), ce((size_t)C * C, 0.0);
+      for (size_t p = 0; p < used.size(); ++p)
+        for (size_t q = 0; q < used.size(); ++q) {
+          // (squared in the kernel's own precision, as the kernel did)
+          const double sg = sig[(size_t)used[p] * T + used[q]];
+          cs[p * C + q] = sys->dtype == MYTHOS_F32 ? double(float(sg) * float(sg)) : sg * sg;
+          ce[p * C + q] = ep[(size_t)used[p] * T + used[q]];
+        }
+      for (int& t : types) t = (t >= 0 && t < T) ? cmap[t] : 0;
+      s->n_ctypes = C;
+      ok = hipMalloc((void**)&s->d_ctypes, (size_t)n * sizeof(int)) == hipSuccess &&
+           hipMemcpy(s->d_ctypes, types.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+           (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_csig2, cs) && upload_real_vec<float>(&s->d_ceps, ce)
+                                     : upload_real_vec<double>(&s->d_csig2, cs) && upload_real_vec<double>(&s->d_ceps, ce));
+    }
+  }
   {
     std::vector<double> ref((size_t)std::max(sys->n_angles, 0));
     if (ok && sys->n_angles > 0) {
