@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
     const R* __restrict__ angle_t0, R kick_close, int do_step, uint64_t seed, uint64_t step,
     const typename Real4<R>::type* __restrict__ ref_pos, int* __restrict__ flags, R* __restrict__ traj,
     double* __restrict__ e_part, const int* __restrict__ list_overflow, int k_index, int* __restrict__ emit_rows,
-    int* __restrict__ emit_len) {
+    int* __restrict__ emit_len, const int* __restrict__ bb_partner, const int2* __restrict__ ba_partner) {
   using V4 = typename Real4<R>::type;
   constexpr int G = kMmG, PPB = kMmPPB;
   extern __shared__ unsigned char smem_raw[];
@@ -152,6 +152,15 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   const int type_i = (int)me.w * K.n_types;  // the bead type travels as an integer-valued real in .w
   const int* __restrict__ row = rows + (size_t)ii * row_stride;
   const int len = valid ? row_len[ii] : 0;
+  // bonds and angles: the lane's incidence entry and the partner beads it names are requested here, in front of the row
+  // walk, so that behind it ONE round of gathers (the partners' positions) is left.  (Until round 4: entry -> bond /
+  // angle record -> positions, three dependent reads behind the walk, 2.2 us of a 10.6 us kernel.)
+  int ent_b0 = -1, par_b0 = -1, ent_a0 = -1;
+  int2 par_a0{-1, -1};
+  if (valid) {
+    if (lane < kMaxBeadBonds) ent_b0 = bead_bonds[(size_t)i * kMaxBeadBonds + lane], par_b0 = bb_partner[(size_t)i * kMaxBeadBonds + lane];
+    if (lane < kMaxBeadAngles) ent_a0 = bead_angles[(size_t)i * kMaxBeadAngles + lane], par_a0 = ba_partner[(size_t)i * kMaxBeadAngles + lane];
+  }
   __syncthreads();
 
   MM_PRIO(0);
@@ -218,10 +227,11 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   MM_PRIO(1);
   if (valid) {
     for (int s = lane; s < kMaxBeadBonds; s += G) {
-      const int ent = bead_bonds[(size_t)i * kMaxBeadBonds + s];
+      const int ent = (s == lane) ? ent_b0 : bead_bonds[(size_t)i * kMaxBeadBonds + s];
       if (ent < 0) continue;
+      const int partner = (s == lane) ? par_b0 : bb_partner[(size_t)i * kMaxBeadBonds + s];
       const int b = ent >> 1, side = ent & 1;
-      const V4 o = in[bonds[2 * b + (1 - side)]];
+      const V4 o = in[partner];
       const R dx = wrap(me.x - o.x, K.lx, K.ilx), dy = wrap(me.y - o.y, K.ly, K.ily), dz = wrap(me.z - o.z, K.lz, K.ilz);
       const R r = m_sqrt(dx * dx + dy * dy + dz * dz), x = r - bond_r0[b];
       const R c = bond_k[b] * x / r;
@@ -230,10 +240,13 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
         if (side == 0) e_b += R(0.5) * bond_k[b] * x * x;
     }
     for (int s = lane; s < kMaxBeadAngles; s += G) {
-      const int ent = bead_angles[(size_t)i * kMaxBeadAngles + s];
+      const int ent = (s == lane) ? ent_a0 : bead_angles[(size_t)i * kMaxBeadAngles + s];
       if (ent < 0) continue;
+      const int2 others = (s == lane) ? par_a0 : ba_partner[(size_t)i * kMaxBeadAngles + s];
       const int a = ent >> 2, role = ent & 3;  // 0: first bead, 1: centre, 2: last bead
-      const V4 pi = in[angles[3 * a]], pj = in[angles[3 * a + 1]], pk = in[angles[3 * a + 2]];
+      // (the other two beads of the angle, in its order; this bead's own position is in registers)
+      const V4 q0 = in[others.x], q1 = in[others.y];
+      const V4 pi = role == 0 ? me : q0, pj = role == 0 ? q0 : (role == 1 ? me : q1), pk = role == 2 ? me : q1;
       const R u[3] = {wrap(pi.x - pj.x, K.lx, K.ilx), wrap(pi.y - pj.y, K.ly, K.ily), wrap(pi.z - pj.z, K.lz, K.ilz)};
       const R v[3] = {wrap(pk.x - pj.x, K.lx, K.ilx), wrap(pk.y - pj.y, K.ly, K.ily), wrap(pk.z - pj.z, K.lz, K.ilz)};
       const R u2 = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], v2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
@@ -622,6 +635,9 @@ struct mythos_martini_sim {
   int n_ctypes = 0;
   int* d_ctypes = nullptr;
   void *d_csig2 = nullptr, *d_ceps = nullptr;
+  // per incidence slot of a bead: the partner of the bond, the two other beads of the angle (see the step kernel)
+  int* d_bb_partner = nullptr;
+  int2* d_ba_partner = nullptr;
   void* d_angle_ref = nullptr;  // per angle: cos(theta0) for the G96 form (once, instead of a cosine per lane and step), theta0 for the harmonic one
   int *d_rows = nullptr, *d_row_len = nullptr, *d_cell = nullptr, *d_flags = nullptr, *d_overflow = nullptr;
   size_t cell_cap = 0;       // ints allocated at d_cell (cell_list.h CellBins: counters [2][H], buckets [H][cap])
@@ -890,7 +906,7 @@ static int mm_advance_typed(mythos_martini_sim* sim, int n_steps, int save_every
       (const R*)sim->d_ceps, m->d_bead_bonds, m->d_bead_angles, m->d_bonds, (const R*)m->d_bond_k,                      \
       (const R*)m->d_bond_r0, m->d_angles, (const R*)m->d_angle_k, (const R*)sim->d_angle_ref, kick_close, do_step,  \
       sim->seed, (uint64_t)(sim->step + k), (const V4*)sim->ref_pos, sim->d_flags, tp, sim->d_epart, sim->d_overflow, k, \
-      emit_rows, emit_len
+      emit_rows, emit_len, sim->d_bb_partner, sim->d_ba_partner
       auto go = [&](auto save_tag, auto emit_tag) {
         constexpr bool SV = decltype(save_tag)::value, EM = decltype(emit_tag)::value;
         if (sampled) {
@@ -1004,7 +1020,7 @@ void mythos_martini_langevin_destroy(mythos_martini_sim_t* s) {
   if (!s) return;
   (void)hipSetDevice(s->sys->device);
   void* ptrs[] = {s->frame[0], s->frame[1], s->vel, s->ref_pos, s->d_inv_mass, s->d_rows, s->d_row_len,
-                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart, s->d_rows_in, s->d_row_len_in, s->d_angle_ref, s->d_ctypes, s->d_csig2, s->d_ceps};
+                  s->d_cell,   s->d_flags,  s->d_overflow, s->d_epart, s->d_rows_in, s->d_row_len_in, s->d_angle_ref, s->d_ctypes, s->d_csig2, s->d_ceps, s->d_bb_partner, s->d_ba_partner};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (s->h_ctl) (void)hipHostFree(s->h_ctl);
@@ -1050,6 +1066,28 @@ mythos_martini_sim_t* mythos_martini_langevin_create(mythos_martini_t* sys, doub
             hipMalloc((void**)&s->d_overflow, 3 * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&s->d_epart, (size_t)blocks * kMmTrace * sizeof(double)) == hipSuccess;
   ok = ok && (sys->dtype == MYTHOS_F32 ? upload_real_vec<float>(&s->d_inv_mass, im) : upload_real_vec<double>(&s->d_inv_mass, im));
+  if (ok) {  // partners per incidence slot
+    std::vector<int> bb((size_t)n * kMaxBeadBonds), ba((size_t)n * kMaxBeadAngles), bonds((size_t)2 * std::max(sys->n_bonds, 0)),
+        angles((size_t)3 * std::max(sys->n_angles, 0));
+    ok = hipMemcpy(bb.data(), sys->d_bead_bonds, bb.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
+         hipMemcpy(ba.data(), sys->d_bead_angles, ba.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess &&
+         (bonds.empty() || hipMemcpy(bonds.data(), sys->d_bonds, bonds.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) &&
+         (angles.empty() || hipMemcpy(angles.data(), sys->d_angles, angles.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess);
+    std::vector<int> pb(bb.size(), -1);
+    std::vector<int2> pa(ba.size(), int2{-1, -1});
+    for (size_t k = 0; ok && k < bb.size(); ++k)
+      if (bb[k] >= 0) pb[k] = bonds[2 * (size_t)(bb[k] >> 1) + (1 - (bb[k] & 1))];
+    for (size_t k = 0; ok && k < ba.size(); ++k)
+      if (ba[k] >= 0) {
+        const int* t = &angles[3 * (size_t)(ba[k] >> 2)];
+        const int role = ba[k] & 3;
+        pa[k] = role == 0 ? int2{t[1], t[2]} : (role == 1 ? int2{t[0], t[2]} : int2{t[0], t[1]});
+      }
+    ok = ok && hipMalloc((void**)&s->d_bb_partner, std::max<size_t>(pb.size(), 1) * sizeof(int)) == hipSuccess &&
+         hipMalloc((void**)&s->d_ba_partner, std::max<size_t>(pa.size(), 1) * sizeof(int2)) == hipSuccess &&
+         hipMemcpy(s->d_bb_partner, pb.data(), pb.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(s->d_ba_partner, pa.data(), pa.size() * sizeof(int2), hipMemcpyHostToDevice) == hipSuccess;
+  }
   if (ok) {  // the compact type tables
     const int T = sys->n_types;
     std::vector<int> types(n), cmap(T, -1), used;
