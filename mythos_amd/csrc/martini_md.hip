@@ -28,7 +28,11 @@
 
 namespace mythos {
 
-constexpr int kMmBlock = 256;
+// (threads per workgroup, scanned in round 4 at 20 480 beads: 128 / 256 / 512 / 1 024 -> 81.4 k / 84.5 k / 83.2 k / 76.6 k steps/s)
+#ifndef MYTHOS_MM_BLOCK
+#define MYTHOS_MM_BLOCK 256
+#endif
+constexpr int kMmBlock = MYTHOS_MM_BLOCK;
 // Lanes per bead.  Sixteen since round 4: the kernel needs 28 VGPRs, so twice the wavefronts (1 280 workgroups of 16 beads
 // for 20 480 beads, five per CU) fit without any trade, and a lane's chain through the row is half as long - the kernel
 // was latency-bound at 2.5 wavefronts per SIMD (65 % of its wave cycles waiting).  20 480 beads, events, loop rate
@@ -107,7 +111,7 @@ constexpr int mm_prio_digit(int phase) {
 // the recovery rebuilds both lists).  GROMACS prunes its pair list the same way between searches ("dynamic pruning").
 // Which list a launch walks is a function of the steps since the Verlet rows were built, so split calls stay bitwise equal.
 template <typename R, bool SAVE, bool EMIT = false>
-__global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
+__global__ __launch_bounds__(kMmBlock, 1024 / kMmBlock) void martini_md_step_kernel(
     int n, const MmConst<R> K, const typename Real4<R>::type* __restrict__ in, typename Real4<R>::type* __restrict__ out,
     typename Real4<R>::type* __restrict__ vel, const int* __restrict__ rows, const int* __restrict__ row_len,
     int row_stride, const R* __restrict__ sigma, const R* __restrict__ eps, const int* __restrict__ bead_bonds,
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(kMmBlock, 4) void martini_md_step_kernel(
   // ---- integrator prologue, before the barrier: the integrating wavefront draws its thermostat noise and fetches
   //      position, velocity and list reference here, so the tail of the kernel behind the barrier is arithmetic only
   //      (the oxDNA step kernel's arrangement, langevin_core.inc).  mm_pin keeps the values on this side of the barrier.
-  const int int_wave = (bid >> 2) & 3;
+  const int int_wave = (bid >> 2) & (kMmBlock / 64 - 1) & 3;
   const int il = threadIdx.x & 63;
   const int ib = bid * PPB + il;
   const bool integrates = (int)(threadIdx.x >> 6) == int_wave && il < PPB && ib < n;
