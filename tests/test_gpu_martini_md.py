@@ -217,6 +217,46 @@ def test_rows_longer_than_the_default_stride_grow_at_the_first_build():
     torch.testing.assert_close(outs[0], outs[1], rtol=1e-9, atol=1e-9)
 
 
+def test_cells_of_more_than_64_beads_build_the_same_rows():
+    """A list range of 1.1 + 0.75 nm is three cells per edge of the 1 280-bead box with ~70 beads in a cell of the bilayer:
+    buckets beyond the 64 entries a register sort holds (ordered by rank through LDS since round 4).  The rows are the
+    pairs inside the range minus the exclusions (k-d tree on the host), in ascending order inside every cell's stretch,
+    and the trajectory equals the one on a comfortable list."""
+    from scipy.spatial import cKDTree
+
+    from mythos_amd.hip_system import MartiniLangevinIntegrator
+
+    sysm, s, top, *_rest, x0, b0 = _make(torch.float64)
+    rl = 1.1 + 0.75
+    nc = np.floor(b0 / rl).astype(int)
+    assert (nc >= 3).all()
+    xw = np.mod(x0, b0)
+    cell = np.floor(xw / b0 * nc).astype(int).clip(0, nc - 1)
+    assert np.bincount(cell[:, 0] * 100 + cell[:, 1] * 10 + cell[:, 2]).max() > 64
+    outs = []
+    for skin in (0.3, 0.75):
+        integ = MartiniLangevinIntegrator(sysm, dt=0.02, kT=KB * T, gamma=1.0, seed=8)
+        integ.set_neighbor_policy(skin, 5)
+        pos = torch.as_tensor(x0, dtype=torch.float64, device=sysm.device).contiguous()
+        vel = integ.init_velocities()
+        integ.load(pos, vel, b0)
+        integ.advance(1)
+        if skin == 0.75:
+            rows, lens = integ.rows(False)
+            tree = cKDTree(xw, boxsize=b0)
+            want = tree.query_ball_point(xw, rl - 1e-9)
+            bonded = {(int(a), int(b)) for a, b in top.bonded_neighbors} | {(int(b), int(a)) for a, b in top.bonded_neighbors}
+            for i in range(0, sysm.n, 11):
+                got = rows[i, : lens[i]]
+                ref = {j for j in want[i] if j != i and (i, j) not in bonded}
+                near = set(tree.query_ball_point(xw[i], rl + 1e-9)) - {i}
+                assert ref <= set(got.tolist()) <= near and len(set(got.tolist())) == len(got), i
+        integ.advance(19)
+        integ.store(pos, vel)
+        outs.append(pos.clone())
+    torch.testing.assert_close(outs[0], outs[1], rtol=1e-9, atol=1e-9)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 def test_resident_advances_equal_one_run_bitwise(dtype):
     """mythos_martini_langevin_load / advance / store: the list and its rebuild schedule carry over,
