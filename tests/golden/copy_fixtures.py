@@ -32,6 +32,13 @@ CASES = {
     "na1": ("simple-helix-dna-dna", "simple-helix-rna-rna", "simple-helix-dna-rna", "simple-helix-rna-dna",
             "simple-coax-dna-dna-dna", "simple-coax-rna-rna-rna", "simple-coax-dna-dna-rna"),
 }
+# System definitions the reference ships for its examples (examples/jaxmd/simulation.ipynb, the tutorials): relaxed, i.e.
+# thermally distorted, conformations - a 500 bp duplex (1 000 nt, box 350) and the 110 bp WLC system (220 nt).  Inputs only:
+# the expected values of the tests on them come from the oracle.
+SYSDEFS = {
+    "sys-defs/persistence-length-500bp": ("sys-defs/persistence-length-500bp", ("init.top", "relaxed.dat")),
+    "sys-defs/wlc-fit": ("sys-defs/wlc-fit", ("generated.top", "generated.dat")),
+}
 SKIP = {"na1": ("pair.dat",)}
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
          # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)
@@ -56,7 +63,7 @@ def pairs():
                 src = REF / "test-data" / model / case / name
                 if src.exists():
                     yield src, DST / model / case / name
-    for src_dir, (dst_dir, names) in MARTINI.items():
+    for src_dir, (dst_dir, names) in (*MARTINI.items(), *SYSDEFS.items()):
         for name in names:
             yield REF / src_dir / name, DST / dst_dir / name
 

@@ -240,3 +240,53 @@ def test_the_three_modes_of_the_energy_kernel_agree_on_the_energies(bp, dtype):
         for kw in ({}, {"grads": True}, {"grads": True, "param_grads": True}):
             a, b = s.energy(c, q, **kw), s.energy(c, q, **kw)
             assert all(torch.equal(x, y) for x, y in zip(a, b) if x is not None), (how, kw)
+
+
+@pytest.mark.parametrize("name, top_file, conf_file", [("persistence-length-500bp", "init.top", "relaxed.dat"), ("wlc-fit", "generated.top", "generated.dat")])
+def test_relaxed_systems_the_reference_ships_match_the_oracle_and_step(name, top_file, conf_file):
+    """data/sys-defs of the reference (a relaxed 500 bp duplex, the 110 bp WLC system; periodic boxes): not ideal helices
+    but thermally distorted ones.  Terms, forces and torques against the oracle over the reference's all-pairs set - fp64
+    1e-9, fp32 1e-3 - the device-built list gives the same energies, and the state steps: 300 Langevin steps on the GPU
+    list stay a duplex (energy per nucleotide, every base pair)."""
+    import warnings
+
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+    from mythos_amd.input import topology, trajectory
+    from oracle import oxdna_oracle as orc
+
+    base = H.GOLDEN / "sys-defs" / name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / top_file)
+    tr = trajectory.from_file(base / conf_file, top.strand_counts, is_5p_3p=False)
+    c, q, box, n = tr.center[0], tr.quaternions[0], tr.box_size, top.n_nucleotides
+    P = H.oracle_params(2, half_charged_ends=True)
+    seq, is_end, b, u = H.topo_tensors(top)
+    e_ref = orc.energy_terms(2, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u, box=box).numpy()
+    _, gc_ref, gq_ref = orc.energy_and_grads(2, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u, box=box)
+    gc_ref, gq_ref = gc_ref.numpy(), gq_ref.numpy()
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3)):
+        s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=dtype)
+        s.set_params(flat)
+        s.set_neighbors(top.unbonded_neighbors)
+        cd = torch.as_tensor(c, dtype=dtype, device=s.device)
+        qd = torch.as_tensor(q, dtype=dtype, device=s.device)
+        e, gc, gq, _ = s.energy(cd, qd, grads=True)
+        e = e.cpu().numpy().reshape(-1)[:8]
+        assert np.abs(e - e_ref).max() <= tol * np.abs(e_ref).max(), (dtype, e, e_ref)
+        assert np.abs(gc.cpu().double().numpy().reshape(-1, 3) - gc_ref).max() <= max(tol, 1e-8) * np.abs(gc_ref).max()
+        assert np.abs(gq.cpu().double().numpy().reshape(-1, 4) - gq_ref).max() <= max(tol, 1e-8) * np.abs(gq_ref).max()
+        s.build_neighbors(cd, R_CUT, 0.0)
+        e2 = s.energy(cd, qd)[0].cpu().numpy().reshape(-1)[:8]
+        assert np.abs(e2 - e).max() <= (1e-10 if dtype == torch.float64 else 1e-4) * np.abs(e).max()
+        kT = sim["kT"]
+        integ = LangevinIntegrator(s, dt=sim["dt"], kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"], seed=3)
+        integ.set_neighbor_policy(R_CUT, 0.6, 20)
+        p, ang = integ.init_momenta()
+        integ.run(cd, qd, p, ang, 300)
+        assert torch.isfinite(cd).all() and np.allclose(qd.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+        s.build_neighbors(cd, R_CUT, 0.0)
+        e3 = s.energy(cd, qd)[0].cpu().numpy().reshape(-1)[:8]
+        assert -1.62 < e3.sum() / n < -1.30 and e3[4] / n < -0.25, (dtype, e3 / n)

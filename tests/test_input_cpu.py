@@ -200,3 +200,38 @@ def test_default_parameters_and_toml_subset(tmp_path):
     # strings that are not arithmetic stay strings: nothing is ever evaluated as Python
     evil = "__import__('os').system('true')"
     assert defaults.parse_str(evil) == evil and defaults.parse_str("sqrt(4) + pi") == 2.0 + math.pi
+
+
+SYSDEFS = (("persistence-length-500bp", "init.top", "relaxed.dat", 1000, 350.0), ("wlc-fit", "generated.top", "generated.dat", 220, 200.0))
+
+
+@pytest.mark.parametrize("name, top_file, conf_file, n, box", SYSDEFS)
+def test_system_definitions_the_reference_ships_read_as_relaxed_duplexes(name, top_file, conf_file, n, box):
+    """data/sys-defs of the reference (inputs of its example notebooks): a relaxed 500 bp duplex and the 110 bp WLC system.
+    Both readers agree on them bit for bit, and the oracle sees what a thermalised duplex is: every base pair bonded,
+    about -1.5 units per nucleotide, no coaxial stacking, in both models."""
+    import torch
+
+    from mythos_amd import _lib
+    from oracle import oxdna_oracle as orc
+    from tests import helpers as H
+
+    base = GOLDEN / "sys-defs" / name
+    with _nowarn():
+        top = topology.from_oxdna_file(base / top_file)
+    assert top.n_nucleotides == n and list(top.strand_counts) == [n // 2, n // 2]
+    assert len(top.bonded_neighbors) == n - 2 and len(top.unbonded_neighbors) == n * (n - 1) // 2 - (n - 2)
+    tr = trajectory.from_file(base / conf_file, top.strand_counts, is_5p_3p=False, native=False)
+    assert tr.center.shape == (1, n, 3) and np.allclose(tr.box_size, box)
+    if _lib.lib_path().exists():
+        nat = trajectory.from_file(base / conf_file, top.strand_counts, is_5p_3p=False, native=True)
+        assert np.array_equal(nat.frames, tr.frames) and np.array_equal(nat.box_size, tr.box_size)
+    assert np.allclose(np.linalg.norm(tr.quaternions[0], axis=1), 1.0, atol=1e-12)
+    seq, is_end, b, u = H.topo_tensors(top)
+    for model in (1, 2):
+        P = H.oracle_params(model, half_charged_ends=(model == 2))
+        e = orc.energy_terms(model, P, torch.as_tensor(tr.center[0]), torch.as_tensor(tr.quaternions[0]), seq, is_end, b, u,
+                             box=tr.box_size).numpy()
+        assert np.isfinite(e).all() and -1.6 < e.sum() / n < -1.4, (model, e)
+        # terms: fene, bonded excl., stacking, unbonded excl., H-bond, cross-stacking, coaxial (, Debye)
+        assert e[0] > 0 and -1.25 < e[2] / n < -1.05 and -0.40 < e[4] / n < -0.28 and -0.14 < e[5] / n < -0.09 and abs(e[6]) < 1e-6
