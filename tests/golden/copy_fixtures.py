@@ -38,6 +38,11 @@ CASES = {
 SYSDEFS = {
     "sys-defs/persistence-length-500bp": ("sys-defs/persistence-length-500bp", ("init.top", "relaxed.dat")),
     "sys-defs/wlc-fit": ("sys-defs/wlc-fit", ("generated.top", "generated.dat")),
+    # ... and the small ones of the melting-temperature examples: hairpins (ONE strand whose ends pair: the stem's base
+    # pairs are unbonded pairs inside a strand, the loop is unpaired), the 8 bp duplex bound, relaxed and with its strands apart
+    "sys-defs/hairpins/4bp_stem_8nt_loop": ("sys-defs/hairpins/4bp_stem_8nt_loop", ("sys.top", "init.conf")),
+    "sys-defs/hairpins/6bp_stem_6nt_loop": ("sys-defs/hairpins/6bp_stem_6nt_loop", ("sys.top", "init_bound.conf", "init_unbound.conf")),
+    "sys-defs/simple-helix": ("sys-defs/simple-helix", ("sys.top", "bound.conf", "bound_relaxed.conf", "unbound.conf")),
 }
 SKIP = {"na1": ("pair.dat",)}
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),

@@ -316,3 +316,84 @@ def test_parameter_gradients_are_bitwise_reproducible():
             again = s.energy(c, q, grads=True, param_grads=True)
             for a, b in zip(first, again):
                 assert torch.equal(a, b)
+
+
+def _lab_torque(q, dq):
+    """-dU/dphi for a rotation of each body about the lab axes, from dU/dq: delta q = 1/2 (0, dphi) (x) q."""
+    q0, qv = q[:, :1], q[:, 1:]
+    out = np.zeros((q.shape[0], 3))
+    for k in range(3):
+        e = np.zeros(3)
+        e[k] = 1.0
+        d0 = -(qv @ e)
+        dv = q0 * e[None, :] + np.cross(e[None, :], qv)
+        out[:, k] = -0.5 * (dq[:, 0] * d0 + (dq[:, 1:] * dv).sum(1))
+    return out
+
+
+SMALL_SYSDEFS = [
+    ("hairpins/4bp_stem_8nt_loop", "init.conf"), ("hairpins/6bp_stem_6nt_loop", "init_bound.conf"),
+    ("hairpins/6bp_stem_6nt_loop", "init_unbound.conf"), ("simple-helix", "bound.conf"), ("simple-helix", "bound_relaxed.conf"),
+    ("simple-helix", "unbound.conf"),
+]
+
+
+@pytest.mark.parametrize("model", [1, 2])
+@pytest.mark.parametrize("case, conf", SMALL_SYSDEFS)
+def test_small_system_definitions_of_the_reference_match_the_oracle(case, conf, model):
+    """data/sys-defs of the reference's melting-temperature examples: hairpins (ONE strand; the stem's base pairs are
+    unbonded pairs inside it, the loop is unpaired; one conformation clashes under oxDNA2's backbone site: excluded
+    volume of 70 units), the 8 bp duplex bound, relaxed in a box of 5 units - smaller than twice the interaction range -
+    and with its strands apart.  Terms, forces, torques: fp64 1e-9, fp32 1e-3 against the oracle; the device-built list
+    gives the energies of the all-pairs set."""
+    import warnings
+
+    from mythos_amd import _lib
+    from mythos_amd.energy import flat_params as fp
+    from mythos_amd.hip_system import OxdnaSystem
+    from mythos_amd.input import defaults, topology, trajectory
+    from oracle import oxdna_oracle as orc
+    from tests import helpers as H
+
+    base = H.GOLDEN / "sys-defs" / case
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / "sys.top")
+    tr = trajectory.from_file(base / conf, top.strand_counts, is_5p_3p=False)
+    c, q, box = tr.center[0], tr.quaternions[0], tr.box_size
+    hce = model == 2
+    P = H.oracle_params(model, half_charged_ends=hce)
+    seq, is_end, b, u = H.topo_tensors(top)
+    e_ref = orc.energy_terms(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u, box=box).numpy()
+    _, gc_ref, gq_ref = orc.energy_and_grads(model, P, torch.as_tensor(c), torch.as_tensor(q), seq, is_end, b, u, box=box)
+    sim, cfg = defaults.default_configs_for("dna1" if model == 1 else "dna2")
+    flat = fp.pack_flat(fp.derive_flat(model, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=hce), _lib.param_names())
+    scale = max(np.abs(e_ref).max(), 1.0)
+    a3 = np.stack([2 * (q[:, 1] * q[:, 3] + q[:, 0] * q[:, 2]), 2 * (q[:, 2] * q[:, 3] - q[:, 0] * q[:, 1]),
+                   q[:, 0] ** 2 - q[:, 1] ** 2 - q[:, 2] ** 2 + q[:, 3] ** 2], axis=1)
+    bn = np.asarray(top.bonded_neighbors)
+    on_kink = bool((np.abs((a3[bn[:, 0]] * a3[bn[:, 1]]).sum(1)) > 1 - 1e-10).any())  # (see the torque comparison below)
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3)):
+        s = OxdnaSystem(model, top.seq, top.is_end, top.bonded_neighbors, box=box, dtype=dtype)
+        s.set_params(flat)
+        s.set_neighbors(top.unbonded_neighbors)
+        cd = torch.as_tensor(c, dtype=dtype, device=s.device)
+        qd = torch.as_tensor(q, dtype=dtype, device=s.device)
+        e, gc, gq, _ = s.energy(cd, qd, grads=True)
+        e = e.cpu().numpy().reshape(-1)[: len(e_ref)]
+        assert np.abs(e - e_ref).max() <= tol * scale, (dtype, e, e_ref)
+        gs = max(gc_ref.abs().max().item(), gq_ref.abs().max().item(), 1.0)
+        assert (gc.cpu().double().reshape(-1, 3) - gc_ref).abs().max().item() <= max(tol, 1e-8) * gs
+        # Torques, i.e. the part of dU/dq that moves a body.  The straight strands of the hairpin files sit EXACTLY on a kink
+        # of the reference's energy: neighbouring a3 are parallel, cos(theta4) = 1 is where `clamp` cuts the gradient to
+        # zero (utils/math.py:68-88) while the limit from inside is 2 a.  Which side a dot product of 1 - 1e-16 (fp64) or
+        # 1 - 6e-8 (fp32) falls on is rounding.  The difference is along q itself (a change of |q|, which the axes are
+        # quadratic in and the integrator projects out): the torques agree, the raw dU/dq only where nothing is on the kink.
+        gq_d = gq.cpu().double().reshape(-1, 4).numpy()
+        tq, tq_ref = _lab_torque(q, gq_d), _lab_torque(q, gq_ref.numpy())
+        assert np.abs(tq - tq_ref).max() <= max(tol, 1e-8) * gs, (dtype, np.abs(tq - tq_ref).max())
+        if dtype == torch.float64 and not on_kink:
+            assert np.abs(gq_d - gq_ref.numpy()).max() <= 1e-8 * gs
+        s.build_neighbors(cd, 3.25, 0.0)
+        e2 = s.energy(cd, qd)[0].cpu().numpy().reshape(-1)[: len(e_ref)]
+        assert np.abs(e2 - e).max() <= (1e-10 if dtype == torch.float64 else 1e-4) * scale, (dtype, e2, e)
