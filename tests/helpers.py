@@ -250,3 +250,21 @@ _S = 0.5 ** 0.5
 # a3 = e_x, e_y, e_z, e_x (TEST_NORMALS): z -> x is +90 degrees about y, z -> y is -90 degrees about x
 PROPELLER_CALL = {"pairs": [[0, 1], [0, 2], [0, 3]], "quats": [[_S, 0, _S, 0], [_S, -_S, 0, 0], [1, 0, 0, 0], [_S, 0, _S, 0]],
                   "frames": 5, "expected": 120.0}
+
+
+def load_regr(name: str):
+    """oxDNA regression runs the reference ships (tests/golden/regr/<name>): oxDNA2, half-charged ends, average sequence,
+    circular strands.  -> (topology, trajectory, oxDNA's split energies per nucleotide for the trajectory's frames (F, 8),
+    bonded pairs with every ring's closing pair turned into strand direction (last, first))."""
+    base = GOLDEN / "regr" / name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / "sys.top")
+    traj = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=False)
+    split = np.loadtxt(base / "split_energy.dat")  # rows: the start configuration, then one per printed frame
+    n_frames = traj.center.shape[0]
+    bonded = np.asarray(top.bonded_neighbors).copy()
+    closing = np.nonzero(bonded[:, 1] - bonded[:, 0] != 1)[0]
+    turned = bonded.copy()
+    turned[closing] = turned[closing][:, ::-1]
+    return top, traj, split[1 : n_frames + 1, 1:9], turned

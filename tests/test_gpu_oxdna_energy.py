@@ -397,3 +397,53 @@ def test_small_system_definitions_of_the_reference_match_the_oracle(case, conf, 
         s.build_neighbors(cd, 3.25, 0.0)
         e2 = s.energy(cd, qd)[0].cpu().numpy().reshape(-1)[: len(e_ref)]
         assert np.abs(e2 - e).max() <= (1e-10 if dtype == torch.float64 else 1e-4) * scale, (dtype, e2, e)
+
+
+@pytest.mark.parametrize("name", ["circle", "burns-natnano-2015"])
+def test_circular_strands_on_the_gpu_against_the_oracle_and_against_oxdna(name):
+    """The reference's shipped oxDNA runs with circular strands (tests/golden/regr, see tests/test_oracle_golden.py): the
+    kernels against the oracle with the reference's closing pair (first, last) - the second-bond slots of the rows - fp64
+    1e-9 / fp32 1e-3 on terms, forces, torques; and, with the closing pairs in strand direction, against oxDNA's own
+    per-term energies to its printed decimals.  Device-built list and a short run on the ring included."""
+    from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem
+    from oracle import oxdna_oracle as orc
+
+    top, traj, split, turned = H.load_regr(name)
+    n, box = top.n_nucleotides, traj.box_size
+    P = H.oracle_params(2, half_charged_ends=True)
+    seq, is_end, b, u = H.topo_tensors(top)
+    sim, cfg = defaults.default_configs_for("dna2")
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=sim["kT"], salt_conc=0.5, half_charged_ends=True), _lib.param_names())
+    frames = [0, 3, traj.center.shape[0] - 1]
+    for dtype, tol in ((torch.float64, 1e-9), (torch.float32, 1e-3)):
+        for bonded, against_oxdna in ((top.bonded_neighbors, False), (turned, True)):
+            s = OxdnaSystem(2, top.seq, top.is_end, bonded, box=box, dtype=dtype)
+            s.set_params(flat)
+            s.set_neighbors(top.unbonded_neighbors)
+            cd = torch.as_tensor(traj.center[frames], dtype=dtype, device=s.device)
+            qd = torch.as_tensor(traj.quaternions[frames], dtype=dtype, device=s.device)
+            e, gc, gq, _ = s.energy(cd, qd, grads=True)
+            e = e.cpu().numpy().reshape(len(frames), -1)[:, :8]
+            if against_oxdna:
+                assert np.abs(e / n - split[frames]).max() <= (2.5e-6 if dtype == torch.float64 else 2e-5), (dtype, np.abs(e / n - split[frames]).max(0))
+                continue
+            for k, f in enumerate(frames):
+                c, q = torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f])
+                e_ref = orc.energy_terms(2, P, c, q, seq, is_end, b, u, box=box).numpy()
+                _, gc_ref, gq_ref = orc.energy_and_grads(2, P, c, q, seq, is_end, b, u, box=box)
+                assert np.abs(e[k] - e_ref).max() <= tol * np.abs(e_ref).max(), (dtype, f)
+                gs = max(gc_ref.abs().max().item(), gq_ref.abs().max().item())
+                assert (gc[k].cpu().double() - gc_ref).abs().max().item() <= max(tol, 1e-8) * gs
+                assert (gq[k].cpu().double() - gq_ref).abs().max().item() <= max(tol, 1e-8) * gs
+            s.build_neighbors(cd[0], 3.25, 0.0)
+            e2 = s.energy(cd[0], qd[0])[0].cpu().numpy().reshape(-1)[:8]
+            assert np.abs(e2 - e[0]).max() <= (1e-10 if dtype == torch.float64 else 1e-4) * np.abs(e[0]).max()
+            kT = sim["kT"]
+            integ = LangevinIntegrator(s, dt=0.003, kT=kT, gamma_t=kT / sim["diff_coef"], gamma_r=kT / sim["rot_diff_coef"], seed=5)
+            integ.set_neighbor_policy(3.25, 0.6, 20)
+            c0, q0 = cd[-1].clone().contiguous(), qd[-1].clone().contiguous()
+            p, ang = integ.init_momenta()
+            integ.run(c0, q0, p, ang, 200)
+            s.build_neighbors(c0, 3.25, 0.0)
+            e3 = s.energy(c0, q0)[0].cpu().numpy().reshape(-1)[:8]
+            assert torch.isfinite(c0).all() and abs(e3.sum() / n - split[-1].sum()) < 0.15, (dtype, e3.sum() / n, split[-1].sum())
