@@ -52,7 +52,16 @@ REGR = {
     "test-data/regr-circle": ("regr/circle", ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
     "test-data/regr-burns-natnano-2015": ("regr/burns-natnano-2015", ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input", "notes.txt")),
 }
-TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10}
+# ... and three more oxDNA2 runs with oxDNA's split energies that no reference test reads: sequence-dependent stacking / H-bond
+# weights from oxDNA2's parameter file, a three-strand coaxial stack with the strands in the other order, a 12 bp duplex.
+REGR.update({
+    "test-data/simple-helix-oxdna2-ss": ("regr/simple-helix-oxdna2-ss", ("generated.top", "output.dat", "split_energy.dat", "energy.dat", "input",
+                                                                           "oxDNA2_sequence_dependent_parameters.txt")),
+    "test-data/simple-coax-oxdna2-rev": ("regr/simple-coax-oxdna2-rev", ("generated.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
+    "test-data/simple-helix-oxdna2-12bp": ("regr/simple-helix-oxdna2-12bp", ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
+})
+TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
+               ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25}
 SKIP = {"na1": ("pair.dat",)}
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
          # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)

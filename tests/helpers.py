@@ -259,7 +259,7 @@ def load_regr(name: str):
     base = GOLDEN / "regr" / name
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        top = topology.from_oxdna_file(base / "sys.top")
+        top = topology.from_oxdna_file(base / ("sys.top" if (base / "sys.top").exists() else "generated.top"))
     traj = trajectory.from_file(base / "output.dat", top.strand_counts, is_5p_3p=False)
     split = np.loadtxt(base / "split_energy.dat")  # rows: the start configuration, then one per printed frame
     n_frames = traj.center.shape[0]
