@@ -59,9 +59,13 @@ REGR.update({
                                                                            "oxDNA2_sequence_dependent_parameters.txt")),
     "test-data/simple-coax-oxdna2-rev": ("regr/simple-coax-oxdna2-rev", ("generated.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
     "test-data/simple-helix-oxdna2-12bp": ("regr/simple-helix-oxdna2-12bp", ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
+    # oxRNA2 with HALF-charged strand ends (salt 1.0): the reference's rna2 tests run on whole end charges only
+    "test-data/simple-helix-rna2-12bp-half-charged-ends": ("regr/simple-helix-rna2-12bp-half-charged-ends",
+                                                             ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
 })
 TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
-               ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25}
+               ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25,
+               ("regr/simple-helix-rna2-12bp-half-charged-ends", "output.dat"): 25}
 SKIP = {"na1": ("pair.dat",)}
 EXTRA = {("dna1", "simple-helix-seq-dep"): ("generated-new.top", "seq_dep.dat"),
          # 8-nt duplex of the probabilistic-sequence tests (mythos/energy/dna1/tests/test_expected_energies.py:162-328)

@@ -450,7 +450,7 @@ def test_circular_strands_on_the_gpu_against_the_oracle_and_against_oxdna(name):
 
 
 @pytest.mark.parametrize("name, ss_file", [("simple-helix-oxdna2-ss", "oxDNA2_sequence_dependent_parameters.txt"), ("simple-coax-oxdna2-rev", None),
-                                           ("simple-helix-oxdna2-12bp", None)])
+                                           ("simple-helix-oxdna2-12bp", None), ("simple-helix-rna2-12bp-half-charged-ends", None)])
 def test_more_oxdna2_runs_of_the_reference_on_the_gpu(name, ss_file):
     """The three further oxDNA2 runs of tests/test_oracle_golden.py through the kernels: every frame's terms per nucleotide
     against oxDNA's split energies - oxDNA2's own sequence-dependent weights among them - fp64 at the oracle's margins, fp32 1e-4."""
@@ -460,8 +460,9 @@ def test_more_oxdna2_runs_of_the_reference_on_the_gpu(name, ss_file):
         w = H.read_ss_weights(H.GOLDEN / "regr" / name / ss_file)
         ov = {"stacking": {"ss_stack_weights": torch.as_tensor(w["ss_stack_weights"]), "eps_stack_kt_coeff": w["eps_stack_kt_coeff"]},
               "hydrogen_bonding": {"ss_hb_weights": torch.as_tensor(w["ss_hb_weights"])}}
-    for dtype, tight, loose in ((torch.float64, 2.5e-6, 3e-5), (torch.float32, 1e-4, 1e-4)):
-        s = _system(2, top, traj, False, dtype, overrides=ov)
+    rna = "rna2" in name  # (oxRNA2 with half-charged strand ends, salt 1.0)
+    for dtype, tight, loose in ((torch.float64, 2.5e-6, 5e-5), (torch.float32, 1e-4, 1e-4)):
+        s = _system(3 if rna else 2, top, traj, rna, dtype, overrides=ov)
         c, q = _frames(traj, dtype, s.device)
         e = s.energy(c, q)[0].cpu().numpy().reshape(len(split), -1)[:, :8] / top.n_nucleotides
         err = np.abs(e - split).max(0)
