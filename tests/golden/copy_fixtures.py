@@ -63,7 +63,16 @@ REGR.update({
     "test-data/simple-helix-rna2-12bp-half-charged-ends": ("regr/simple-helix-rna2-12bp-half-charged-ends",
                                                              ("sys.top", "output.dat", "split_energy.dat", "energy.dat", "input")),
 })
-TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
+# LAMMPS (Sep 2021, oxdna2 pair styles) runs of a 40 bp duplex under tension and torque at T = 0.1, salt 0.15 - an
+# implementation independent of oxDNA's, at a temperature and a salt concentration no other golden has: the TacoxDNA conversion
+# of its dump (data.oxdna, first TRIM_FRAMES frames), its log with the per-term energies of every dumped step, its input.
+# "-sa": average-sequence strengths, the other: LAMMPS's sequence-dependent tables.
+REGR.update({
+    "test-data/lammps-oxdna2-40bp-sa": ("regr/lammps-oxdna2-40bp-sa", ("data.top", "data.oxdna", "log.lammps", "in")),
+    "test-data/lammps-oxdna2-40bp": ("regr/lammps-oxdna2-40bp", ("data.top", "data.oxdna", "log.lammps", "in", "notes.txt")),
+})
+TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/lammps-oxdna2-40bp-sa", "data.oxdna"): 40,
+               ("regr/lammps-oxdna2-40bp", "data.oxdna"): 12, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
                ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25,
                ("regr/simple-helix-rna2-12bp-half-charged-ends", "output.dat"): 25}
 SKIP = {"na1": ("pair.dat",)}

@@ -268,3 +268,32 @@ def load_regr(name: str):
     turned = bonded.copy()
     turned[closing] = turned[closing][:, ::-1]
     return top, traj, split[1 : n_frames + 1, 1:9], turned
+
+
+def load_lammps_regr(name: str):
+    """LAMMPS oxDNA2 runs the reference ships (tests/golden/regr/lammps-oxdna2-40bp[-sa]): -> (topology, trajectory of the
+    dumped steps (TacoxDNA conversion), per-nucleotide energies of those steps from LAMMPS's log as a dict of arrays:
+    bond (FENE), hb, excv (NON-bonded pairs only: LAMMPS's pair styles skip bonded neighbours), stk, xstk, coax, dh)."""
+    base = GOLDEN / "regr" / name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / "data.top")
+    traj = trajectory.from_file(base / "data.oxdna", top.strand_counts, is_5p_3p=False)
+    rows, on = [], False
+    for ln in (base / "log.lammps").read_text().splitlines():
+        if ln.startswith("v_tns Temp"):  # thermo_style custom v_tns temp evdwl ecoul ebond eangle edihed pe v_cpuh c_hbond c_excv c_stk c_xstk c_coaxstk c_dh
+            on = True
+            continue
+        if on:
+            parts = ln.split()
+            try:
+                vals = [float(x) for x in parts]
+            except ValueError:
+                vals = []
+            if len(vals) == 15:
+                rows.append(vals)
+            else:
+                on = False
+    rows = np.array(rows)[: traj.center.shape[0]]
+    cols = {"bond": 4, "hb": 9, "excv": 10, "stk": 11, "xstk": 12, "coax": 13, "dh": 14}
+    return top, traj, {k: rows[:, c] for k, c in cols.items()}

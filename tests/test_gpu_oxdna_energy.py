@@ -467,3 +467,28 @@ def test_more_oxdna2_runs_of_the_reference_on_the_gpu(name, ss_file):
         e = s.energy(c, q)[0].cpu().numpy().reshape(len(split), -1)[:, :8] / top.n_nucleotides
         err = np.abs(e - split).max(0)
         assert err[[0, 1, 2, 3, 6]].max() <= tight and err[[4, 5, 7]].max() <= loose, (dtype, err)
+
+
+@pytest.mark.parametrize("name, seqdep, tol_stk", [("lammps-oxdna2-40bp-sa", False, 3e-6), ("lammps-oxdna2-40bp", True, 2e-5)])
+def test_lammps_runs_at_another_temperature_and_salt_on_the_gpu(name, seqdep, tol_stk):
+    """The LAMMPS runs of tests/test_oracle_golden.py through the kernels: T = 0.1, salt 0.15 - the stacking strength and
+    the Debye length of conditions no other golden has - per term and dumped step against LAMMPS's own log (fp64 at the
+    oracle's margins, fp32 1e-4).  LAMMPS has no bonded excluded volume; its excluded-volume column is our non-bonded one."""
+    from mythos_amd.hip_system import OxdnaSystem
+
+    top, traj, lam = H.load_lammps_regr(name)
+    n = top.n_nucleotides
+    sim, cfg = defaults.default_configs_for("dna2")
+    if seqdep:
+        w = H.read_ss_weights(H.GOLDEN / "regr" / "simple-helix-oxdna2-ss" / "oxDNA2_sequence_dependent_parameters.txt")
+        cfg["stacking"].update({"ss_stack_weights": torch.as_tensor(w["ss_stack_weights"]), "eps_stack_kt_coeff": w["eps_stack_kt_coeff"]})
+        cfg["hydrogen_bonding"].update({"ss_hb_weights": torch.as_tensor(w["ss_hb_weights"])})
+    flat = fp.pack_flat(fp.derive_flat(2, cfg, kt=0.1, salt_conc=0.15, half_charged_ends=False), _lib.param_names())
+    for dtype, tol, ts in ((torch.float64, 3e-6, tol_stk), (torch.float32, 1e-4, 1e-4)):
+        s = OxdnaSystem(2, top.seq, top.is_end, top.bonded_neighbors, box=traj.box_size, dtype=dtype)
+        s.set_params(flat)
+        s.set_neighbors(top.unbonded_neighbors)
+        c, q = _frames(traj, dtype, s.device)
+        e = s.energy(c, q)[0].cpu().numpy().reshape(traj.center.shape[0], -1)[:, :8] / n
+        for key, col, t in (("bond", 0, tol), ("hb", 4, tol), ("excv", 3, tol), ("stk", 2, ts), ("xstk", 5, tol), ("coax", 6, tol), ("dh", 7, tol)):
+            assert np.abs(e[:, col] - lam[key]).max() <= t, (dtype, key, np.abs(e[:, col] - lam[key]).max())

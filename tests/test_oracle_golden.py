@@ -207,3 +207,30 @@ def test_more_oxdna2_runs_the_reference_ships(name, ss_file):
     err = np.array(err).max(0)
     assert err[[0, 1, 2, 3, 6]].max() <= 2.5e-6 and err[[4, 5, 7]].max() <= 5e-5, err
     assert np.abs(split[:, 6]).max() > (0.01 if "coax" in name else -1.0)  # (the coaxial run has its term switched on)
+
+
+@pytest.mark.parametrize("name, seqdep, tol_stk", [("lammps-oxdna2-40bp-sa", False, 3e-6), ("lammps-oxdna2-40bp", True, 2e-5)])
+def test_lammps_runs_at_another_temperature_and_salt(name, seqdep, tol_stk):
+    """LAMMPS's oxDNA2 - an implementation independent of oxDNA's - on a 40 bp duplex at T = 0.1 (stacking strength
+    1.3523 + 2.6717 T) and salt 0.15 (Debye length), whole end charges; the reference ships dump and log, no test reads
+    them.  Per nucleotide and dumped step: FENE, H-bond, stacking, cross-stacking, coaxial, Debye-Hueckel and the
+    excluded volume of NON-bonded pairs to 3e-6 (stacking 2e-5 with LAMMPS's own sequence-dependent table).  LAMMPS's pair
+    styles skip bonded neighbours, so it has no bonded excluded volume: the oracle's is non-zero on a few steps, as oxDNA's."""
+    top, traj, lam = H.load_lammps_regr(name)
+    n = top.n_nucleotides
+    ov = None
+    if seqdep:
+        w = H.read_ss_weights(H.GOLDEN / "regr" / "simple-helix-oxdna2-ss" / "oxDNA2_sequence_dependent_parameters.txt")
+        ov = {"stacking": {"ss_stack_weights": w["ss_stack_weights"], "eps_stack_kt_coeff": w["eps_stack_kt_coeff"]},
+              "hydrogen_bonding": {"ss_hb_weights": w["ss_hb_weights"]}}
+    P = H.oracle_params(2, half_charged_ends=False, overrides=ov, kt=0.1, salt=0.15)
+    seq, is_end, b, u = H.topo_tensors(top)
+    bexc = []
+    for f in range(traj.center.shape[0]):
+        e = orc.energy_terms(2, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, u,
+                             box=traj.box_size).numpy() / n
+        for key, mine, tol in (("bond", e[0], 3e-6), ("hb", e[4], 3e-6), ("excv", e[3], 3e-6), ("stk", e[2], tol_stk), ("xstk", e[5], 3e-6),
+                               ("coax", e[6], 3e-6), ("dh", e[7], 3e-6)):
+            assert abs(mine - lam[key][f]) <= tol, (f, key, mine, lam[key][f])
+        bexc.append(e[1])
+    assert min(bexc) >= 0.0 and (name != "lammps-oxdna2-40bp-sa" or max(bexc) > 1e-3)
