@@ -71,6 +71,9 @@ REGR.update({
     "test-data/lammps-oxdna2-40bp-sa": ("regr/lammps-oxdna2-40bp-sa", ("data.top", "data.oxdna", "log.lammps", "in")),
     "test-data/lammps-oxdna2-40bp": ("regr/lammps-oxdna2-40bp", ("data.top", "data.oxdna", "log.lammps", "in", "notes.txt")),
 })
+# oxRNA2's model constants as oxDNA's external-model file lists them, the dependent smoothing constants included (the oxRNA2
+# counterpart of data/templates/model_template.h, which holds the DNA ones)
+REGR["test-data/regr-rna2-2ht-293.15-sa"] = ("regr/rna2-external-model", ("external_model.txt",))
 TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/lammps-oxdna2-40bp-sa", "data.oxdna"): 40,
                ("regr/lammps-oxdna2-40bp", "data.oxdna"): 12, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
                ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25,
