@@ -74,7 +74,11 @@ REGR.update({
 # oxRNA2's model constants as oxDNA's external-model file lists them, the dependent smoothing constants included (the oxRNA2
 # counterpart of data/templates/model_template.h, which holds the DNA ones)
 REGR["test-data/regr-rna2-2ht-293.15-sa"] = ("regr/rna2-external-model", ("external_model.txt",))
-TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/lammps-oxdna2-40bp-sa", "data.oxdna"): 40,
+# 60 bp duplexes (120 nt) with oxDNA's total potential energy per printed step: oxDNA1 (only the last configuration was kept) and
+# oxDNA2 with half-charged ends (first TRIM_FRAMES configurations)
+REGR["test-data/simple-helix-60bp"] = ("regr/simple-helix-60bp", ("sys.top", "last_conf.dat", "energy.dat", "input"))
+REGR["test-data/simple-helix-60bp-oxdna2"] = ("regr/simple-helix-60bp-oxdna2", ("sys.top", "output.dat", "energy.dat", "input"))
+TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/simple-helix-60bp-oxdna2", "output.dat"): 8, ("regr/lammps-oxdna2-40bp-sa", "data.oxdna"): 40,
                ("regr/lammps-oxdna2-40bp", "data.oxdna"): 12, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
                ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25,
                ("regr/simple-helix-rna2-12bp-half-charged-ends", "output.dat"): 25}

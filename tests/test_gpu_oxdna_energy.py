@@ -492,3 +492,20 @@ def test_lammps_runs_at_another_temperature_and_salt_on_the_gpu(name, seqdep, to
         e = s.energy(c, q)[0].cpu().numpy().reshape(traj.center.shape[0], -1)[:, :8] / n
         for key, col, t in (("bond", 0, tol), ("hb", 4, tol), ("excv", 3, tol), ("stk", 2, ts), ("xstk", 5, tol), ("coax", 6, tol), ("dh", 7, tol)):
             assert np.abs(e[:, col] - lam[key]).max() <= t, (dtype, key, np.abs(e[:, col] - lam[key]).max())
+
+
+@pytest.mark.parametrize("name, model, hce", [("simple-helix-60bp", 1, False), ("simple-helix-60bp-oxdna2", 2, True)])
+def test_sixty_base_pairs_total_energy_on_the_gpu(name, model, hce):
+    """The 120-nt duplexes of tests/test_oracle_golden.py through the kernels: oxDNA's total potential energy per nucleotide
+    of every kept configuration (fp64 6e-6 - the printed digits of the configurations - fp32 1e-4), all-pairs and device-built list."""
+    from tests.test_oracle_golden import _sixty_bp
+
+    top, traj, want = _sixty_bp(name)
+    for dtype, tol in ((torch.float64, 6e-6), (torch.float32, 1e-4)):
+        s = _system(model, top, traj, hce, dtype)
+        c, q = _frames(traj, dtype, s.device)
+        e = s.energy(c, q)[0].cpu().numpy().reshape(traj.center.shape[0], -1)[:, :8].sum(1) / top.n_nucleotides
+        assert np.abs(e - want).max() <= tol, (dtype, e, want)
+        s.build_neighbors(c[0], 3.25, 0.0)
+        e2 = s.energy(c[:1], q[:1])[0].cpu().numpy().reshape(-1)[:8].sum() / top.n_nucleotides
+        assert abs(e2 - e[0]) <= (1e-10 if dtype == torch.float64 else 1e-5)

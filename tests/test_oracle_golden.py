@@ -234,3 +234,32 @@ def test_lammps_runs_at_another_temperature_and_salt(name, seqdep, tol_stk):
             assert abs(mine - lam[key][f]) <= tol, (f, key, mine, lam[key][f])
         bexc.append(e[1])
     assert min(bexc) >= 0.0 and (name != "lammps-oxdna2-40bp-sa" or max(bexc) > 1e-3)
+
+
+def _sixty_bp(name):
+    import warnings
+
+    from mythos_amd.input import topology, trajectory
+
+    base = H.GOLDEN / "regr" / name
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        top = topology.from_oxdna_file(base / "sys.top")
+    last = name == "simple-helix-60bp"
+    traj = trajectory.from_file(base / ("last_conf.dat" if last else "output.dat"), top.strand_counts, is_5p_3p=False)
+    en = np.loadtxt(base / "energy.dat")  # time, potential, kinetic, total - per nucleotide; row 0 is the start configuration
+    want = en[-1:, 1] if last else en[1 : traj.center.shape[0] + 1, 1]
+    return top, traj, want
+
+
+@pytest.mark.parametrize("name, model, hce", [("simple-helix-60bp", 1, False), ("simple-helix-60bp-oxdna2", 2, True)])
+def test_sixty_base_pairs_total_energy_against_oxdna(name, model, hce):
+    """120-nt duplexes of the reference's data with oxDNA's total potential energy per nucleotide (energy.dat; six decimals;
+    configurations are printed with fewer digits than they were evaluated with: 6e-6)."""
+    top, traj, want = _sixty_bp(name)
+    P = H.oracle_params(model, half_charged_ends=hce)
+    seq, is_end, b, u = H.topo_tensors(top)
+    for f in range(traj.center.shape[0]):
+        e = orc.energy_terms(model, P, torch.as_tensor(traj.center[f]), torch.as_tensor(traj.quaternions[f]), seq, is_end, b, u,
+                             box=traj.box_size).numpy().sum() / top.n_nucleotides
+        assert abs(e - want[f]) <= 6e-6, (f, e, want[f])  # (the reference holds its own totals to rtol 1e-5)
