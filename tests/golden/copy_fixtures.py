@@ -78,6 +78,8 @@ REGR["test-data/regr-rna2-2ht-293.15-sa"] = ("regr/rna2-external-model", ("exter
 # oxDNA2 with half-charged ends (first TRIM_FRAMES configurations)
 REGR["test-data/simple-helix-60bp"] = ("regr/simple-helix-60bp", ("sys.top", "last_conf.dat", "energy.dat", "input"))
 REGR["test-data/simple-helix-60bp-oxdna2"] = ("regr/simple-helix-60bp-oxdna2", ("sys.top", "output.dat", "energy.dat", "input"))
+# the sequence-dependence files the reference ships for its users (input/sequence_dependence.py reads them)
+REGR["seq-specific"] = ("seq-specific", ("seq_oxdna1.txt", "seq_oxdna2.txt"))
 TRIM_FRAMES = {("regr/burns-natnano-2015", "output.dat"): 10, ("regr/simple-helix-60bp-oxdna2", "output.dat"): 8, ("regr/lammps-oxdna2-40bp-sa", "data.oxdna"): 40,
                ("regr/lammps-oxdna2-40bp", "data.oxdna"): 12, ("regr/simple-helix-oxdna2-ss", "output.dat"): 25,
                ("regr/simple-coax-oxdna2-rev", "output.dat"): 25, ("regr/simple-helix-oxdna2-12bp", "output.dat"): 25,

@@ -287,3 +287,22 @@ def test_simulator_batches_independent_replicas_in_one_launch():
     box_disp, box_shift = space.periodic(traj.box_size)
     with pytest.raises(ValueError, match="free space"):
         dc.replace(sim, energy_fn=mod.create_default_energy_fn(top, box_disp), space=(box_disp, box_shift)).run({}, init, 5, key=1)
+
+
+def test_sequence_dependent_energy_function_from_the_references_file():
+    """The drop-in route to sequence-dependent weights, as a user of the reference takes it: `read_ss_weights(file)` into
+    `with_params` of the default oxDNA2 energy function (mythos/input/sequence_dependence.py:12-51), evaluated with `map` over
+    oxDNA's own sequence-dependent run (tests/golden/regr/simple-helix-oxdna2-ss): oxDNA's total per nucleotide, 25 frames."""
+    from mythos_amd.energy import dna2
+    from mythos_amd.input.sequence_dependence import read_ss_weights
+    from tests import helpers as H
+
+    top, traj, split, _ = H.load_regr("simple-helix-oxdna2-ss")
+    disp, _ = space.periodic(traj.box_size)
+    w = read_ss_weights(H.GOLDEN / "seq-specific" / "seq_oxdna2.txt")
+    ef = dna2.create_default_energy_fn(top, disp).with_params(half_charged_ends=False, **w)
+    body = RigidBody(center=torch.as_tensor(traj.center, device="cuda"), orientation=Quaternion(vec=torch.as_tensor(traj.quaternions, device="cuda")))
+    e = ef.map(body).cpu().numpy() / top.n_nucleotides
+    assert e.shape == (25,) and np.abs(e - split.sum(1)).max() <= 3e-5, np.abs(e - split.sum(1)).max()
+    plain = dna2.create_default_energy_fn(top, disp).with_params(half_charged_ends=False).map(body).cpu().numpy() / top.n_nucleotides
+    assert np.abs(plain - split.sum(1)).max() > 1e-3  # (the average-sequence model is a different function)

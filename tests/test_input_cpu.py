@@ -235,3 +235,36 @@ def test_system_definitions_the_reference_ships_read_as_relaxed_duplexes(name, t
         assert np.isfinite(e).all() and -1.6 < e.sum() / n < -1.4, (model, e)
         # terms: fene, bonded excl., stacking, unbonded excl., H-bond, cross-stacking, coaxial (, Debye)
         assert e[0] > 0 and -1.25 < e[2] / n < -1.05 and -0.40 < e[4] / n < -0.28 and -0.14 < e[5] / n < -0.09 and abs(e[6]) < 1e-6
+
+
+def test_sequence_dependence_files_read_like_the_reference(tmp_path):
+    """mythos_amd.input.sequence_dependence.read_ss_weights (mythos/input/sequence_dependence.py:12-51): the two files the
+    reference ships for its users, the goldens' own, the `f` suffix and white space, one member of a Watson-Crick pair
+    standing for both, a missing entry as a KeyError."""
+    from mythos_amd.input.sequence_dependence import read_ss_weights
+    from tests import helpers as H
+
+    for path in (GOLDEN / "seq-specific" / "seq_oxdna1.txt", GOLDEN / "seq-specific" / "seq_oxdna2.txt",
+                 GOLDEN / "dna1" / "simple-helix-seq-dep" / "seq_dep.dat"):
+        got, want = read_ss_weights(path), H.read_ss_weights(path)
+        assert set(got) == {"eps_stack_kt_coeff", "ss_stack_weights", "ss_hb_weights"}
+        assert got["ss_stack_weights"].dtype.is_floating_point and got["ss_stack_weights"].shape == (4, 4)
+        for k in got:
+            assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), (path.name, k)
+        hb = np.asarray(got["ss_hb_weights"])
+        assert np.count_nonzero(hb) == 4 and np.array_equal(hb, hb.T) and hb[0, 3] > 0 and hb[1, 2] > 0  # A-T, C-G (A, C, G, T)
+    w2 = read_ss_weights(GOLDEN / "seq-specific" / "seq_oxdna2.txt")
+    assert float(w2["eps_stack_kt_coeff"]) == 0.18 and float(w2["ss_stack_weights"][0, 0]) == 1.84642  # STCK_A_A
+    lines = [ln for ln in (GOLDEN / "seq-specific" / "seq_oxdna2.txt").read_text().splitlines() if ln.strip()]
+    odd = tmp_path / "odd.txt"
+    odd.write_text("\n".join(("  " + ln.replace(" = ", "=") + "f" if k % 2 else ln) for k, ln in enumerate(lines)
+                             if not ln.startswith(("HYDR_T_A", "HYDR_G_C"))) + "\n\n")
+    w3 = read_ss_weights(odd)
+    for k in w2:
+        assert np.array_equal(np.asarray(w3[k]), np.asarray(w2[k])), k
+    odd.write_text("\n".join(ln for ln in lines if not ln.startswith("STCK_G_A")))
+    with pytest.raises(KeyError, match="STCK_G_A"):
+        read_ss_weights(odd)
+    odd.write_text("\n".join(ln for ln in lines if not ln.startswith(("HYDR_A_T", "HYDR_T_A"))))
+    with pytest.raises(KeyError, match="HYDR_T_A"):
+        read_ss_weights(odd)
