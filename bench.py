@@ -62,9 +62,9 @@ from mythos_amd.energy import flat_params as fp  # noqa: E402
 from mythos_amd.hip_system import LangevinIntegrator, OxdnaSystem  # noqa: E402
 from mythos_amd.input import defaults  # noqa: E402
 from mythos_amd.utils import generators  # noqa: E402
+from mythos_amd.utils.units import PS_PER_OXDNA_TIME as OXDNA_TIME_UNIT_PS  # noqa: E402  (3.03: oxDNA simulation time unit)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-OXDNA_TIME_UNIT_PS = 3.03  # oxDNA simulation time unit
 R_CUT = 3.25  # largest centre-centre interaction range: Debye r_cut 2.2867 + 2 * |backbone offset| 0.4814
 
 

@@ -281,3 +281,19 @@ def test_bench_strings_fit_the_drivers_parsed_record():
         assert len(txt) <= 120 and f"{n} x {steps} steps" in txt and "f64 40.7k" in txt and "steps / total time" in txt
         launches = n * (steps + (1 if save_every and steps % save_every == 0 else 0))
         assert f"= {launches} launches" in txt and f"+ {n * (steps // 50)} list rebuilds" in txt
+
+
+def test_units_as_the_reference_defines_them():
+    """mythos_amd.utils.units mirrors mythos/utils/units.py:5-38; the defaults of the package are at its 296.15 K."""
+    from mythos_amd.input import defaults
+    from mythos_amd.utils import units
+
+    assert units.NM_PER_OXDNA_LENGTH == pytest.approx(0.8518) and units.PN_PER_OXDNA_FORCE == 48.63 and units.JOULES_PER_OXDNA_ENERGY == 4.142e-20
+    assert units.get_kt(300.0) == pytest.approx(0.1) and units.get_kt_from_c(23.0) == pytest.approx(units.get_kt(296.15))
+    assert units.get_kt_from_string("296.15K") == pytest.approx(0.0987166666) and units.get_kt_from_string("23C") == pytest.approx(units.get_kt(296.15))
+    assert units.from_kt(units.get_kt(310.0)) == pytest.approx(310.0)
+    assert np.allclose(units.get_kt(np.array([300.0, 330.0])), [0.1, 0.11])
+    with pytest.raises(ValueError, match="Invalid temperature string"):
+        units.get_kt_from_string("300")
+    sim, _ = defaults.default_configs_for("dna2")
+    assert sim["kT"] == pytest.approx(units.get_kt(296.15))
