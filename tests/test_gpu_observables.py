@@ -242,3 +242,20 @@ def test_difftre_loss_and_gradient_are_unchanged_by_fusing_the_observable():
     assert float(l0) == float(l1) and float(n0) == float(n1)
     for k in opt:
         assert float(g0[k]) == float(g1[k])
+
+
+def test_observable_loss_wrapper_on_a_hip_observable():
+    """mythos_amd.losses.observable_wrappers.ObservableLossFn (the reference's class) around the HIP propeller twist:
+    the weighted mean of the kernel's per-state values, the squared error to a target, and its gradient to the weights."""
+    from mythos_amd.losses import observable_wrappers as ow
+
+    top, traj = _thermal_duplex(12, 7)
+    half = top.n_nucleotides // 2
+    pairs = np.stack([np.arange(half), top.n_nucleotides - 1 - np.arange(half)], axis=1)[1:-1]
+    pt = PropellerTwist(pairs)
+    per_state = pt(traj).double()
+    w = torch.full((7,), 1.0 / 7, dtype=torch.float64, device=per_state.device, requires_grad=True)
+    loss, mean = ow.ObservableLossFn(observable=pt, loss_fn=ow.SquaredError(), return_observable=True)(traj, torch.tensor(21.7, dtype=torch.float64, device=per_state.device), w)
+    assert float(mean.detach()) == pytest.approx(float(per_state.mean()), rel=1e-12) and float(loss.detach()) == pytest.approx((21.7 - float(per_state.mean())) ** 2, rel=1e-12)
+    loss.backward()
+    assert torch.allclose(w.grad, -2.0 * (21.7 - per_state.mean()) * per_state, rtol=1e-12)

@@ -182,3 +182,34 @@ def test_persistence_length_fit_needs_two_lags():
         persistence_length_fit(torch.tensor([0.9]), 0.4)
     lp, off = persistence_length_fit(torch.exp(-0.4 * torch.arange(6, dtype=torch.float64) / 120.0), 0.4)
     assert abs(float(lp) - 120.0) < 1e-9 and abs(float(off)) < 1e-12
+
+
+def test_loss_wrappers_as_the_reference_tests_them():
+    """mythos_amd.losses.observable_wrappers against the known answers of mythos/losses/tests/test_observable_wrapper.py:
+    the base class refuses, SquaredError element-wise and on scalars, ObservableLossFn with and without the observable."""
+    import numpy as np
+    import torch
+
+    from mythos_amd.losses import observable_wrappers as ow
+
+    with pytest.raises(NotImplementedError):
+        ow.LossFn()(None, None, None)
+    for x, y, want in ((torch.arange(5), torch.ones(5), (torch.arange(5) - torch.ones(5)) ** 2), (torch.tensor(2), torch.tensor(1), torch.tensor(1)),
+                       (torch.tensor(0), torch.tensor(0), torch.tensor(0))):
+        assert torch.equal(ow.SquaredError()(x, y).double(), want.double())
+    assert float(ow.RootMeanSquaredError()(torch.tensor([1.0, 3.0]), torch.tensor([0.0, 0.0]))) == pytest.approx(np.sqrt(5.0))
+    assert float(ow.l2_loss(torch.tensor([1.0, 3.0]), torch.tensor([0.0, 1.0]))) == 5.0
+    traj = torch.tensor([[1, 1, 1], [2, 2, 2], [3, 3, 3]], dtype=torch.float64)
+    weights = torch.ones(3, dtype=torch.float64) / 3
+    want_obs = (traj.sum(1) * weights).sum()
+    for ret in (True, False):
+        out = ow.ObservableLossFn(observable=lambda t: t.sum(1), loss_fn=lambda actual, target: actual - target, return_observable=ret)(
+            trajectory=traj, target=torch.tensor(1.0), weights=weights)
+        assert isinstance(out, tuple) and len(out) == (2 if ret else 1) and float(out[0]) == pytest.approx(float(want_obs) - 1.0)
+        if ret:
+            assert float(out[1]) == pytest.approx(float(want_obs))
+    # the loss carries a gradient to the weights (what DiffTRe differentiates)
+    w = weights.clone().requires_grad_(True)
+    (loss,) = ow.ObservableLossFn(observable=lambda t: t.sum(1), loss_fn=ow.SquaredError())(traj, torch.tensor(5.0), w)
+    loss.backward()
+    assert torch.allclose(w.grad, -2.0 * (5.0 - want_obs) * traj.sum(1))
