@@ -103,10 +103,30 @@ __host__ __device__ __forceinline__ void axpy(V3<R>& y, R a, V3<R> x) {
 }
 
 __device__ __forceinline__ float m_sqrt(float x) { return sqrtf(x); }
-__device__ __forceinline__ double m_sqrt(double x) { return sqrt(x); }
+// fp64 square root (round 4): the compiler's expansion of sqrt(double) is v_rsq_f64 and two and a half coupled Newton steps
+// - the ten instructions below - wrapped in a scaling of inputs under 2^-767 (compare, select, two ldexp) and a class test that
+// puts 0, inf and NaN back (20 instructions in all, 44 square roots in md_step_kernel<double, 2>).  The arguments here are
+// squared lengths and 1 - c^2: never that small, never infinite; zero is possible and is put back by one select.  Same
+// arithmetic, same bits for every argument in range.  (The host build of these templates - oracle/cpu_port - takes libm's.)
+__device__ __forceinline__ double m_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return x == 0.0 ? 0.0 : g;
+#else
+  return sqrt(x);
+#endif
+}
 __device__ __forceinline__ float m_rsqrt(float x) { return rsqrtf(x); }
 // (the library's rsqrt - v_rsq_f64 + refinement - measured 1.4 % SLOWER per fp64 MD step than this form)
-__device__ __forceinline__ double m_rsqrt(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double m_rsqrt(double x) { return 1.0 / m_sqrt(x); }
 __device__ __forceinline__ float m_exp(float x) { return __expf(x); }
 __device__ __forceinline__ double m_exp(double x) { return exp(x); }
 __device__ __forceinline__ float m_log(float x) { return __logf(x); }

@@ -15,7 +15,9 @@ global_*, scratch_*, buffer_*, flat_*).
 
 usage: check_exec0_reloads.py file.s [...]      exit code 1 if anything is reported
        check_exec0_reloads.py --lib libmythos_hip.so    the same scan over the disassembly of every gfx950 code object
-                                                        inside the built library (what tests/test_build_cpu.py runs)
+                                                        inside the built library (what tests/test_api_cpu.py runs)
+       check_exec0_reloads.py --scratch libmythos_hip.so   kernels of the built library that use scratch memory (both wrong
+                                                        results of round 4 went with spill code at a register bound)
 """
 import re
 import struct
@@ -154,7 +156,42 @@ def scan_library(lib_path):
     return found
 
 
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernels_with_scratch(lib_path):
+    """{kernel symbol: private segment bytes} for every kernel of the library that has any (the code objects' metadata)."""
+    out = {}
+    if not Path(READELF).exists():
+        print(f"check_exec0_reloads: {READELF} not found, scratch listing skipped", file=sys.stderr)
+        return out
+    with tempfile.TemporaryDirectory() as tmp:
+        for k, obj in enumerate(code_objects(lib_path)):
+            f = Path(tmp) / f"co{k}.elf"
+            f.write_bytes(obj)
+            notes = subprocess.run([READELF, "--notes", str(f)], check=True, capture_output=True, text=True).stdout
+            name = None
+            size = 0
+            for ln in notes.split("\n"):
+                t = ln.strip()
+                if t.startswith("- .agpr_count:") or t.startswith("- .args:"):
+                    name, size = None, 0
+                if t.startswith(".private_segment_fixed_size:"):
+                    size = int(t.split(":")[1])
+                if t.startswith(".name:"):
+                    name = t.split(":", 1)[1].strip()
+                if t.startswith(".symbol:") and name is not None and size > 0:
+                    out[name] = size
+    return out
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--scratch":
+        rows = kernels_with_scratch(sys.argv[2])
+        for name, size in sorted(rows.items()):
+            print(f"{size:5d} B  {name[:120]}")
+        print(f"{len(rows)} kernel(s) with scratch")
+        return 0
     if len(sys.argv) == 3 and sys.argv[1] == "--lib":
         hits = scan_library(sys.argv[2])
         for name, addr, text in hits:
